@@ -1,0 +1,79 @@
+"""MolecularHamiltonian: the `hamil.local_energy` surface of the hot path.
+
+Host-side integer logic follows reference src/deepqmc/hamil.py:32-41 (`get_shell`) and
+hamil.py:108-154 (`MolecularHamiltonian.__init__`: valence counts, n_up/n_down, shells).
+`local_energy(ansatz)` (hamil.py:156-184) returns a callable with the reference's
+signature `(rng, params, phys_conf) -> (E_loc, stats)`; the arithmetic runs in the HIP
+library through `deepqmc_amd.engine.Engine` -- there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from itertools import count
+from typing import Optional
+
+import numpy as np
+
+from .molecule import Molecule
+
+STAT_KEYS = (
+    'hamil/V_el', 'hamil/E_kin', 'hamil/V_loc', 'hamil/V_nl', 'hamil/lap',
+    'hamil/quantum_force',
+)  # hamil.py:173-180
+
+
+def get_shell(z) -> int:
+    """Number of (at least partially) occupied shells for z electrons (hamil.py:32-41)."""
+    max_elec = 0
+    n = 0
+    for n in count():
+        if z <= max_elec:
+            break
+        max_elec += 2 * (1 + n) ** 2
+    return n
+
+
+class MolecularHamiltonian:
+    """hamil.py:70-154.  Only the all-electron Coulomb potential is available in this
+    round (`ecp_type=None`); requesting an ECP raises NotImplementedError (the
+    coefficient tables live in pyscf, which is absent -- SURVEY.md section 8c)."""
+
+    def __init__(self, *, mol: Molecule, ecp_type: Optional[str] = None,
+                 ecp_mask=None, elec_std: float = 1.0):
+        self.mol = mol
+        self.elec_std = elec_std
+        self.ecp_type = ecp_type
+        if ecp_type is None:
+            ecp_mask = [False] * len(mol.charges)          # hamil.py:120-121
+        elif ecp_mask is None:
+            ecp_mask = list(mol.charges > 2)               # hamil.py:122-124
+        assert len(ecp_mask) == len(mol.charges), "Incompatible shape of 'ecp_mask'!"
+        self.ecp_mask = np.asarray(ecp_mask, bool)
+        if self.ecp_mask.any():
+            raise NotImplementedError(
+                'effective core potentials are not part of this round (pyscf tables absent)')
+        self.ns_valence = np.asarray(mol.charges, np.float64)   # physics.py:127-129
+        n_elec = int(sum(self.ns_valence) - mol.charge)         # hamil.py:142
+        assert not (n_elec + mol.spin) % 2
+        assert n_elec > 1, 'The system must contain at least two active electrons.'
+        self.n_nuc = len(mol.charges)
+        self.n_up = (n_elec + mol.spin) // 2
+        self.n_down = (n_elec - mol.spin) // 2
+        self.mol_shells = [get_shell(z) for z in mol.charges]
+        self.mol_ecp_shells = [get_shell(z + 1) - 1 for z in mol.charges - self.ns_valence]
+
+    @property
+    def n_elec(self) -> int:
+        return self.n_up + self.n_down
+
+    def local_energy(self, ansatz):
+        """hamil.py:156-184.  `ansatz` is a `deepqmc_amd.wf.NeuralNetworkWaveFunction`
+        bound to this Hamiltonian.  Returns `loc_ene(rng, params, phys_conf)` which
+        evaluates a whole batch phys_conf.r[B,N,3] on the GPU and returns
+        (E_loc[B], stats{key: [B]}) -- the reference's per-walker function vmapped over
+        the electron batch (loss/energy.py:50-57)."""
+        assert ansatz.hamil is self
+
+        def loc_ene(rng, params, phys_conf):
+            return ansatz.engine(params).local_energy(phys_conf, rng=rng)
+
+        return loc_ene
