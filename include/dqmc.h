@@ -1,0 +1,187 @@
+/*
+ * dqmc.h -- C ABI of libdqmc_hip.so, the MI355X (gfx950) local-energy / MCMC evaluator.
+ *
+ * The reference (deepqmc/deepqmc) has no FFI boundary: its hot path is a set of Python
+ * callables.  Each entry point below replaces one of them; the
+ * reference-side binding a maintainer would add is the ctypes stub in INTEGRATION.md.
+ *
+ *   dqmc_wf_eval        <- ansatz.apply(params, phys_conf) -> Psi(sign, log)
+ *                          reference src/deepqmc/types.py:107-150,
+ *                          wf/nn_wave_function.py:127-173 (vmapped over walkers at
+ *                          sampling/electron_samplers.py:76-81)
+ *   dqmc_local_energy   <- hamil.local_energy(ansatz)(rng, params, phys_conf)
+ *                          hamil.py:156-184, vmapped over walkers at loss/energy.py:50-57
+ *   dqmc_mcmc_steps     <- DecorrSampler.sample / MetropolisSampler.sample
+ *                          sampling/electron_samplers.py:140-163,347-357
+ *   dqmc_energy_stats   <- EnergyMonitor's mean/std/min/max, observable.py:474-479
+ *                          (per-rank partial record; ranks merge them after one all-gather)
+ *   dqmc_set_weights    <- a new `params` tree after an optimiser step
+ *
+ * Conventions: plain pointers and sizes only.  Unless marked "host", every pointer is a
+ * DEVICE pointer.  Walker-major contiguous layouts: r[B][N][3], R[n_nuc][3].  `real` is
+ * float (dtype 0) or double (dtype 1), fixed per context.  Every function returns 0 on
+ * success or a negative DQMC_E_* code and never throws; dqmc_last_error() gives a message.
+ * A context is bound to one device and is not thread-safe; use one context per GPU.
+ * All work is enqueued on the stream given at creation (0 = the null stream); functions
+ * that return host values synchronise that stream.
+ */
+#ifndef DQMC_H
+#define DQMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQMC_OK 0
+#define DQMC_E_ARG (-1)     /* invalid argument / malformed program */
+#define DQMC_E_HIP (-2)     /* a HIP runtime call failed */
+#define DQMC_E_NOMEM (-3)
+#define DQMC_E_UNSUPPORTED (-4)
+
+/* ---- the layer program ------------------------------------------------------------
+ * The wave function is handed over as a flat list of ops acting on per-walker
+ * activation buffers.  Activation buffer b has `rows` rows per walker and `width`
+ * features per row (width % 4 == 0, zero padded); in memory it is
+ * real[B][rows][TP][width], TP = number of forward-Laplacian lanes: lane 0 = value,
+ * lanes 1..3N = d/dr_c, lane 3N+1 = Laplacian, further lanes zero padding.  TP = 1 for
+ * value-only evaluation (dqmc_wf_eval, MCMC); TP = round_up(3N+2, 16) for the local
+ * energy.  Weight offsets index the `real` weight buffer, table offsets the int32 table. */
+
+typedef struct dqmc_buf {
+  int32_t rows;
+  int32_t width;
+} dqmc_buf;
+
+enum dqmc_op_kind {
+  /* i: [0]=dst buf [1]=log_rescale [2]=use_spin. Electron-nucleus input features
+   * (gnn/electron_gnn.py:596-625): row i = [|d|,dx,dy,dz] per nucleus (+ spin). */
+  DQMC_OP_FEAT_EN = 1,
+  /* i: [0]=dst buf [1]=table offset of (recv,send) int pairs [2]=n_edge_rows
+   * [3]=log_rescale.  Electron-electron edge features d = r_recv - r_send
+   * (gnn/graph.py:23-31, gnn/edge_features.py:21-123). */
+  DQMC_OP_FEAT_EE = 2,
+  /* Forward-Laplacian linear layer y = act(concat(pieces) W + b) (+ residual).
+   * i: [0]=n_pieces, then per piece p (p<4) at [1+4p..]: src buf, r0, K (unpadded
+   * width used), bcast (1: every dst row of a walker reads src row r0);
+   * [17]=dst buf [18]=dst r0 [19]=dst col0 [20]=nrows (per walker) [21]=Nout
+   * [22]=W offset [23]=bias offset or -1 [24]=act (0 none,1 tanh,2 silu)
+   * [25]=residual buf or -1 [26]=residual r0.   f: [0]=residual scale
+   * (out = (res + y) * scale).  W is row-major [sum_p pad4(K_p)][pad4(Nout)]. */
+  DQMC_OP_LINEAR = 3,
+  /* i: [0]=src buf [1]=dst buf (rows = 2) [2]=n_up.  Mean over up / down electrons
+   * (gnn/update_features.py:86-102). */
+  DQMC_OP_SPIN_MEAN = 4,
+  /* i: [0]=edge buf (we) [1]=node buf (hx) [2]=dst buf [3]=dst col0 [4]=table offset of
+   * int [N][S][2] (edge row, sender; -1 = none) [5]=S [6]=width.
+   * out[i] = sum_s we[row(i,s)] * hx[send(i,s)] (gnn/graph.py:226-335). */
+  DQMC_OP_CONV = 5,
+  /* i: as CONV without node buf ([1] unused).  f: [0]=scale.  out[i] = scale *
+   * sum_s e[row(i,s)] (EdgeSum, gnn/update_features.py:109-159). */
+  DQMC_OP_EDGE_SUM = 6,
+  /* i: [0]=src buf [1]=dst buf (rows = 1).  Sum over all rows (Jastrow sum_first,
+   * wf/omni.py:35-40). */
+  DQMC_OP_ROW_SUM = 7,
+  /* i: [0]=backflow buf ([N][pad4(K*N)], column k*N+mu) [1]=dst buf (rows=K,
+   * width=pad4(N*N), column i*N+mu) [2..5]=weight offsets of pi_up, pi_down, zetas_up,
+   * zetas_down ([K*N][n_nuc]).  Slater matrix entries A = envelope * backflow
+   * (wf/env.py:57-75, wf/nn_wave_function.py:135-147). */
+  DQMC_OP_ORBITALS = 8,
+  /* i: [0]=orbital buf.  sign/log|det| of the K matrices and their forward-Laplacian
+   * lanes, kept in double inside the context (wf/nn_wave_function.py:36-39). */
+  DQMC_OP_SLOGDET = 9,
+  /* i: [0]=jastrow buf or -1 [1]=conf_coeff weight offset or -1 (SumPool) [2]=cusp kind
+   * (0 none,1 deepqmc,2 psiformer) [3]=weight offset of {same_alpha, anti_alpha}.
+   * f: [0]=same_scale [1]=anti_scale.  CI sum + cusps + Jastrow
+   * (wf/nn_wave_function.py:152-171); in Laplacian mode also the potentials and E_loc
+   * (hamil.py:160-182, physics.py:105-133). */
+  DQMC_OP_FINAL = 10,
+  /* Multi-head self attention over the electrons of a walker, forward-Laplacian form
+   * (hk.MultiHeadAttention called at gnn/update_features.py:273-278).
+   * i: [0]=q buf [1]=k buf [2]=v buf [3]=dst buf [4]=heads [5]=head_dim. */
+  DQMC_OP_ATTENTION = 11
+};
+
+typedef struct dqmc_op {
+  int32_t kind;
+  int32_t i[27];
+  float f[4];
+} dqmc_op;
+
+typedef struct dqmc_system {
+  int32_t n_up, n_down, n_nuc, n_det;
+  int32_t dtype;        /* 0 = float32, 1 = float64 */
+  int32_t reserved;
+  double norm_eps;      /* eps under the safe norm, utils.py:79-85 (finfo(dtype).eps) */
+  double e_nuc;         /* nuclear repulsion, physics.py:112-116 (constant per geometry) */
+} dqmc_system;
+
+typedef struct dqmc_ctx dqmc_ctx;
+
+/* Create a context on `device`.  charges: host double[n_nuc].  weights: host double[]
+ * (converted to `real` on upload).  itable: host int32[].  stream: a hipStream_t (or 0). */
+int dqmc_create(dqmc_ctx** out, int device, void* stream, const dqmc_system* sys,
+                const double* charges_host, const dqmc_buf* bufs_host, int n_bufs,
+                const dqmc_op* ops_host, int n_ops, const double* weights_host,
+                size_t n_weights, const int32_t* itable_host, size_t n_itable);
+void dqmc_destroy(dqmc_ctx* ctx);
+const char* dqmc_last_error(void);
+
+/* Replace the weight buffer (same length as at creation).  host double[]. */
+int dqmc_set_weights(dqmc_ctx* ctx, const double* weights_host, size_t n_weights);
+
+/* psi for B walkers.  r: real[B][N][3], R: real[n_nuc][3]; out logpsi: real[B],
+ * sign: int32[B] (values -1, 0, +1; bit-exact item of the parity contract). */
+int dqmc_wf_eval(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logpsi, int32_t* sign);
+
+/* Local energy for B walkers.  e_loc: real[B]; stats: real[6][B] in the order V_el, E_kin,
+ * V_loc, V_nl, lap, quantum_force (hamil.py:173-180), may be NULL; grad: real[B][3N]
+ * (d log|psi| / dr, the quantum force), may be NULL; logpsi/sign may be NULL. */
+int dqmc_local_energy(dqmc_ctx* ctx, const void* r, const void* R, int B, void* e_loc,
+                      void* stats, void* grad, void* logpsi, int32_t* sign);
+
+/* n_sub Metropolis sub-steps, in place on the sampler state
+ * (sampling/electron_samplers.py:102-138,347-357).
+ *   r real[B][N][3], logpsi real[B], sign int32[B], age int32[B], tau real[1] (device).
+ *   max_age < 0: off.  target_acceptance <= 0: tau not adapted.
+ *   noise: real[n_sub][B][N][3] standard normals and unif: real[n_sub][B] in [0,1), or
+ *   both NULL to draw them on the device from Philox4x32-10 keyed by (seed, sub-step).
+ *   accept_out: uint8[n_sub][B] accept decisions or NULL.
+ *   stats7_host: host double[7] = acceptance, tau, age mean, age max, log|psi| mean,
+ *   log|psi| std, mean e-e distance of the LAST sub-step (electron_samplers.py:154-163),
+ *   or NULL (then the call does not synchronise). */
+int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age,
+                    void* tau, const void* R, int B, int n_sub, int max_age,
+                    double target_acceptance, uint64_t seed, const void* noise,
+                    const void* unif, uint8_t* accept_out, double* stats7_host);
+
+/* Per-rank partial record of the energy reduction: host double[7] =
+ * {n, sum_w, sum_wE, sum_E, M2 (sum of squared deviations from this rank's mean), min,
+ * max}.  w may be NULL (all ones).  Ranks all-gather the 56-byte records (RCCL) and
+ * merge them with dqmc_merge_energy_stats. */
+int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, double* out7_host);
+/* Chan merge of n_ranks records -> host double[5] = mean, std (population), min, max,
+ * weighted mean.  Pure host arithmetic. */
+int dqmc_merge_energy_stats(const double* records_host, int n_ranks, double* out5_host);
+
+/* Debug / test access: copy activation buffer `buf` of the last evaluation (layout
+ * real[B][rows][TP][width]) to host as double[].  n must equal B*rows*TP*width.
+ * buf = -1: log|det| lanes double[B][K][TP]; buf = -2: det signs as double[B][K]. */
+int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out_host, size_t n);
+/* Lanes (TP) used by the last evaluation. */
+int dqmc_debug_lanes(dqmc_ctx* ctx);
+
+/* Per-kernel timing (HIP events on the context's stream).  enable != 0 starts recording
+ * every launch; dqmc_timing_get returns total ms / launch count / algorithmic flops of the
+ * kernel class `name` ("linear", "slogdet", ...) accumulated since the last reset. */
+int dqmc_timing_enable(dqmc_ctx* ctx, int enable);
+int dqmc_timing_reset(dqmc_ctx* ctx);
+int dqmc_timing_get(dqmc_ctx* ctx, const char* name, double* ms, int64_t* launches, double* flops);
+int dqmc_timing_names(dqmc_ctx* ctx, char* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQMC_H */
