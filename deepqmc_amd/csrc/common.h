@@ -1,0 +1,112 @@
+// common.h -- shared device helpers for the gfx950 local-energy kernels.
+//
+// Activation layout (include/dqmc.h): real X[B][rows][TP][width]; element
+// (b,row,t,col) at ((b*rows + row)*TP + t)*width + col.  Lane t = 0 is the value,
+// t = 1..3N the derivative w.r.t. electron coordinate c = t-1, t = 3N+1 the Laplacian.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dqmc {
+
+struct LaneInfo {
+  int T;    // used lanes (1 or 3N+2)
+  int TP;   // allocated lanes (1 or round_up(T,16))
+  int N;    // electrons
+};
+
+// MFMA 16x16x4 wrappers.  A operand: lane l holds A[row = l&15][k = l>>4]; B operand:
+// B[k = l>>4][col = l&15]; C/D: col = l&15, four rows per lane -- f32: (l>>4)*4 + reg,
+// f64: (l>>4) + 4*reg (MI355X guide, "Fragment layout").
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef double f64x4 __attribute__((vector_size(32)));
+
+template <typename real> struct Mfma;
+template <> struct Mfma<float> {
+  typedef f32x4 acc_t;
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row_of(int lane, int reg) { return ((lane >> 4) << 2) + reg; }
+};
+template <> struct Mfma<double> {
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row_of(int lane, int reg) { return (lane >> 4) + (reg << 2); }
+};
+
+template <typename real> struct Vec4;   // 4 consecutive reals, naturally aligned
+template <> struct __attribute__((aligned(16))) Vec4<float> { float v[4]; };
+template <> struct __attribute__((aligned(32))) Vec4<double> { double v[4]; };
+
+template <typename real> __device__ __forceinline__ real r_tanh(real x);
+template <> __device__ __forceinline__ float r_tanh<float>(float x) { return tanhf(x); }
+template <> __device__ __forceinline__ double r_tanh<double>(double x) { return tanh(x); }
+template <typename real> __device__ __forceinline__ real r_exp(real x);
+template <> __device__ __forceinline__ float r_exp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ double r_exp<double>(double x) { return exp(x); }
+
+// Sum over the four 16-lane quads of a wave (same lane&15).
+template <typename real> __device__ __forceinline__ real quad_sum(real v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+template <typename real> __device__ __forceinline__ real wave_sum(real v) {
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// Lane-t value of the pair features [rho, d_x, d_y, d_z] (optionally * log1p(rho)/rho) of the
+// difference d = r_recv - r_send (send < 0: a nucleus, no dependence), rho = sqrt(eps + d.d).
+// Reference: gnn/edge_features.py:21-123 + utils.py:79-85; derivative lanes per SURVEY.md
+// appendix C.  All arithmetic in double (inputs are 3 coordinates; cost is negligible).
+__device__ __forceinline__ void pair_feature_lane(const double d[3], double eps, int recv, int send, int t,
+                                                  const LaneInfo li, bool log_rescale, double out[4]) {
+  const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+  const double rho = sqrt(eps + d2);
+  const int n_ends = (recv == send) ? 0 : (send >= 0 ? 2 : 1);
+  // lane of rho and of the three components of d
+  double rho_t = 0.0, dc_t[3] = {0.0, 0.0, 0.0};
+  double sgn = 0.0;
+  int x = -1;
+  if (t == 0) {
+    rho_t = rho;
+    dc_t[0] = d[0]; dc_t[1] = d[1]; dc_t[2] = d[2];
+  } else if (t < li.T - 1) {
+    const int c = t - 1, e = c / 3;
+    x = c - 3 * e;
+    sgn = (e == recv ? 1.0 : 0.0) - (e == send ? 1.0 : 0.0);
+    rho_t = sgn * d[x] / rho;
+    dc_t[x] = sgn;
+  } else if (t == li.T - 1) {
+    rho_t = n_ends * (3.0 / rho - d2 / (rho * rho * rho));
+  }
+  if (!log_rescale) {
+    out[0] = rho_t; out[1] = dc_t[0]; out[2] = dc_t[1]; out[3] = dc_t[2];
+    return;
+  }
+  const double l1 = log1p(rho), ir = 1.0 / (1.0 + rho);
+  const double s = l1 / rho;
+  const double s1 = (ir - s) / rho;
+  const double s2 = (-ir * ir - 2.0 * s1) / rho;
+  const double sumJ2 = n_ends * d2 / (rho * rho);             // sum_c rho_c^2
+  if (t == 0) {
+    out[0] = l1;
+    for (int a = 0; a < 3; ++a) out[1 + a] = d[a] * s;
+  } else if (t < li.T - 1) {
+    out[0] = rho_t * ir;
+    for (int a = 0; a < 3; ++a) out[1 + a] = dc_t[a] * s + d[a] * s1 * rho_t;
+  } else if (t == li.T - 1) {
+    out[0] = rho_t * ir - sumJ2 * ir * ir;
+    const double sL = s1 * rho_t + s2 * sumJ2;
+    for (int a = 0; a < 3; ++a) out[1 + a] = d[a] * sL + 2.0 * n_ends * s1 * d[a] / rho;
+  } else {
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+  }
+}
+
+}  // namespace dqmc

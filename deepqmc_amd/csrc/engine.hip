@@ -1,0 +1,558 @@
+// engine.hip -- the C ABI of include/dqmc.h: context, layer-program executor, MCMC driver,
+// per-kernel timing.  Host code only; every arithmetic step is one of the kernels in
+// kernel_linear.hip / kernels_graph.hip / kernels_head.hip / kernels_mcmc.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dqmc.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess)                                                                               \
+      return fail(DQMC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" + __FILE__ +   \
+                                  ":" + std::to_string(__LINE__) + ")");                                \
+  } while (0)
+
+inline int pad4(int n) { return (n + 3) / 4 * 4; }
+
+struct TimingRec {
+  double ms = 0;
+  int64_t launches = 0;
+  double flops = 0;
+};
+
+}  // namespace
+
+struct dqmc_ctx {
+  virtual ~dqmc_ctx() {}
+  virtual int set_weights(const double* w, size_t n) = 0;
+  virtual int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) = 0;
+  virtual int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
+                           int32_t* sign) = 0;
+  virtual int mcmc(void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R, int B, int n_sub,
+                   int max_age, double target, uint64_t seed, const void* noise, const void* unif, uint8_t* accept_out,
+                   double* stats7) = 0;
+  virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
+  virtual int debug_read(int buf, double* out, size_t n) = 0;
+  int last_TP = 0;
+  // timing
+  bool timing = false;
+  std::map<std::string, TimingRec> trec;
+  struct Pending { std::string name; hipEvent_t a, b; double flops; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> ev_pool;
+  hipStream_t st = nullptr;
+
+  hipEvent_t get_event() {
+    if (!ev_pool.empty()) { hipEvent_t e = ev_pool.back(); ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void t_begin(const char* name, double flops) {
+    if (!timing) return;
+    Pending p{name, get_event(), get_event(), flops};
+    (void)hipEventRecord(p.a, st);
+    pending.push_back(p);
+  }
+  void t_end() {
+    if (!timing) return;
+    (void)hipEventRecord(pending.back().b, st);
+  }
+  void t_collect() {
+    if (pending.empty()) return;
+    (void)hipStreamSynchronize(st);
+    for (auto& p : pending) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, p.a, p.b);
+      auto& r = trec[p.name];
+      r.ms += ms; r.launches += 1; r.flops += p.flops;
+      ev_pool.push_back(p.a); ev_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+namespace {
+
+template <typename real>
+struct Engine : dqmc_ctx {
+  dqmc_system sys{};
+  int N = 0;
+  std::vector<dqmc_buf> bufs;
+  std::vector<dqmc_op> ops;
+  std::vector<double> charges_h;
+  size_t n_weights = 0, n_itable = 0;
+  real* d_w = nullptr;
+  int32_t* d_it = nullptr;
+  double* d_charges = nullptr;
+  // workspace
+  char* d_ws = nullptr;
+  size_t ws_bytes = 0;
+  std::vector<size_t> buf_off;  // byte offsets for the current (B, TP)
+  size_t off_logdet = 0, off_signk = 0;
+  int last_B = 0;
+  // mcmc scratch
+  char* d_mc = nullptr;
+  size_t mc_bytes = 0;
+  int32_t* d_nacc = nullptr;
+  double* d_acc = nullptr;     // [1] acceptance, then [7] stats, then [7] energy record
+  std::vector<real> wtmp;
+
+  ~Engine() override {
+    for (auto e : ev_pool) (void)hipEventDestroy(e);
+    if (d_w) (void)hipFree(d_w);
+    if (d_it) (void)hipFree(d_it);
+    if (d_charges) (void)hipFree(d_charges);
+    if (d_ws) (void)hipFree(d_ws);
+    if (d_mc) (void)hipFree(d_mc);
+    if (d_nacc) (void)hipFree(d_nacc);
+    if (d_acc) (void)hipFree(d_acc);
+  }
+
+  int init(const dqmc_system* s, const double* charges, const dqmc_buf* b, int nb, const dqmc_op* o, int no,
+           const double* w, size_t nw, const int32_t* it, size_t nit) {
+    sys = *s;
+    N = sys.n_up + sys.n_down;
+    if (N < 1 || sys.n_nuc < 1 || sys.n_det < 1) return fail(DQMC_E_ARG, "bad system sizes");
+    bufs.assign(b, b + nb);
+    ops.assign(o, o + no);
+    charges_h.assign(charges, charges + sys.n_nuc);
+    for (auto& bb : bufs)
+      if (bb.rows < 1 || bb.width < 4 || bb.width % 4) return fail(DQMC_E_ARG, "buffer width must be a positive multiple of 4");
+    n_weights = nw; n_itable = nit;
+    HIP_TRY(hipMalloc((void**)&d_w, sizeof(real) * (nw ? nw : 1)));
+    HIP_TRY(hipMalloc((void**)&d_it, sizeof(int32_t) * (nit ? nit : 1)));
+    HIP_TRY(hipMalloc((void**)&d_charges, sizeof(double) * sys.n_nuc));
+    HIP_TRY(hipMalloc((void**)&d_nacc, sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&d_acc, sizeof(double) * 16));
+    HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t), st));
+    HIP_TRY(hipMemcpyAsync(d_charges, charges, sizeof(double) * sys.n_nuc, hipMemcpyHostToDevice, st));
+    if (nit) HIP_TRY(hipMemcpyAsync(d_it, it, sizeof(int32_t) * nit, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int rc = validate();
+    if (rc) return rc;
+    return set_weights(w, nw);
+  }
+
+  int validate() {
+    const int nb = (int)bufs.size();
+    auto okb = [&](int b) { return b >= 0 && b < nb; };
+    for (size_t k = 0; k < ops.size(); ++k) {
+      const dqmc_op& op = ops[k];
+      const int32_t* i = op.i;
+      bool ok = true;
+      switch (op.kind) {
+        case DQMC_OP_FEAT_EN: ok = okb(i[0]) && bufs[i[0]].rows == N && bufs[i[0]].width >= 4 * sys.n_nuc + (i[2] ? 1 : 0); break;
+        case DQMC_OP_FEAT_EE: ok = okb(i[0]) && bufs[i[0]].rows == i[2] && bufs[i[0]].width == 4 && i[1] >= 0 && (size_t)(i[1] + 2 * i[2]) <= n_itable; break;
+        case DQMC_OP_LINEAR: {
+          ok = i[0] >= 1 && i[0] <= 4 && okb(i[17]);
+          size_t wrows = 0;
+          for (int p = 0; ok && p < i[0]; ++p) {
+            const int sb = i[1 + 4 * p], r0 = i[2 + 4 * p], K = i[3 + 4 * p], bc = i[4 + 4 * p];
+            ok = okb(sb) && K >= 1 && pad4(K) <= bufs[sb].width && r0 >= 0 && r0 + (bc ? 1 : i[20]) <= bufs[sb].rows;
+            wrows += pad4(K);
+          }
+          if (ok) {
+            const dqmc_buf& d = bufs[i[17]];
+            const int ldw = pad4(i[21]);
+            ok = i[18] >= 0 && i[18] + i[20] <= d.rows && i[19] >= 0 && i[19] % 4 == 0 && i[19] + ldw <= d.width &&
+                 i[22] >= 0 && i[22] % 4 == 0 && (size_t)i[22] + wrows * ldw <= n_weights &&
+                 (i[23] < 0 || (i[23] % 4 == 0 && (size_t)(i[23] + ldw) <= n_weights)) && i[24] >= 0 && i[24] <= 2;
+            if (ok && i[25] >= 0)
+              ok = okb(i[25]) && bufs[i[25]].width >= i[19] + ldw && i[26] >= 0 && i[26] + i[20] <= bufs[i[25]].rows;
+          }
+          break;
+        }
+        case DQMC_OP_SPIN_MEAN: ok = okb(i[0]) && okb(i[1]) && bufs[i[0]].rows == N && bufs[i[1]].rows == 2 && bufs[i[0]].width == bufs[i[1]].width; break;
+        case DQMC_OP_CONV: ok = okb(i[0]) && okb(i[1]) && okb(i[2]) && bufs[i[1]].rows == N && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[6] <= bufs[i[1]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
+        case DQMC_OP_EDGE_SUM: ok = okb(i[0]) && okb(i[2]) && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
+        case DQMC_OP_ROW_SUM: ok = okb(i[0]) && okb(i[1]) && bufs[i[1]].rows == 1 && bufs[i[0]].width == bufs[i[1]].width; break;
+        case DQMC_OP_ORBITALS: {
+          const size_t ne = (size_t)sys.n_det * N * sys.n_nuc;
+          ok = okb(i[0]) && okb(i[1]) && bufs[i[0]].rows == N && bufs[i[0]].width >= sys.n_det * N && bufs[i[1]].rows == sys.n_det && bufs[i[1]].width >= N * N;
+          for (int q = 2; ok && q < 6; ++q) ok = i[q] >= 0 && (size_t)i[q] + ne <= n_weights;
+          break;
+        }
+        case DQMC_OP_SLOGDET: ok = okb(i[0]) && bufs[i[0]].rows == sys.n_det && bufs[i[0]].width >= N * N && N <= 44; break;
+        case DQMC_OP_FINAL: ok = (i[0] < 0 || (okb(i[0]) && bufs[i[0]].rows == 1)) && (i[1] < 0 || (size_t)(i[1] + sys.n_det) <= n_weights) && i[3] >= 0 && (size_t)(i[3] + 2) <= n_weights && i[2] >= 0 && i[2] <= 2; break;
+        case DQMC_OP_ATTENTION: return fail(DQMC_E_UNSUPPORTED, "attention op is not built in this round");
+        default: ok = false;
+      }
+      if (!ok) return fail(DQMC_E_ARG, "malformed op #" + std::to_string(k) + " kind " + std::to_string(op.kind));
+    }
+    return DQMC_OK;
+  }
+
+  int set_weights(const double* w, size_t n) override {
+    if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
+    wtmp.resize(n);
+    for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
+    HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQMC_OK;
+  }
+
+  static bool lanes_supported(int TP) {
+    return TP == 1 || TP == 16 || TP == 32 || TP == 48 || TP == 64 || TP == 96 || TP == 128;
+  }
+
+  int plan(int B, int TP) {
+    buf_off.resize(bufs.size());
+    size_t off = 0;
+    auto bump = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    for (size_t k = 0; k < bufs.size(); ++k)
+      buf_off[k] = bump(sizeof(real) * (size_t)B * bufs[k].rows * TP * bufs[k].width);
+    off_logdet = bump(sizeof(double) * (size_t)B * sys.n_det * TP);
+    off_signk = bump(sizeof(int32_t) * (size_t)B * sys.n_det);
+    if (off > ws_bytes) {
+      if (d_ws) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ws)); d_ws = nullptr; ws_bytes = 0; }
+      hipError_t e = hipMalloc((void**)&d_ws, off);
+      if (e != hipSuccess) return fail(DQMC_E_NOMEM, "workspace of " + std::to_string(off) + " bytes: " + hipGetErrorString(e));
+      ws_bytes = off;
+    }
+    last_B = B; last_TP = TP;
+    return DQMC_OK;
+  }
+  real* bptr(int b) { return reinterpret_cast<real*>(d_ws + buf_off[b]); }
+
+  // Execute the layer program on B walkers.  laplacian: TP lanes and local-energy outputs.
+  int run(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
+          real* grad) {
+    if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    dqmc::LaneInfo li;
+    li.N = N;
+    li.T = laplacian ? 3 * N + 2 : 1;
+    li.TP = laplacian ? (li.T + 15) / 16 * 16 : 1;
+    if (!lanes_supported(li.TP)) return fail(DQMC_E_UNSUPPORTED, "no kernel instance for " + std::to_string(li.TP) + " lanes");
+    int rc = plan(B, li.TP);
+    if (rc) return rc;
+    for (const dqmc_op& op : ops) {
+      const int32_t* i = op.i;
+      switch (op.kind) {
+        case DQMC_OP_FEAT_EN:
+          t_begin("feat", 0);
+          dqmc::launch_feat_en<real>(st, r, R, bptr(i[0]), B, sys.n_nuc, sys.n_up, bufs[i[0]].width, li, sys.norm_eps, i[1], i[2]);
+          t_end();
+          break;
+        case DQMC_OP_FEAT_EE:
+          t_begin("feat", 0);
+          dqmc::launch_feat_ee<real>(st, r, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3]);
+          t_end();
+          break;
+        case DQMC_OP_LINEAR: {
+          dqmc::LinArgs<real> a{};
+          a.n_pieces = i[0];
+          int ktot = 0;
+          for (int p = 0; p < i[0]; ++p) {
+            const int sb = i[1 + 4 * p];
+            a.piece[p].src = bptr(sb);
+            a.piece[p].ld = bufs[sb].width;
+            a.piece[p].rpw = bufs[sb].rows;
+            a.piece[p].r0 = i[2 + 4 * p];
+            a.piece[p].K = pad4(i[3 + 4 * p]);
+            a.piece[p].bcast = i[4 + 4 * p];
+            ktot += i[3 + 4 * p];
+          }
+          a.W = d_w + i[22];
+          a.ldw = pad4(i[21]);
+          a.bias = i[23] >= 0 ? d_w + i[23] : nullptr;
+          a.dst = bptr(i[17]);
+          a.ld_dst = bufs[i[17]].width; a.rpw_dst = bufs[i[17]].rows; a.r0_dst = i[18]; a.col0_dst = i[19];
+          a.res = i[25] >= 0 ? bptr(i[25]) : nullptr;
+          if (i[25] >= 0) { a.ld_res = bufs[i[25]].width; a.rpw_res = bufs[i[25]].rows; a.r0_res = i[26]; }
+          a.res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
+          a.act = i[24]; a.nrows = i[20]; a.B = B; a.T = li.T; a.TP = li.TP;
+          t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21]);
+          dqmc::launch_linear<real>(st, a);
+          t_end();
+          break;
+        }
+        case DQMC_OP_SPIN_MEAN:
+          t_begin("graph", 0);
+          dqmc::launch_spin_mean<real>(st, bptr(i[0]), bptr(i[1]), B, i[2], bufs[i[0]].width, li);
+          t_end();
+          break;
+        case DQMC_OP_CONV:
+          t_begin("graph", 0);
+          dqmc::launch_conv<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, bptr(i[2]),
+                                  bufs[i[2]].width, i[3], d_it + i[4], i[5], i[6], B, li);
+          t_end();
+          break;
+        case DQMC_OP_EDGE_SUM:
+          t_begin("graph", 0);
+          dqmc::launch_edge_sum<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[2]), bufs[i[2]].width, i[3],
+                                      d_it + i[4], i[5], i[6], (double)op.f[0], B, li);
+          t_end();
+          break;
+        case DQMC_OP_ROW_SUM:
+          t_begin("graph", 0);
+          dqmc::launch_row_sum<real>(st, bptr(i[0]), bptr(i[1]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
+          t_end();
+          break;
+        case DQMC_OP_ORBITALS:
+          t_begin("orbitals", 0);
+          dqmc::launch_orbitals<real>(st, r, R, bptr(i[0]), bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, d_w + i[2], d_w + i[3],
+                                      d_w + i[4], d_w + i[5], B, sys.n_up, sys.n_nuc, sys.n_det, li, sys.norm_eps);
+          t_end();
+          break;
+        case DQMC_OP_SLOGDET:
+          t_begin("slogdet", 0);
+          dqmc::launch_slogdet<real>(st, bptr(i[0]), bufs[i[0]].width, reinterpret_cast<double*>(d_ws + off_logdet),
+                                     reinterpret_cast<int32_t*>(d_ws + off_signk), B, sys.n_det, li);
+          t_end();
+          break;
+        case DQMC_OP_FINAL: {
+          dqmc::FinalArgs a{};
+          a.r = r; a.R = R; a.charges = d_charges;
+          a.logdet = reinterpret_cast<double*>(d_ws + off_logdet);
+          a.sign_k = reinterpret_cast<int32_t*>(d_ws + off_signk);
+          a.jastrow = i[0] >= 0 ? bptr(i[0]) : nullptr;
+          a.jas_width = i[0] >= 0 ? bufs[i[0]].width : 0;
+          a.conf_coeff = i[1] >= 0 ? d_w + i[1] : nullptr;
+          a.alphas = d_w + i[3];
+          a.cusp_kind = i[2];
+          a.same_scale = op.f[0]; a.anti_scale = op.f[1];
+          a.eps = sys.norm_eps; a.e_nuc = sys.e_nuc;
+          a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
+          a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.grad = grad;
+          t_begin("final", 0);
+          dqmc::launch_final<real>(st, a);
+          t_end();
+          break;
+        }
+        default:
+          return fail(DQMC_E_UNSUPPORTED, "op kind " + std::to_string(op.kind));
+      }
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+
+  int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) override {
+    return run((const real*)r, (const real*)R, B, false, (real*)logpsi, sign, nullptr, nullptr, nullptr);
+  }
+  int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
+                   int32_t* sign) override {
+    return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, (real*)e_loc, (real*)stats, (real*)grad);
+  }
+
+  int mcmc(void* r_, void* logpsi_, int32_t* sign, int32_t* age, void* tau_, const void* R_, int B, int n_sub,
+           int max_age, double target, uint64_t seed, const void* noise_, const void* unif_, uint8_t* accept_out,
+           double* stats7) override {
+    if (B < 1 || n_sub < 0) return fail(DQMC_E_ARG, "bad B / n_sub");
+    if ((noise_ == nullptr) != (unif_ == nullptr)) return fail(DQMC_E_ARG, "noise and unif must both be given or both NULL");
+    real* r = (real*)r_; real* logpsi = (real*)logpsi_; real* tau = (real*)tau_;
+    const real* R = (const real*)R_;
+    const size_t n_r = (size_t)B * N * 3;
+    // scratch: r_prop, logpsi_prop, sign_prop, noise, unif
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_rp = 0, o_lp = o_rp + al(sizeof(real) * n_r), o_sp = o_lp + al(sizeof(real) * B),
+                 o_nz = o_sp + al(sizeof(int32_t) * B), o_un = o_nz + al(sizeof(real) * n_r), tot = o_un + al(sizeof(real) * B);
+    if (tot > mc_bytes) {
+      if (d_mc) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_mc)); d_mc = nullptr; }
+      HIP_TRY(hipMalloc((void**)&d_mc, tot));
+      mc_bytes = tot;
+    }
+    real* r_prop = (real*)(d_mc + o_rp); real* lp_prop = (real*)(d_mc + o_lp);
+    int32_t* s_prop = (int32_t*)(d_mc + o_sp);
+    real* nz = (real*)(d_mc + o_nz); real* un = (real*)(d_mc + o_un);
+    for (int s = 0; s < n_sub; ++s) {
+      const real* noise_s; const real* unif_s;
+      if (noise_) {
+        noise_s = (const real*)noise_ + (size_t)s * n_r;
+        unif_s = (const real*)unif_ + (size_t)s * B;
+      } else {
+        t_begin("mcmc", 0);
+        dqmc::launch_rng<real>(st, nz, (long)n_r, un, (long)B, seed, (uint64_t)s);
+        t_end();
+        noise_s = nz; unif_s = un;
+      }
+      t_begin("mcmc", 0);
+      dqmc::launch_propose<real>(st, r, noise_s, tau, r_prop, (long)n_r);
+      t_end();
+      int rc = run(r_prop, R, B, false, lp_prop, s_prop, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      t_begin("mcmc", 0);
+      dqmc::launch_accept<real>(st, r, logpsi, sign, age, r_prop, lp_prop, s_prop, unif_s, max_age, B, N, d_nacc,
+                                accept_out ? accept_out + (size_t)s * B : nullptr);
+      dqmc::launch_tau_update<real>(st, tau, d_nacc, B, target, d_acc);
+      t_end();
+    }
+    if (stats7) {
+      dqmc::launch_sampler_stats<real>(st, r, logpsi, age, tau, d_acc, B, N, sys.norm_eps, d_acc + 1);
+      HIP_TRY(hipMemcpyAsync(stats7, d_acc + 1, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+
+  int energy_stats(const void* e, const void* w, int B, double* out7) override {
+    if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    dqmc::launch_energy_stats<real>(st, (const real*)e, (const real*)w, B, d_acc + 8);
+    HIP_TRY(hipMemcpyAsync(out7, d_acc + 8, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQMC_OK;
+  }
+
+  int debug_read(int buf, double* out, size_t n) override {
+    if (last_B == 0) return fail(DQMC_E_ARG, "no evaluation has run yet");
+    HIP_TRY(hipStreamSynchronize(st));
+    if (buf == -1) {
+      const size_t cnt = (size_t)last_B * sys.n_det * last_TP;
+      if (n != cnt) return fail(DQMC_E_ARG, "size mismatch");
+      HIP_TRY(hipMemcpy(out, d_ws + off_logdet, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+      return DQMC_OK;
+    }
+    if (buf == -2) {
+      const size_t cnt = (size_t)last_B * sys.n_det;
+      if (n != cnt) return fail(DQMC_E_ARG, "size mismatch");
+      std::vector<int32_t> tmp(cnt);
+      HIP_TRY(hipMemcpy(tmp.data(), d_ws + off_signk, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < cnt; ++k) out[k] = tmp[k];
+      return DQMC_OK;
+    }
+    if (buf < 0 || buf >= (int)bufs.size()) return fail(DQMC_E_ARG, "no such buffer");
+    const size_t cnt = (size_t)last_B * bufs[buf].rows * last_TP * bufs[buf].width;
+    if (n != cnt) return fail(DQMC_E_ARG, "size mismatch: expected " + std::to_string(cnt));
+    std::vector<real> tmp(cnt);
+    HIP_TRY(hipMemcpy(tmp.data(), d_ws + buf_off[buf], sizeof(real) * cnt, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < cnt; ++k) out[k] = (double)tmp[k];
+    return DQMC_OK;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* dqmc_last_error(void) { return g_err.c_str(); }
+
+int dqmc_create(dqmc_ctx** out, int device, void* stream, const dqmc_system* sys, const double* charges_host,
+                const dqmc_buf* bufs_host, int n_bufs, const dqmc_op* ops_host, int n_ops, const double* weights_host,
+                size_t n_weights, const int32_t* itable_host, size_t n_itable) {
+  if (!out || !sys || !charges_host || !bufs_host || !ops_host || !weights_host || n_bufs < 1 || n_ops < 1)
+    return fail(DQMC_E_ARG, "null argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(device));
+  dqmc_ctx* ctx = nullptr;
+  int rc;
+  if (sys->dtype == 0) {
+    auto* e = new Engine<float>();
+    e->st = (hipStream_t)stream;
+    rc = e->init(sys, charges_host, bufs_host, n_bufs, ops_host, n_ops, weights_host, n_weights, itable_host, n_itable);
+    ctx = e;
+  } else if (sys->dtype == 1) {
+    auto* e = new Engine<double>();
+    e->st = (hipStream_t)stream;
+    rc = e->init(sys, charges_host, bufs_host, n_bufs, ops_host, n_ops, weights_host, n_weights, itable_host, n_itable);
+    ctx = e;
+  } else {
+    return fail(DQMC_E_ARG, "dtype must be 0 (float32) or 1 (float64)");
+  }
+  if (rc) { delete ctx; return rc; }
+  *out = ctx;
+  return DQMC_OK;
+}
+
+void dqmc_destroy(dqmc_ctx* ctx) { delete ctx; }
+
+int dqmc_set_weights(dqmc_ctx* ctx, const double* w, size_t n) {
+  if (!ctx || !w) return fail(DQMC_E_ARG, "null argument");
+  return ctx->set_weights(w, n);
+}
+int dqmc_wf_eval(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logpsi, int32_t* sign) {
+  if (!ctx || !r || !R || !logpsi || !sign) return fail(DQMC_E_ARG, "null argument");
+  return ctx->wf_eval(r, R, B, logpsi, sign);
+}
+int dqmc_local_energy(dqmc_ctx* ctx, const void* r, const void* R, int B, void* e_loc, void* stats, void* grad,
+                      void* logpsi, int32_t* sign) {
+  if (!ctx || !r || !R || !e_loc) return fail(DQMC_E_ARG, "null argument");
+  return ctx->local_energy(r, R, B, e_loc, stats, grad, logpsi, sign);
+}
+int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R,
+                    int B, int n_sub, int max_age, double target_acceptance, uint64_t seed, const void* noise,
+                    const void* unif, uint8_t* accept_out, double* stats7_host) {
+  if (!ctx || !r || !logpsi || !sign || !age || !tau || !R) return fail(DQMC_E_ARG, "null argument");
+  return ctx->mcmc(r, logpsi, sign, age, tau, R, B, n_sub, max_age, target_acceptance, seed, noise, unif, accept_out,
+                   stats7_host);
+}
+int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, double* out7_host) {
+  if (!ctx || !e_loc || !out7_host) return fail(DQMC_E_ARG, "null argument");
+  return ctx->energy_stats(e_loc, w, B, out7_host);
+}
+
+int dqmc_merge_energy_stats(const double* rec, int n_ranks, double* out5) {
+  if (!rec || !out5 || n_ranks < 1) return fail(DQMC_E_ARG, "null argument");
+  // Chan et al. pairwise merge of (n, mean, M2); min/max/weighted sums are plain reductions.
+  double n = 0, mean = 0, m2 = 0, sw = 0, swe = 0, mn = INFINITY, mx = -INFINITY;
+  for (int k = 0; k < n_ranks; ++k) {
+    const double* r = rec + 7 * k;
+    const double nb = r[0], mb = r[3] / r[0];
+    const double d = mb - mean, nt = n + nb;
+    m2 += r[4] + d * d * n * nb / nt;
+    mean += d * nb / nt;
+    n = nt;
+    sw += r[1]; swe += r[2];
+    mn = std::fmin(mn, r[5]); mx = std::fmax(mx, r[6]);
+  }
+  out5[0] = mean; out5[1] = std::sqrt(m2 / n); out5[2] = mn; out5[3] = mx; out5[4] = swe / sw;
+  return DQMC_OK;
+}
+
+int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
+  if (!ctx || !out) return fail(DQMC_E_ARG, "null argument");
+  return ctx->debug_read(buf, out, n);
+}
+int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
+
+int dqmc_timing_enable(dqmc_ctx* ctx, int enable) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  ctx->t_collect();
+  ctx->timing = enable != 0;
+  return DQMC_OK;
+}
+int dqmc_timing_reset(dqmc_ctx* ctx) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  ctx->t_collect();
+  ctx->trec.clear();
+  return DQMC_OK;
+}
+int dqmc_timing_get(dqmc_ctx* ctx, const char* name, double* ms, int64_t* launches, double* flops) {
+  if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
+  ctx->t_collect();
+  auto it = ctx->trec.find(name);
+  TimingRec r = it == ctx->trec.end() ? TimingRec{} : it->second;
+  if (ms) *ms = r.ms;
+  if (launches) *launches = r.launches;
+  if (flops) *flops = r.flops;
+  return DQMC_OK;
+}
+int dqmc_timing_names(dqmc_ctx* ctx, char* out, size_t n) {
+  if (!ctx || !out || n == 0) return fail(DQMC_E_ARG, "null argument");
+  ctx->t_collect();
+  std::string s;
+  for (auto& kv : ctx->trec) { if (!s.empty()) s += ","; s += kv.first; }
+  std::snprintf(out, n, "%s", s.c_str());
+  return DQMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// kernel_linear.hip -- the forward-Laplacian linear layer, the dominant kernel of the path.
+//
+//   Y = act( concat_p(X_p) W + b )  (+ residual),   rows = (walker, row, lane)
+//
+// Every lane of an activation (value, 3N first derivatives, Laplacian) goes through the
+// same matrix, so a layer is ONE GEMM over B*rows*TP stacked rows (reference: what folx's
+// forward Laplacian does for hk.Linear, conf/hamil/qc_forward_laplacian.yaml:7-10, restated
+// in SURVEY.md appendix C).  The nonlinearity needs all lanes of one (walker,row,column):
+//     y = phi(v),  J'_c = phi'(v) J_c,  L' = phi'(v) L + phi''(v) sum_c J_c^2
+// Rows are ordered lane-fastest and TP is a multiple of 16, so one (walker,row) group is
+// TP/16 consecutive MFMA row blocks held by ONE wave: the chain rule runs on the
+// accumulators in registers (sum_c J_c^2 = per-lane partial + two cross-quad shuffles), fused
+// with bias, residual and the store.
+//
+// gfx950 mapping: exact-f32 v_mfma_f32_16x16x4_f32 (or v_mfma_f64_16x16x4_f64 in the float64
+// parity build); block = 4 waves stacked in M, wave tile (16*MR) x (16*NR), K staged through
+// LDS in chunks of 16 (A transposed on the way in so both fragments are conflict-free
+// ds_read_b32), next chunk prefetched into registers while the current one is multiplied.
+// The A operand is a virtual concatenation of up to 4 pieces (e.g. [x | mean_up | mean_down |
+// conv] for the g layer, reference gnn/electron_gnn.py:239-243), per-walker-mean pieces being
+// broadcast by the row mapping instead of materialised.
+#include "common.h"
+#include "kernels.h"
+
+namespace dqmc {
+
+template <typename real> __device__ __forceinline__ void act_derivs(int act, real v, real& y, real& d1, real& d2) {
+  if (act == 1) {
+    y = r_tanh<real>(v);
+    d1 = 1 - y * y;
+    d2 = -2 * y * d1;
+  } else if (act == 2) {
+    const real s = 1 / (1 + r_exp<real>(-v));
+    y = v * s;
+    d1 = s * (1 + v * (1 - s));
+    d2 = s * (1 - s) * (2 + v * (1 - 2 * s));
+  } else {
+    y = v; d1 = 1; d2 = 0;
+  }
+}
+
+template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
+
+// MR row blocks x NR column blocks per wave; GPW groups per wave (0: value-only rows).
+template <typename real, int MR, int NR, int GPW>
+__global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
+  constexpr int BM = 64 * MR, BN = 16 * NR, BK = 16;
+  constexpr int AS = BM + 16, BS = BStride<BN>::v;
+  constexpr int GB = GPW > 0 ? MR / GPW : 1;     // row blocks per group
+  constexpr int NBV = (BK * BN / 4 + 255) / 256; // B float4 per thread
+  typedef typename Mfma<real>::acc_t acc_t;
+  __shared__ real As[BK * AS];
+  __shared__ real Bs[BK * BS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_groups = a.B * a.nrows;            // (walker,row) groups == value-mode rows
+  const int col_blk0 = blockIdx.y * BN;
+
+  // ---- per-thread A rows: MR float4 per chunk ----
+  int a_row[MR];          // row inside the tile
+  int a_g[MR], a_t[MR];   // group index (b*nrows+rr) and lane t; a_g < 0: out of range
+  const int a_kq = tid & 3;
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    const int row = (tid >> 2) + 64 * j;
+    a_row[j] = row;
+    int g, t;
+    if (GPW > 0) {
+      const int w = row / (16 * MR), rb = (row >> 4) % MR;
+      g = (blockIdx.x * 4 + w) * GPW + rb / GB;
+      t = (rb % GB) * 16 + (row & 15);
+    } else {
+      g = blockIdx.x * BM + row;
+      t = 0;
+    }
+    a_g[j] = g < n_groups ? g : -1;
+    a_t[j] = t;
+  }
+
+  acc_t acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  int w_row0 = 0;  // first W row of the current piece
+  for (int p = 0; p < a.n_pieces; ++p) {
+    const LinPiece<real> pc = a.piece[p];
+    const real* a_src[MR];
+#pragma unroll
+    for (int j = 0; j < MR; ++j) {
+      if (a_g[j] >= 0) {
+        const int b = a_g[j] / a.nrows, rr = a_g[j] - b * a.nrows;
+        const long srow = ((long)b * pc.rpw + pc.r0 + (pc.bcast ? 0 : rr)) * a.TP + a_t[j];
+        a_src[j] = pc.src + srow * pc.ld;
+      } else {
+        a_src[j] = nullptr;
+      }
+    }
+    const int n_chunks = (pc.K + BK - 1) / BK;
+    Vec4<real> ra[MR], rb_[NBV];
+    auto load_chunk = [&](int kc) {
+      const int k0 = kc * BK + 4 * a_kq;
+#pragma unroll
+      for (int j = 0; j < MR; ++j) {
+        if (a_src[j] != nullptr && k0 < pc.K) ra[j] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
+        else ra[j] = Vec4<real>{{0, 0, 0, 0}};
+      }
+#pragma unroll
+      for (int j = 0; j < NBV; ++j) {
+        const int f = tid + 256 * j;
+        const int k = f / (BN / 4), n4 = f % (BN / 4);
+        const int kk = kc * BK + k, col = col_blk0 + 4 * n4;
+        if (f < BK * BN / 4 && kk < pc.K && col < a.ldw)
+          rb_[j] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk) * a.ldw + col);
+        else
+          rb_[j] = Vec4<real>{{0, 0, 0, 0}};
+      }
+    };
+    load_chunk(0);
+    for (int kc = 0; kc < n_chunks; ++kc) {
+      __syncthreads();  // previous chunk's fragments have been read
+#pragma unroll
+      for (int j = 0; j < MR; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[(4 * a_kq + i) * AS + a_row[j]] = ra[j].v[i];
+#pragma unroll
+      for (int j = 0; j < NBV; ++j) {
+        const int f = tid + 256 * j;
+        if (f < BK * BN / 4) {
+          const int k = f / (BN / 4), n4 = f % (BN / 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Bs[k * BS + 4 * n4 + i] = rb_[j].v[i];
+        }
+      }
+      __syncthreads();
+      if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int krow = kk * 4 + (lane >> 4);
+        real fa[MR], fb[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) fa[i] = As[krow * AS + wave * (16 * MR) + i * 16 + (lane & 15)];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) fb[j] = Bs[krow * BS + j * 16 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
+      }
+    }
+    w_row0 += (pc.K + 3) / 4 * 4;
+  }
+
+  // ---- epilogue ----
+  const int cl = lane & 15;
+  if (GPW > 0) {
+#pragma unroll
+    for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
+      const int g = (blockIdx.x * 4 + wave) * GPW + gj;
+      if (g >= n_groups) continue;   // wave-uniform
+      const int b = g / a.nrows, rr = g - b * a.nrows;
+      const long drow0 = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
+      const long rrow0 = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int col = col_blk0 + n * 16 + cl;
+        const bool col_ok = col < a.ldw;
+        real v = __shfl(acc[gj * GB][n][0], cl, 64);
+        if (a.bias != nullptr && col_ok) v += a.bias[col];
+        real s_part = 0, l_part = 0;
+#pragma unroll
+        for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
+            const real x = acc[gj * GB + tb][n][rg];
+            if (t >= 1 && t < a.T - 1) s_part += x * x;
+            if (t == a.T - 1) l_part = x;
+          }
+        const real S = quad_sum<real>(s_part);
+        (void)l_part;
+        real y, d1, d2;
+        act_derivs<real>(a.act, v, y, d1, d2);
+#pragma unroll
+        for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
+            const real x = acc[gj * GB + tb][n][rg];
+            real o;
+            if (t == 0) o = y;
+            else if (t < a.T - 1) o = d1 * x;
+            else if (t == a.T - 1) o = d1 * x + d2 * S;
+            else o = 0;
+            if (col_ok) {
+              if (a.res != nullptr) o = (a.res[(rrow0 + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
+              a.dst[(drow0 + t) * a.ld_dst + a.col0_dst + col] = o;
+            }
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int m = blockIdx.x * BM + wave * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
+        if (m >= n_groups) continue;
+        const int b = m / a.nrows, rr = m - b * a.nrows;
+        const long drow = (long)b * a.rpw_dst + a.r0_dst + rr;
+        const long rrow = a.res ? (long)b * a.rpw_res + a.r0_res + rr : 0;
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_blk0 + n * 16 + cl;
+          if (col >= a.ldw) continue;
+          real v = acc[i][n][rg];
+          if (a.bias != nullptr) v += a.bias[col];
+          real y, d1, d2;
+          act_derivs<real>(a.act, v, y, d1, d2);
+          if (a.res != nullptr) y = (a.res[rrow * a.ld_res + a.col0_dst + col] + y) * a.res_scale;
+          a.dst[drow * a.ld_dst + a.col0_dst + col] = y;
+        }
+      }
+  }
+}
+
+template <typename real, int MR, int NR, int GPW> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
+  constexpr int BM = 64 * MR, BN = 16 * NR;
+  const long n_groups = (long)a.B * a.nrows;
+  const unsigned gx = GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
+  const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW>), dim3(gx, gy), dim3(256), 0, st, a);
+}
+
+template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, const LinArgs<real>& a) {
+  constexpr int NR_MAX = sizeof(real) == 8 ? 2 : 4;   // accumulator registers: MR*NR*4 per lane
+  if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW>(st, a);
+  else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW>(st, a);
+  else launch_cfg<real, MR, 1, GPW>(st, a);
+}
+
+template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
+  switch (a.TP) {
+    case 1: launch_nr<real, 4, 0>(st, a); break;
+    case 16: launch_nr<real, 4, 4>(st, a); break;
+    case 32: launch_nr<real, 4, 2>(st, a); break;
+    case 48: launch_nr<real, 3, 1>(st, a); break;
+    case 64: launch_nr<real, 4, 1>(st, a); break;
+    case 96: launch_nr<real, 6, 1>(st, a); break;
+    case 128: launch_nr<real, 8, 1>(st, a); break;
+    default: break;  // rejected by the engine before launch (lanes_supported)
+  }
+}
+
+template void launch_linear<float>(hipStream_t, const LinArgs<float>&);
+template void launch_linear<double>(hipStream_t, const LinArgs<double>&);
+
+}  // namespace dqmc

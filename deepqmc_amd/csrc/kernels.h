@@ -1,0 +1,104 @@
+// kernels.h -- host-callable launchers of the gfx950 kernels (explicitly instantiated for
+// float and double in the .hip files).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.h"
+
+namespace dqmc {
+
+// ---- kernels_graph.hip ----
+template <typename real>
+void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B, int n_nuc, int n_up, int width,
+                    LaneInfo li, double eps, int log_rescale, int use_spin);
+template <typename real>
+void launch_feat_ee(hipStream_t st, const real* r, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
+                    double eps, int log_rescale);
+template <typename real>
+void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li);
+template <typename real>
+void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int width, LaneInfo li);
+template <typename real>
+void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
+                 int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li);
+template <typename real>
+void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,
+                     const int32_t* tab, int S, int W, double scale, int B, LaneInfo li);
+
+// ---- kernel_linear.hip ----
+// One concat piece of the A operand: logical row (b, rr, t) reads
+// src[((b*rpw + r0 + (bcast ? 0 : rr))*TP + t)*ld + k], k < K (K % 4 == 0, zero padded).
+template <typename real> struct LinPiece {
+  const real* src;
+  int ld, rpw, r0, K, bcast;
+};
+template <typename real> struct LinArgs {
+  int n_pieces;
+  LinPiece<real> piece[4];
+  const real* W;      // [sum K][ldw]
+  int ldw;            // pad4(Nout)
+  const real* bias;   // [ldw] or nullptr (value lane only)
+  real* dst;
+  int ld_dst, rpw_dst, r0_dst, col0_dst;
+  const real* res;    // residual input or nullptr: out = (res + y) * res_scale
+  int ld_res, rpw_res, r0_res;
+  real res_scale;
+  int act;            // 0 none, 1 tanh, 2 silu
+  int nrows;          // rows per walker in this segment
+  int B;
+  int T, TP;
+};
+template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
+
+// ---- kernels_head.hip ----
+template <typename real>
+void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
+                     int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
+                     int n_up, int n_nuc, int K, LaneInfo li, double eps);
+template <typename real>
+void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
+                    LaneInfo li);
+struct FinalArgs {
+  const void* r;          // real[B][N][3]
+  const void* R;          // real[n_nuc][3]
+  const double* charges;  // device double[n_nuc]
+  const double* logdet;   // [B][K][TP]
+  const int32_t* sign_k;  // [B][K]
+  const void* jastrow;    // real[B][1][TP][jas_width] or nullptr
+  int jas_width;
+  const void* conf_coeff; // real[K] or nullptr
+  const void* alphas;     // real[2]
+  int cusp_kind;
+  double same_scale, anti_scale;
+  double eps, e_nuc;
+  int B, n_up, n_nuc, K;
+  LaneInfo li;
+  // outputs (any may be nullptr)
+  void* logpsi;   // real[B]
+  int32_t* sign;  // [B]
+  void* e_loc;    // real[B]
+  void* stats;    // real[6][B]
+  void* grad;     // real[B][3N]
+};
+template <typename real> void launch_final(hipStream_t st, const FinalArgs& a);
+
+// ---- kernels_mcmc.hip ----
+template <typename real>
+void launch_rng(hipStream_t st, real* noise, long n_noise, real* unif, long n_unif, uint64_t seed, uint64_t stream_id);
+template <typename real>
+void launch_propose(hipStream_t st, const real* r, const real* noise, const real* tau, real* r_prop, long n);
+template <typename real>
+void launch_accept(hipStream_t st, real* r, real* logpsi, int32_t* sign, int32_t* age, const real* r_prop,
+                   const real* logpsi_prop, const int32_t* sign_prop, const real* unif, int max_age, int B, int N,
+                   int32_t* n_accept, uint8_t* accept_out);
+template <typename real>
+void launch_tau_update(hipStream_t st, real* tau, int32_t* n_accept, int B, double target, double* acc_out);
+template <typename real>
+void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, const int32_t* age, const real* tau,
+                          const double* acc, int B, int N, double eps, double* stats7);
+template <typename real>
+void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B, double* out7);
+
+}  // namespace dqmc

@@ -1,0 +1,212 @@
+// kernels_graph.hip -- input features and the small structured ops of the electron GNN,
+// all in forward-Laplacian (lane-stacked) form.  One thread per output element
+// (walker, row, lane, column) with the column fastest => coalesced row-major traffic.
+#include "common.h"
+#include "kernels.h"
+
+namespace dqmc {
+
+// Electron-nucleus input features, reference gnn/electron_gnn.py:596-625:
+// x[b][i][t][4a + f] = lane t of [|d|, d_x, d_y, d_z], d = r_i - R_a (+ spin column).
+template <typename real>
+__global__ void __launch_bounds__(256) k_feat_en(const real* __restrict__ r, const real* __restrict__ R, real* __restrict__ x,
+                                                 int B, int n_nuc, int n_up, int width, LaneInfo li, double eps,
+                                                 int log_rescale, int use_spin) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * li.N * li.TP * n_nuc;
+  if (idx >= total) return;
+  const int a = (int)(idx % n_nuc);
+  long q = idx / n_nuc;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int i = (int)(q % li.N);
+  const int b = (int)(q / li.N);
+  double d[3];
+  for (int k = 0; k < 3; ++k) d[k] = (double)r[((long)b * li.N + i) * 3 + k] - (double)R[a * 3 + k];
+  double f[4];
+  pair_feature_lane(d, eps, i, -1, t, li, log_rescale != 0, f);
+  real* row = x + (((long)b * li.N + i) * li.TP + t) * width;
+  for (int k = 0; k < 4; ++k) row[4 * a + k] = (real)f[k];
+  if (a == 0) {  // spin column and zero padding of the row tail
+    int c = 4 * n_nuc;
+    if (use_spin) row[c++] = (t == 0) ? (real)(i < n_up ? 1.0 : -1.0) : (real)0;
+    for (; c < width; ++c) row[c] = (real)0;
+  }
+}
+
+// Electron-electron edge features, reference gnn/graph.py:23-31 (d = r_recv - r_send).
+template <typename real>
+__global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, const int32_t* __restrict__ pairs,
+                                                 real* __restrict__ e, int B, int n_rows, LaneInfo li, double eps,
+                                                 int log_rescale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * n_rows * li.TP;
+  if (idx >= total) return;
+  const int t = (int)(idx % li.TP);
+  long q = idx / li.TP;
+  const int k = (int)(q % n_rows);
+  const int b = (int)(q / n_rows);
+  const int rc = pairs[2 * k], sd = pairs[2 * k + 1];
+  double d[3];
+  for (int c = 0; c < 3; ++c)
+    d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (double)r[((long)b * li.N + sd) * 3 + c];
+  double f[4];
+  pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f);
+  Vec4<real> o;
+  for (int c = 0; c < 4; ++c) o.v[c] = (real)f[c];
+  *reinterpret_cast<Vec4<real>*>(e + idx * 4) = o;
+}
+
+// Mean over spin-up / spin-down electrons, reference gnn/update_features.py:86-102.
+template <typename real>
+__global__ void __launch_bounds__(256) k_spin_mean(const real* __restrict__ x, real* __restrict__ m, int B, int n_up,
+                                                   int width, LaneInfo li) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 2 * li.TP * width;
+  if (idx >= total) return;
+  const int c = (int)(idx % width);
+  long q = idx / width;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int which = (int)(q % 2);
+  const int b = (int)(q / 2);
+  const int i0 = which ? n_up : 0, i1 = which ? li.N : n_up;
+  real acc = 0;
+  for (int i = i0; i < i1; ++i) acc += x[(((long)b * li.N + i) * li.TP + t) * width + c];
+  m[idx] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
+}
+
+// Sum over all rows of a walker (Jastrow sum_first, wf/omni.py:35-40).
+template <typename real>
+__global__ void __launch_bounds__(256) k_row_sum(const real* __restrict__ x, real* __restrict__ s, int B, int rows,
+                                                 int width, LaneInfo li) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * li.TP * width;
+  if (idx >= total) return;
+  const int c = (int)(idx % width);
+  long q = idx / width;
+  const int t = (int)(q % li.TP);
+  const int b = (int)(q / li.TP);
+  real acc = 0;
+  for (int i = 0; i < rows; ++i) acc += x[(((long)b * rows + i) * li.TP + t) * width + c];
+  s[idx] = acc;
+}
+
+// Convolution feature, reference gnn/graph.py:226-335: out[i] = sum_s we[row(i,s)] * hx[send(i,s)]
+// with the product rule across lanes (value, d/dr_c, Laplacian).  tab: int [N][S][2].
+template <typename real>
+__global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int we_rows, int we_width,
+                                              const real* __restrict__ hx, int hx_width, real* __restrict__ out,
+                                              int out_width, int col0, const int32_t* __restrict__ tab, int S, int W,
+                                              int B, LaneInfo li) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * li.N * li.TP * W;
+  if (idx >= total) return;
+  const int c = (int)(idx % W);
+  long q = idx / W;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int i = (int)(q % li.N);
+  const int b = (int)(q / li.N);
+  real acc = 0;
+  if (t < li.T) {
+    for (int s = 0; s < S; ++s) {
+      const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
+      if (row < 0) continue;
+      const real* a = we + (((long)b * we_rows + row) * li.TP) * we_width + c;
+      const real* h = hx + (((long)b * li.N + snd) * li.TP) * hx_width + c;
+      const real a0 = a[0], h0 = h[0];
+      if (t == 0) {
+        acc += a0 * h0;
+      } else {
+        acc += a[(long)t * we_width] * h0 + a0 * h[(long)t * hx_width];
+        if (t == li.T - 1) {
+          real dot = 0;
+          for (int u = 1; u < li.T - 1; ++u) dot += a[(long)u * we_width] * h[(long)u * hx_width];
+          acc += 2 * dot;
+        }
+      }
+    }
+  }
+  out[(((long)b * li.N + i) * li.TP + t) * out_width + col0 + c] = acc;
+}
+
+// Edge sum/mean feature, reference gnn/update_features.py:109-159 (linear in the lanes).
+template <typename real>
+__global__ void __launch_bounds__(256) k_edge_sum(const real* __restrict__ e, int e_rows, int e_width,
+                                                  real* __restrict__ out, int out_width, int col0,
+                                                  const int32_t* __restrict__ tab, int S, int W, real scale, int B,
+                                                  LaneInfo li) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * li.N * li.TP * W;
+  if (idx >= total) return;
+  const int c = (int)(idx % W);
+  long q = idx / W;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int i = (int)(q % li.N);
+  const int b = (int)(q / li.N);
+  real acc = 0;
+  for (int s = 0; s < S; ++s) {
+    const int row = tab[2 * (i * S + s)];
+    if (row >= 0) acc += e[(((long)b * e_rows + row) * li.TP + t) * e_width + c];
+  }
+  out[(((long)b * li.N + i) * li.TP + t) * out_width + col0 + c] = acc * scale;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+
+static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
+template <typename real>
+void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B, int n_nuc, int n_up, int width,
+                    LaneInfo li, double eps, int log_rescale, int use_spin) {
+  const long total = (long)B * li.N * li.TP * n_nuc;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_en<real>), dim3(nblk(total)), dim3(256), 0, st, r, R, x, B, n_nuc, n_up,
+                     width, li, eps, log_rescale, use_spin);
+}
+template <typename real>
+void launch_feat_ee(hipStream_t st, const real* r, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
+                    double eps, int log_rescale) {
+  const long total = (long)B * n_rows * li.TP;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_ee<real>), dim3(nblk(total)), dim3(256), 0, st, r, pairs, e, B, n_rows,
+                     li, eps, log_rescale);
+}
+template <typename real>
+void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li) {
+  const long total = (long)B * 2 * li.TP * width;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spin_mean<real>), dim3(nblk(total)), dim3(256), 0, st, x, m, B, n_up, width, li);
+}
+template <typename real>
+void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int width, LaneInfo li) {
+  const long total = (long)B * li.TP * width;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_sum<real>), dim3(nblk(total)), dim3(256), 0, st, x, s, B, rows, width, li);
+}
+template <typename real>
+void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
+                 int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li) {
+  const long total = (long)B * li.N * li.TP * W;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx,
+                     hx_width, out, out_width, col0, tab, S, W, B, li);
+}
+template <typename real>
+void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,
+                     const int32_t* tab, int S, int W, double scale, int B, LaneInfo li) {
+  const long total = (long)B * li.N * li.TP * W;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_sum<real>), dim3(nblk(total)), dim3(256), 0, st, e, e_rows, e_width, out,
+                     out_width, col0, tab, S, W, (real)scale, B, li);
+}
+
+#define DQMC_INST(real)                                                                                              \
+  template void launch_feat_en<real>(hipStream_t, const real*, const real*, real*, int, int, int, int, LaneInfo,     \
+                                     double, int, int);                                                              \
+  template void launch_feat_ee<real>(hipStream_t, const real*, const int32_t*, real*, int, int, LaneInfo, double,    \
+                                     int);                                                                           \
+  template void launch_spin_mean<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                    \
+  template void launch_row_sum<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                      \
+  template void launch_conv<real>(hipStream_t, const real*, int, int, const real*, int, real*, int, int,             \
+                                  const int32_t*, int, int, int, LaneInfo);                                          \
+  template void launch_edge_sum<real>(hipStream_t, const real*, int, int, real*, int, int, const int32_t*, int, int, \
+                                      double, int, LaneInfo);
+DQMC_INST(float)
+DQMC_INST(double)
+#undef DQMC_INST
+
+}  // namespace dqmc

@@ -1,0 +1,329 @@
+// kernels_head.hip -- the Slater-determinant head of the wave function and the local-energy
+// assembly: envelope * backflow -> K Slater matrices (with lanes) -> slogdet and its
+// derivative traces (LDS-resident inverse, wave shuffles for the trace reductions) ->
+// CI sum + cusps + Jastrow -> kinetic energy + Coulomb terms.
+#include "common.h"
+#include "kernels.h"
+
+namespace dqmc {
+
+// A[b][k][t][i*N + mu] = lane t of envelope(i; k,mu) * backflow(i; k,mu).
+// Envelope: sum_a pi[k*N+mu][a] * exp(-|zeta[k*N+mu][a]| rho_ia)   (reference wf/env.py:57-75,
+// isotropic, per-orbital exponents, one shell per nucleus); it depends on r_i only, so its
+// derivative lanes are the three of electron i and the Laplacian.  Backflow is dense.
+template <typename real>
+__global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, const real* __restrict__ R,
+                                                  const real* __restrict__ bf, int bf_width, real* __restrict__ orb,
+                                                  int orb_width, const real* __restrict__ pi_up,
+                                                  const real* __restrict__ pi_dn, const real* __restrict__ ze_up,
+                                                  const real* __restrict__ ze_dn, int B, int n_up, int n_nuc, int K,
+                                                  LaneInfo li, double eps) {
+  const int N = li.N, KN = K * N;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * N * li.TP * KN;
+  if (idx >= total) return;
+  const int kmu = (int)(idx % KN);
+  long q = idx / KN;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int i = (int)(q % N);
+  const int b = (int)(q / N);
+  const int k = kmu / N, mu = kmu - k * N;
+  real out = 0;
+  if (t < li.T) {
+    const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc;
+    const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc;
+    double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
+    const bool need_d = li.T > 1;
+    for (int a = 0; a < n_nuc; ++a) {
+      double d[3];
+      for (int c = 0; c < 3; ++c) d[c] = (double)r[((long)b * N + i) * 3 + c] - (double)R[a * 3 + c];
+      const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+      const double rho = sqrt(eps + d2);
+      const double z = fabs((double)ze[a]);
+      const double w = (double)pi[a] * exp(-z * rho);
+      e0 += w;
+      if (need_d) {
+        for (int c = 0; c < 3; ++c) eJ[c] += -z * w * d[c] / rho;
+        eL += w * (z * z * d2 / (rho * rho) - z * (3.0 / rho - d2 / (rho * rho * rho)));
+      }
+    }
+    const real* brow = bf + (((long)b * N + i) * li.TP) * bf_width + kmu;
+    const double b0 = (double)brow[0];
+    double o;
+    if (t == 0) {
+      o = e0 * b0;
+    } else {
+      const double bt = (double)brow[(long)t * bf_width];
+      o = e0 * bt;
+      if (t < li.T - 1) {
+        const int c = t - 1;
+        if (c / 3 == i) o += eJ[c - 3 * i] * b0;
+      } else {  // Laplacian lane
+        o += eL * b0;
+        for (int c = 0; c < 3; ++c) o += 2.0 * eJ[c] * (double)brow[(long)(1 + 3 * i + c) * bf_width];
+      }
+    }
+    out = (real)o;
+  }
+  orb[(((long)b * K + k) * li.TP + t) * orb_width + i * N + mu] = out;
+}
+
+// slogdet of one N x N matrix per wave plus its forward-Laplacian lanes:
+//   J_c = tr(A^-1 dA_c),   L = tr(A^-1 A_L) - sum_c tr((A^-1 dA_c)^2)        
+// Gauss-Jordan with partial pivoting in LDS (double), sign = (-1)^swaps * prod sign(pivot)
+// -- the restatement of LAPACK getrf's sign/log|det| used by jnp.linalg.slogdet
+// (reference wf/nn_wave_function.py:36-39).  One 64-lane workgroup per (walker, determinant).
+template <typename real, int NMAX>
+__global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, int orb_width,
+                                                double* __restrict__ logdet, int32_t* __restrict__ sign_k, int K,
+                                                LaneInfo li) {
+  __shared__ double A[NMAX * NMAX];
+  __shared__ double Inv[NMAX * NMAX];
+  __shared__ double M[NMAX * NMAX];
+  __shared__ double colp[NMAX];
+  __shared__ int piv_s;
+  const int N = li.N, NN = N * N;
+  const int lane = threadIdx.x;
+  const long bk = blockIdx.x;  // b*K + k
+  const real* base = orb + bk * li.TP * orb_width;
+  for (int e = lane; e < NN; e += 64) {
+    A[e] = (double)base[e];
+    Inv[e] = (e / N == e % N) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double logabs = 0.0;
+  int sgn = 1;
+  for (int p = 0; p < N; ++p) {
+    if (lane == 0) {
+      int best = p;
+      double bv = fabs(A[p * N + p]);
+      for (int i = p + 1; i < N; ++i) {
+        const double v = fabs(A[i * N + p]);
+        if (v > bv) { bv = v; best = i; }   // first maximum, as LAPACK idamax
+      }
+      piv_s = best;
+    }
+    __syncthreads();
+    const int q = piv_s;
+    if (q != p) {
+      for (int j = lane; j < N; j += 64) {
+        double t0 = A[p * N + j]; A[p * N + j] = A[q * N + j]; A[q * N + j] = t0;
+        t0 = Inv[p * N + j]; Inv[p * N + j] = Inv[q * N + j]; Inv[q * N + j] = t0;
+      }
+      sgn = -sgn;
+    }
+    __syncthreads();
+    const double piv = A[p * N + p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) sgn = 0;
+    __syncthreads();
+    const double ip = 1.0 / piv;
+    for (int j = lane; j < N; j += 64) { A[p * N + j] *= ip; Inv[p * N + j] *= ip; }
+    for (int i = lane; i < N; i += 64) colp[i] = A[i * N + p];
+    __syncthreads();
+    for (int e = lane; e < NN; e += 64) {
+      const int i = e / N, j = e - i * N;
+      if (i != p) {
+        const double f = colp[i];
+        A[e] -= f * A[p * N + j];
+        Inv[e] -= f * Inv[p * N + j];
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
+  if (li.T == 1) return;
+  double tr2_sum = 0.0;
+  for (int t = 1; t < li.T; ++t) {
+    const real* At = base + (long)t * orb_width;
+    for (int e = lane; e < NN; e += 64) A[e] = (double)At[e];
+    __syncthreads();
+    double tr = 0.0;
+    for (int e = lane; e < NN; e += 64) {
+      const int i = e / N, l = e - i * N;
+      double m = 0.0;
+      for (int j = 0; j < N; ++j) m += Inv[i * N + j] * A[j * N + l];
+      M[e] = m;
+      if (i == l) tr += m;
+    }
+    __syncthreads();
+    tr = wave_sum<double>(tr);
+    if (t < li.T - 1) {
+      double t2 = 0.0;
+      for (int e = lane; e < NN; e += 64) {
+        const int i = e / N, l = e - i * N;
+        t2 += M[e] * M[l * N + i];
+      }
+      tr2_sum += wave_sum<double>(t2);
+      if (lane == 0) logdet[bk * li.TP + t] = tr;
+    } else if (lane == 0) {
+      logdet[bk * li.TP + t] = tr - tr2_sum;
+    }
+    __syncthreads();
+  }
+  for (int t = li.T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
+}
+
+// CI sum, cusps, Jastrow, and (Laplacian mode) the local energy.  One thread per walker;
+// double arithmetic (the cancellation Delta + |grad|^2 is the sensitive spot).
+template <typename real>
+__global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  const int N = a.li.N, T = a.li.T, TP = a.li.TP, K = a.K;
+  const real* r = reinterpret_cast<const real*>(a.r) + (long)b * N * 3;
+  const real* R = reinterpret_cast<const real*>(a.R);
+  const double* x = a.logdet + (long)b * K * TP;
+  const int32_t* sk = a.sign_k + (long)b * K;
+  const real* cc = reinterpret_cast<const real*>(a.conf_coeff);
+  // exp-normalised CI sum, reference wf/nn_wave_function.py:152-160
+  double shift = -INFINITY;
+  for (int k = 0; k < K; ++k) shift = fmax(shift, x[(long)k * TP]);
+  if (isinf(shift)) shift = 0.0;
+  double psi = 0.0;
+  for (int k = 0; k < K; ++k) psi += (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift);
+  double logpsi = log(fabs(psi)) + shift;
+  const int sign = (psi > 0) - (psi < 0);
+  // cusps (value), reference wf/cusp.py:5-26,68-78
+  const real* al = reinterpret_cast<const real*>(a.alphas);
+  double cusp = 0.0;
+  if (a.cusp_kind) {
+    for (int i = 0; i < N; ++i)
+      for (int j = i + 1; j < N; ++j) {
+        double d2 = a.eps;
+        for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
+        const double rho = sqrt(d2);
+        const bool same = (i < a.n_up) == (j < a.n_up);
+        const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
+        cusp += a.cusp_kind == 1 ? -sc / (alp * (1 + alp * rho)) : -sc * alp * alp / (alp + rho);
+      }
+  }
+  const real* jas = reinterpret_cast<const real*>(a.jastrow);
+  const real* jrow = jas ? jas + (long)b * TP * a.jas_width : nullptr;
+  logpsi += cusp + (jrow ? (double)jrow[0] : 0.0);
+  if (a.logpsi) reinterpret_cast<real*>(a.logpsi)[b] = (real)logpsi;
+  if (a.sign) a.sign[b] = sign;
+  if (T == 1) return;
+
+  // ---- gradient and Laplacian of log|psi| ----
+  double lap = 0.0, qf2 = 0.0, sumJ2 = 0.0;
+  for (int k = 0; k < K; ++k) {
+    const double pk = (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift) / psi;
+    double s2 = 0.0;
+    for (int t = 1; t < T - 1; ++t) { const double j = x[(long)k * TP + t]; s2 += j * j; }
+    lap += pk * (x[(long)k * TP + T - 1] + s2);
+  }
+  real* grad = reinterpret_cast<real*>(a.grad);
+  for (int t = 1; t < T - 1; ++t) {
+    const int c = t - 1, e = c / 3, xyz = c - 3 * e;
+    double g = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double pk = (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift) / psi;
+      g += pk * x[(long)k * TP + t];
+    }
+    sumJ2 += g * g;   // CI part only: subtracted in the Laplacian of the log-sum
+    if (jrow) g += (double)jrow[(long)t * a.jas_width];
+    if (a.cusp_kind) {  // d/dr_e of the pair cusps involving electron e
+      for (int j = 0; j < N; ++j) {
+        if (j == e) continue;
+        double dv[3], d2 = a.eps;
+        for (int c2 = 0; c2 < 3; ++c2) { dv[c2] = (double)r[e * 3 + c2] - (double)r[j * 3 + c2]; d2 += dv[c2] * dv[c2]; }
+        const double rho = sqrt(d2);
+        const bool same = (e < a.n_up) == (j < a.n_up);
+        const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
+        const double g1 = a.cusp_kind == 1 ? sc / ((1 + alp * rho) * (1 + alp * rho))
+                                           : sc * alp * alp / ((alp + rho) * (alp + rho));
+        g += g1 * dv[xyz] / rho;
+      }
+    }
+    qf2 += g * g;
+    if (grad) grad[(long)b * (3 * N) + c] = (real)g;
+  }
+  lap -= sumJ2;
+  if (jrow) lap += (double)jrow[(long)(T - 1) * a.jas_width];
+  double v_el = 0.0;
+  for (int i = 0; i < N; ++i)
+    for (int j = i + 1; j < N; ++j) {
+      double d2 = 0.0;
+      for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
+      const double rho = sqrt(a.eps + d2);
+      v_el += 1.0 / rho;                                    // reference physics.py:119-121 (safe norm)
+      if (a.cusp_kind) {
+        const bool same = (i < a.n_up) == (j < a.n_up);
+        const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
+        double g1, g2;
+        if (a.cusp_kind == 1) {
+          const double u = 1 + alp * rho;
+          g1 = sc / (u * u); g2 = -2 * sc * alp / (u * u * u);
+        } else {
+          const double u = alp + rho;
+          g1 = sc * alp * alp / (u * u); g2 = -2 * sc * alp * alp / (u * u * u);
+        }
+        // both electrons: 2 * (g'' |grad rho|^2 + g' Lap rho)
+        lap += 2.0 * (g2 * d2 / (rho * rho) + g1 * (3.0 / rho - d2 / (rho * rho * rho)));
+      }
+    }
+  double v_loc = 0.0;
+  for (int i = 0; i < N; ++i)
+    for (int n = 0; n < a.n_nuc; ++n) {
+      double d2 = 0.0;
+      for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)R[n * 3 + c]; d2 += d * d; }
+      v_loc -= a.charges[n] / sqrt(d2);                     // reference physics.py:131-133 (plain norm)
+    }
+  const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
+  const double e_loc = e_kin + v_loc + v_el + a.e_nuc;      // reference hamil.py:172 (V_nl = 0)
+  if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
+  if (a.stats) {
+    real* s = reinterpret_cast<real*>(a.stats);
+    s[0L * a.B + b] = (real)v_el;
+    s[1L * a.B + b] = (real)e_kin;
+    s[2L * a.B + b] = (real)v_loc;
+    s[3L * a.B + b] = (real)0;
+    s[4L * a.B + b] = (real)lap;
+    s[5L * a.B + b] = (real)qf2;
+  }
+}
+
+template <typename real>
+void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
+                     int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
+                     int n_up, int n_nuc, int K, LaneInfo li, double eps) {
+  const long total = (long)B * li.N * li.TP * K * li.N;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_orbitals<real>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r, R,
+                     bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, K, li, eps);
+}
+
+template <typename real>
+void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
+                    LaneInfo li) {
+  const unsigned grid = (unsigned)((long)B * K);
+  if (li.N <= 8)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
+                       sign_k, K, li);
+  else if (li.N <= 16)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 16>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
+                       sign_k, K, li);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 44>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
+                       sign_k, K, li);
+}
+
+template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<real>), dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, st, a);
+}
+
+#define DQMC_INST(real)                                                                                              \
+  template void launch_orbitals<real>(hipStream_t, const real*, const real*, const real*, int, real*, int,           \
+                                      const real*, const real*, const real*, const real*, int, int, int, int,        \
+                                      LaneInfo, double);                                                             \
+  template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo);          \
+  template void launch_final<real>(hipStream_t, const FinalArgs&);
+DQMC_INST(float)
+DQMC_INST(double)
+#undef DQMC_INST
+
+}  // namespace dqmc

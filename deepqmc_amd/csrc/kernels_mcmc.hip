@@ -1,0 +1,231 @@
+// kernels_mcmc.hip -- Metropolis propose / accept / step-size adaptation, sampler statistics and
+// the per-rank energy record.  Reference: sampling/electron_samplers.py:102-163.
+#include "common.h"
+#include "kernels.h"
+
+namespace dqmc {
+
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: (seed, stream, index) -> 4 x u32 ----
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[4]) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // [0,1) with 53 bits
+  return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// noise ~ N(0,1) (Box-Muller, two per counter), unif ~ U[0,1).
+template <typename real>
+__global__ void __launch_bounds__(256) k_rng(real* __restrict__ noise, long n_noise, real* __restrict__ unif,
+                                             long n_unif, uint64_t seed, uint64_t stream_id) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n_pairs = (n_noise + 1) / 2;
+  uint32_t o[4];
+  if (idx < n_pairs) {
+    philox4x32(seed, 2 * stream_id, (uint64_t)idx, o);
+    const double u1 = 1.0 - u01(o[0], o[1]);   // (0,1]
+    const double u2 = u01(o[2], o[3]);
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586 * u2;
+    noise[2 * idx] = (real)(rad * cos(ang));
+    if (2 * idx + 1 < n_noise) noise[2 * idx + 1] = (real)(rad * sin(ang));
+  }
+  if (idx < n_unif) {
+    philox4x32(seed, 2 * stream_id + 1, (uint64_t)idx, o);
+    if (sizeof(real) == 4) unif[idx] = (real)((float)(o[0] >> 8) * (1.0f / 16777216.0f));
+    else unif[idx] = (real)u01(o[0], o[1]);
+  }
+}
+
+// r' = r + tau * xi   (electron_samplers.py:102-104)
+template <typename real>
+__global__ void __launch_bounds__(256) k_propose(const real* __restrict__ r, const real* __restrict__ noise,
+                                                 const real* __restrict__ tau, real* __restrict__ r_prop, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < n) r_prop[idx] = r[idx] + tau[0] * noise[idx];
+}
+
+// accept = 2 (log|psi'| - log|psi|) > log u  [| age >= max_age];  select r/psi; age bookkeeping
+// (electron_samplers.py:106-138).  A NaN proposal compares false and is rejected.
+template <typename real>
+__global__ void __launch_bounds__(256) k_accept(real* __restrict__ r, real* __restrict__ logpsi,
+                                                int32_t* __restrict__ sign, int32_t* __restrict__ age,
+                                                const real* __restrict__ r_prop, const real* __restrict__ lp_prop,
+                                                const int32_t* __restrict__ sign_prop, const real* __restrict__ unif,
+                                                int max_age, int B, int N, int32_t* __restrict__ n_accept,
+                                                uint8_t* __restrict__ accept_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const real log_prob = 2 * (lp_prop[b] - logpsi[b]);
+  const real lu = sizeof(real) == 4 ? (real)logf((float)unif[b]) : (real)log((double)unif[b]);
+  bool acc = log_prob > lu;
+  if (max_age >= 0) acc = acc || (age[b] >= max_age);
+  if (acc) {
+    for (int k = 0; k < 3 * N; ++k) r[(long)b * 3 * N + k] = r_prop[(long)b * 3 * N + k];
+    logpsi[b] = lp_prop[b];
+    sign[b] = sign_prop[b];
+    age[b] = 0;
+    atomicAdd(n_accept, 1);
+  } else {
+    age[b] = age[b] + 1;
+  }
+  if (accept_out) accept_out[b] = acc ? 1 : 0;
+}
+
+// tau <- tau * max(acceptance, 0.05) / target   (electron_samplers.py:121-126); resets the counter.
+template <typename real>
+__global__ void k_tau_update(real* __restrict__ tau, int32_t* __restrict__ n_accept, int B, double target,
+                             double* __restrict__ acc_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const real acceptance = (real)n_accept[0] / (real)B;
+    if (target > 0) {
+      const real m = acceptance > (real)0.05 ? acceptance : (real)0.05;
+      tau[0] = tau[0] / ((real)target / m);
+    }
+    acc_out[0] = (double)n_accept[0] / (double)B;
+    n_accept[0] = 0;
+  }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+  v = wave_sum<double>(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double t = 0;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ double block_max(double v, double* sh) {
+  for (int m = 1; m < 64; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double t = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmax(t, sh[i]);
+  return t;
+}
+
+// compute_stats (electron_samplers.py:154-163): acceptance, tau, age mean/max, log|psi| mean/std
+// (population), mean pairwise e-e distance.  One 256-thread block.
+template <typename real>
+__global__ void __launch_bounds__(256) k_sampler_stats(const real* __restrict__ r, const real* __restrict__ logpsi,
+                                                       const int32_t* __restrict__ age, const real* __restrict__ tau,
+                                                       const double* __restrict__ acc, int B, int N, double eps,
+                                                       double* __restrict__ out7) {
+  __shared__ double sh[4];
+  double s_age = 0, m_age = 0, s_lp = 0, s_d = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    s_age += age[b];
+    m_age = fmax(m_age, (double)age[b]);
+    s_lp += (double)logpsi[b];
+    const real* rb = r + (long)b * 3 * N;
+    for (int i = 0; i < N; ++i)
+      for (int j = i + 1; j < N; ++j) {
+        double d2 = eps;
+        for (int c = 0; c < 3; ++c) { const double d = (double)rb[3 * i + c] - (double)rb[3 * j + c]; d2 += d * d; }
+        s_d += sqrt(d2);
+      }
+  }
+  s_age = block_sum(s_age, sh);
+  m_age = block_max(m_age, sh);
+  s_lp = block_sum(s_lp, sh);
+  s_d = block_sum(s_d, sh);
+  const double mean_lp = s_lp / B;
+  double v = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) { const double d = (double)logpsi[b] - mean_lp; v += d * d; }
+  v = block_sum(v, sh);
+  if (threadIdx.x == 0) {
+    out7[0] = acc[0];
+    out7[1] = (double)tau[0];
+    out7[2] = s_age / B;
+    out7[3] = m_age;
+    out7[4] = mean_lp;
+    out7[5] = sqrt(v / B);
+    out7[6] = s_d / ((double)B * (N * (N - 1) / 2));
+  }
+}
+
+// Per-rank record {n, sum_w, sum_wE, sum_E, M2, min, max} of the energy reduction
+// (observable.py:474-479, parallel.py:175-225), merged across ranks on the host.
+template <typename real>
+__global__ void __launch_bounds__(256) k_energy_stats(const real* __restrict__ e, const real* __restrict__ w, int B,
+                                                      double* __restrict__ out7) {
+  __shared__ double sh[4];
+  double sw = 0, swe = 0, se = 0, mn = INFINITY, mx = -INFINITY;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const double x = (double)e[b], ww = w ? (double)w[b] : 1.0;
+    sw += ww; swe += ww * x; se += x;
+    mn = fmin(mn, x); mx = fmax(mx, x);
+  }
+  sw = block_sum(sw, sh); swe = block_sum(swe, sh); se = block_sum(se, sh);
+  mx = block_max(mx, sh);
+  mn = -block_max(-mn, sh);
+  const double mean = se / B;
+  double m2 = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) { const double d = (double)e[b] - mean; m2 += d * d; }
+  m2 = block_sum(m2, sh);
+  if (threadIdx.x == 0) {
+    out7[0] = B; out7[1] = sw; out7[2] = swe; out7[3] = se; out7[4] = m2; out7[5] = mn; out7[6] = mx;
+  }
+}
+
+template <typename real>
+void launch_rng(hipStream_t st, real* noise, long n_noise, real* unif, long n_unif, uint64_t seed, uint64_t stream_id) {
+  const long n = ((n_noise + 1) / 2 > n_unif) ? (n_noise + 1) / 2 : n_unif;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rng<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, noise, n_noise,
+                     unif, n_unif, seed, stream_id);
+}
+template <typename real>
+void launch_propose(hipStream_t st, const real* r, const real* noise, const real* tau, real* r_prop, long n) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_propose<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, noise,
+                     tau, r_prop, n);
+}
+template <typename real>
+void launch_accept(hipStream_t st, real* r, real* logpsi, int32_t* sign, int32_t* age, const real* r_prop,
+                   const real* logpsi_prop, const int32_t* sign_prop, const real* unif, int max_age, int B, int N,
+                   int32_t* n_accept, uint8_t* accept_out) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_accept<real>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, r, logpsi,
+                     sign, age, r_prop, logpsi_prop, sign_prop, unif, max_age, B, N, n_accept, accept_out);
+}
+template <typename real>
+void launch_tau_update(hipStream_t st, real* tau, int32_t* n_accept, int B, double target, double* acc_out) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tau_update<real>), dim3(1), dim3(64), 0, st, tau, n_accept, B, target, acc_out);
+}
+template <typename real>
+void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, const int32_t* age, const real* tau,
+                          const double* acc, int B, int N, double eps, double* stats7) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sampler_stats<real>), dim3(1), dim3(256), 0, st, r, logpsi, age, tau, acc, B, N,
+                     eps, stats7);
+}
+template <typename real>
+void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B, double* out7) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_energy_stats<real>), dim3(1), dim3(256), 0, st, e_loc, w, B, out7);
+}
+
+#define DQMC_INST(real)                                                                                             \
+  template void launch_rng<real>(hipStream_t, real*, long, real*, long, uint64_t, uint64_t);                        \
+  template void launch_propose<real>(hipStream_t, const real*, const real*, const real*, real*, long);              \
+  template void launch_accept<real>(hipStream_t, real*, real*, int32_t*, int32_t*, const real*, const real*,        \
+                                    const int32_t*, const real*, int, int, int, int32_t*, uint8_t*);                \
+  template void launch_tau_update<real>(hipStream_t, real*, int32_t*, int, double, double*);                        \
+  template void launch_sampler_stats<real>(hipStream_t, const real*, const real*, const int32_t*, const real*,      \
+                                           const double*, int, int, double, double*);                               \
+  template void launch_energy_stats<real>(hipStream_t, const real*, const real*, int, double*);
+DQMC_INST(float)
+DQMC_INST(double)
+#undef DQMC_INST
+
+}  // namespace dqmc

@@ -1,0 +1,199 @@
+"""Engine: one HIP context (`dqmc_ctx`) = one ansatz + parameter set on one GPU.
+
+Host glue only: compiles the layer program (program.py), hands it to the C ABI
+(include/dqmc.h) and moves raw device pointers of torch tensors across it.  torch is used
+for device memory and streams, nothing else.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .hamil import STAT_KEYS, MolecularHamiltonian
+from .program import DqmcSystem, Program, compile_program
+from .spec import AnsatzSpec
+from .types import PhysicalConfiguration
+
+F32_EPS = float(np.finfo(np.float32).eps)
+F64_EPS = float(np.finfo(np.float64).eps)
+SAMPLER_STAT_KEYS = ('sampling/acceptance', 'sampling/tau', 'sampling/age/mean', 'sampling/age/max',
+                     'sampling/log_psi/mean', 'sampling/log_psi/std', 'sampling/dists/mean')
+
+
+class DqmcError(RuntimeError):
+    pass
+
+
+def nuclear_energy(coords: np.ndarray, charges: np.ndarray) -> float:
+    """sum_{a<b} Z_a Z_b / R_ab (reference physics.py:112-116); constant per geometry."""
+    e = 0.0
+    for a in range(len(charges)):
+        for b in range(a + 1, len(charges)):
+            e += charges[a] * charges[b] / float(np.linalg.norm(coords[a] - coords[b]))
+    return e
+
+
+class Engine:
+    def __init__(self, spec: AnsatzSpec, hamil: MolecularHamiltonian, params, *, dtype=torch.float32,
+                 device='cuda', norm_eps: Optional[float] = None, lib=None):
+        self.lib = lib if lib is not None else _lib.load()
+        self.spec, self.hamil = spec, hamil
+        self.dtype = dtype
+        self.device = torch.device(device)
+        if dtype not in (torch.float32, torch.float64):
+            raise ValueError('dtype must be float32 or float64')
+        # eps under the safe norm is the compute dtype's machine eps (reference utils.py:79-85)
+        self.norm_eps = norm_eps if norm_eps is not None else (F32_EPS if dtype == torch.float32 else F64_EPS)
+        self.program: Program = compile_program(spec, params, hamil.n_up, hamil.n_down, hamil.n_nuc)
+        self.N = hamil.n_up + hamil.n_down
+        sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,
+                          0 if dtype == torch.float32 else 1, 0, self.norm_eps,
+                          nuclear_energy(hamil.mol.coords, hamil.ns_valence))
+        p = self.program
+        self._bufs, self._ops = p.c_bufs(), p.c_ops()
+        w = np.ascontiguousarray(p.weights, np.float64)
+        it = np.ascontiguousarray(p.itable if p.itable.size else np.zeros(1, np.int32), np.int32)
+        ch = np.ascontiguousarray(hamil.ns_valence, np.float64)
+        stream = 0
+        dev_index = 0
+        if self.device.type == 'cuda':
+            dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        ctx = ctypes.c_void_p()
+        rc = self.lib.dqmc_create(ctypes.byref(ctx), dev_index, ctypes.c_void_p(stream), ctypes.byref(sysd),
+                                  ch.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), self._bufs, len(p.bufs),
+                                  self._ops, len(p.ops), w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size,
+                                  it.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p.itable.size)
+        self._ctx = ctx
+        self._check(rc)
+        self.R = torch.as_tensor(hamil.mol.coords, dtype=dtype, device=self.device).contiguous()
+
+    # ------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DqmcError(f'dqmc error {rc}: {self.lib.dqmc_last_error().decode()}')
+
+    def close(self):
+        if getattr(self, '_ctx', None):
+            self.lib.dqmc_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _t(self, x, dtype=None):
+        return torch.as_tensor(x, dtype=dtype or self.dtype, device=self.device).contiguous()
+
+    def _R(self, R):
+        if R is None:
+            return self.R
+        R = self._t(R)
+        if R.dim() == 3:      # reference tiles R per walker (electron_samplers.py:165-173)
+            R = R[0].contiguous()
+        return R
+
+    def set_params(self, params):
+        """New parameter tree after an optimiser step (same structure)."""
+        prog = compile_program(self.spec, params, self.hamil.n_up, self.hamil.n_down, self.hamil.n_nuc)
+        w = np.ascontiguousarray(prog.weights, np.float64)
+        self._check(self.lib.dqmc_set_weights(self._ctx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size))
+
+    # ---- ansatz.apply ---------------------------------------------------
+    def wf_eval(self, r, R=None):
+        r = self._t(r)
+        B = r.shape[0]
+        assert r.shape[1:] == (self.N, 3)
+        logpsi = torch.empty(B, dtype=self.dtype, device=self.device)
+        sign = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.dqmc_wf_eval(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, logpsi.data_ptr(),
+                                          sign.data_ptr()))
+        return sign, logpsi
+
+    # ---- hamil.local_energy ---------------------------------------------
+    def local_energy(self, phys_conf, rng=None, return_grad=False):
+        if isinstance(phys_conf, PhysicalConfiguration):
+            r, R = phys_conf.r, phys_conf.R
+        else:
+            r, R = phys_conf, None
+        r = self._t(r)
+        B = r.shape[0]
+        assert r.shape[1:] == (self.N, 3)
+        e = torch.empty(B, dtype=self.dtype, device=self.device)
+        st = torch.empty(6, B, dtype=self.dtype, device=self.device)
+        grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device) if return_grad else None
+        self._check(self.lib.dqmc_local_energy(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, e.data_ptr(),
+                                               st.data_ptr(), grad.data_ptr() if return_grad else None, None, None))
+        stats = {k: st[i] for i, k in enumerate(STAT_KEYS)}
+        return (e, stats, grad) if return_grad else (e, stats)
+
+    # ---- sampler ----------------------------------------------------------
+    def mcmc_steps(self, state: Dict[str, torch.Tensor], n_sub: int, *, max_age=None, target_acceptance=0.57,
+                   seed: int = 0, noise=None, unif=None, R=None, want_stats=True, return_accept=False):
+        """In-place Metropolis sub-steps on state {'r','log','sign','age','tau'} (device tensors)."""
+        r, B = state['r'], state['r'].shape[0]
+        acc = torch.empty(n_sub, B, dtype=torch.uint8, device=self.device) if return_accept else None
+        stats = (ctypes.c_double * 7)()
+        if noise is not None:
+            noise, unif = self._t(noise), self._t(unif)
+            assert noise.shape == (n_sub, B, self.N, 3) and unif.shape == (n_sub, B)
+        rc = self.lib.dqmc_mcmc_steps(
+            self._ctx, r.data_ptr(), state['log'].data_ptr(), state['sign'].data_ptr(), state['age'].data_ptr(),
+            state['tau'].data_ptr(), self._R(R).data_ptr(), B, n_sub, -1 if max_age is None else int(max_age),
+            -1.0 if target_acceptance is None else float(target_acceptance), int(seed),
+            noise.data_ptr() if noise is not None else None, unif.data_ptr() if unif is not None else None,
+            acc.data_ptr() if return_accept else None, stats if want_stats else None)
+        self._check(rc)
+        out = dict(zip(SAMPLER_STAT_KEYS, list(stats))) if want_stats else {}
+        return (out, acc) if return_accept else out
+
+    def energy_record(self, e_loc, w=None):
+        rec = (ctypes.c_double * 7)()
+        self._check(self.lib.dqmc_energy_stats(self._ctx, e_loc.data_ptr(), w.data_ptr() if w is not None else None,
+                                               e_loc.shape[0], rec))
+        return np.array(list(rec))
+
+    def merge_energy_records(self, records: np.ndarray):
+        records = np.ascontiguousarray(records, np.float64).reshape(-1, 7)
+        out = (ctypes.c_double * 5)()
+        self._check(self.lib.dqmc_merge_energy_stats(records.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                                     records.shape[0], out))
+        return dict(zip(('local_energy/mean', 'local_energy/std', 'local_energy/min', 'local_energy/max',
+                         'local_energy/weighted_mean'), list(out)))
+
+    # ---- debug / timing ---------------------------------------------------
+    def debug_read(self, name_or_idx, B: int):
+        TP = self.lib.dqmc_debug_lanes(self._ctx)
+        if name_or_idx == 'logdet':
+            shape, idx = (B, self.spec.n_determinants, TP), -1
+        elif name_or_idx == 'sign_k':
+            shape, idx = (B, self.spec.n_determinants), -2
+        else:
+            idx = self.program.buf_names[name_or_idx] if isinstance(name_or_idx, str) else int(name_or_idx)
+            rows, width = self.program.bufs[idx]
+            shape = (B, rows, TP, width)
+        out = np.empty(shape, np.float64)
+        self._check(self.lib.dqmc_debug_read(self._ctx, idx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
+        return out
+
+    def timing(self, enable=True):
+        self._check(self.lib.dqmc_timing_enable(self._ctx, int(enable)))
+
+    def timing_reset(self):
+        self._check(self.lib.dqmc_timing_reset(self._ctx))
+
+    def timing_report(self):
+        buf = ctypes.create_string_buffer(1024)
+        self._check(self.lib.dqmc_timing_names(self._ctx, buf, 1024))
+        out = {}
+        for nm in filter(None, buf.value.decode().split(',')):
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            self._check(self.lib.dqmc_timing_get(self._ctx, nm.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
+            out[nm] = {'ms': ms.value, 'launches': n.value, 'flops': fl.value}
+        return out

@@ -20,7 +20,7 @@ from .spec import AnsatzSpec, MLPSpec
 OP_FEAT_EN, OP_FEAT_EE, OP_LINEAR, OP_SPIN_MEAN, OP_CONV, OP_EDGE_SUM, OP_ROW_SUM = 1, 2, 3, 4, 5, 6, 7
 OP_ORBITALS, OP_SLOGDET, OP_FINAL, OP_ATTENTION = 8, 9, 10, 11
 ACT = {None: 0, 'tanh': 1, 'silu': 2}
-N_OP_I = 27
+N_OP_I = 28
 
 
 def pad4(n: int) -> int:
@@ -180,8 +180,8 @@ class _Builder:
         for p in pieces:
             i += list(p)
         i += [0] * (17 - len(i))
-        i += [dst, dst_r0, dst_col0, nrows, nout, w_off, b_off, ACT[act], res, res_r0]
-        self.ops.append(Op(OP_LINEAR, i, [res_scale, 0, 0, 0], note or module))
+        i += [dst, dst_r0, dst_col0, nrows, nout, w_off, b_off, ACT[act], res, res_r0, int(res_scale != 1.0)]
+        self.ops.append(Op(OP_LINEAR, i, [0, 0, 0, 0], note or module))
         self.flops += 2.0 * nrows * sum(p[2] for p in pieces) * nout
         return nout
 

@@ -68,8 +68,8 @@ enum dqmc_op_kind {
    * width used), bcast (1: every dst row of a walker reads src row r0);
    * [17]=dst buf [18]=dst r0 [19]=dst col0 [20]=nrows (per walker) [21]=Nout
    * [22]=W offset [23]=bias offset or -1 [24]=act (0 none,1 tanh,2 silu)
-   * [25]=residual buf or -1 [26]=residual r0.   f: [0]=residual scale
-   * (out = (res + y) * scale).  W is row-major [sum_p pad4(K_p)][pad4(Nout)]. */
+   * [25]=residual buf or -1 [26]=residual r0 [27]=normalize (1: out = (res + y)/sqrt(2),
+   * 0: out = res + y; hkext.py:130-137).  W is row-major [sum_p pad4(K_p)][pad4(Nout)]. */
   DQMC_OP_LINEAR = 3,
   /* i: [0]=src buf [1]=dst buf (rows = 2) [2]=n_up.  Mean over up / down electrons
    * (gnn/update_features.py:86-102). */
@@ -106,7 +106,7 @@ enum dqmc_op_kind {
 
 typedef struct dqmc_op {
   int32_t kind;
-  int32_t i[27];
+  int32_t i[28];
   float f[4];
 } dqmc_op;
 

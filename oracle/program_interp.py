@@ -145,7 +145,7 @@ class Interp:
     def op_3(self, op):  # LINEAR
         i = op.i
         npieces = i[0]
-        dst, dr0, dc0, nrows, nout, woff, boff, act, res, rr0 = i[17:27]
+        dst, dr0, dc0, nrows, nout, woff, boff, act, res, rr0, rnorm = i[17:28]
         nout_p = P.pad4(nout)
         acc = np.zeros((self.B, nrows, self.TP, nout_p))
         o = woff
@@ -170,7 +170,7 @@ class Interp:
             y = self._chain(y, v * s, d1, d2)
         y = self._ll(y)
         if res >= 0:
-            y = (self.bufs[res][:, rr0:rr0 + nrows, :, dc0:dc0 + nout_p] + y) * op.f[0]
+            y = (self.bufs[res][:, rr0:rr0 + nrows, :, dc0:dc0 + nout_p] + y) * (1 / math.sqrt(2.0) if rnorm else 1.0)
         self.bufs[dst][:, dr0:dr0 + nrows, :, dc0:dc0 + nout_p] = y
 
     def op_4(self, op):  # SPIN_MEAN

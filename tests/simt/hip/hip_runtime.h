@@ -1,0 +1,126 @@
+// SIMT emulation shim -- TEST INFRASTRUCTURE ONLY (tests/simt).
+//
+// Lets the unmodified kernel sources of deepqmc_amd/csrc be compiled with g++ and executed
+// on the host so that kernel index arithmetic (MFMA fragment layouts, lane shuffles, LDS
+// tiling, barriers) can be checked against the CPU oracle in a container without a GPU.
+// Every workgroup runs as one set of cooperatively scheduled fibers (ucontext), one per
+// thread; __syncthreads / wave shuffles / MFMA are rendezvous points.  The product library
+// (libdqmc_hip.so) is never built from or linked against this file, and the product Python
+// package never loads the emulated library.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <functional>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+#define hipSuccess 0
+typedef struct simt_stream* hipStream_t;
+typedef struct simt_event { double t; }* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+inline const char* hipGetErrorString(hipError_t) { return "simt-emu"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipMalloc(void** p, size_t n) { *p = calloc(n ? n : 1, 1); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new simt_event{0}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+  e->t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  return hipSuccess;
+}
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+
+namespace simt {
+void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+// wave rendezvous: deposit 16 bytes per lane, then read another lane's deposit
+void wave_exchange(const void* mine, size_t n, int src_lane, void* out);
+void wave_gather_begin(const void* a, const void* b, size_t n);   // deposit two values
+const char* wave_slot_a(int lane);
+const char* wave_slot_b(int lane);
+void wave_gather_end();
+int lane_id();
+}  // namespace simt
+
+template <typename K, typename... Args>
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+  simt::run_grid(grid, block, [=]() { kernel(args...); });
+}
+
+inline void __syncthreads() { simt::sync_block(); }
+template <typename T> inline T __shfl(T v, int src, int = 64) {
+  T o;
+  simt::wave_exchange(&v, sizeof(T), src & 63, &o);
+  return o;
+}
+template <typename T> inline T __shfl_xor(T v, int mask, int = 64) {
+  T o;
+  simt::wave_exchange(&v, sizeof(T), (simt::lane_id() ^ mask) & 63, &o);
+  return o;
+}
+inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
+inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
+
+typedef float simt_f32x4 __attribute__((vector_size(16)));
+typedef double simt_f64x4 __attribute__((vector_size(32)));
+// v_mfma_f32_16x16x4_f32: A[row=l&15][k=l>>4], B[k=l>>4][col=l&15], D col=l&15 row=(l>>4)*4+reg;
+// exact f32 fmaf chain in k order (MI355X guide).
+inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, simt_f32x4 c, int, int, int) {
+  simt::wave_gather_begin(&a, &b, sizeof(float));
+  const int l = simt::lane_id(), col = l & 15;
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = (l >> 4) * 4 + reg;
+    float acc = c[reg];
+    for (int k = 0; k < 4; ++k) {
+      float av, bv;
+      memcpy(&av, simt::wave_slot_a(k * 16 + row), 4);
+      memcpy(&bv, simt::wave_slot_b(k * 16 + col), 4);
+      acc = fmaf(av, bv, acc);
+    }
+    c[reg] = acc;
+  }
+  simt::wave_gather_end();
+  return c;
+}
+// v_mfma_f64_16x16x4_f64: same A/B maps; D col=l&15 row=(l>>4)+4*reg.
+inline simt_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, simt_f64x4 c, int, int, int) {
+  simt::wave_gather_begin(&a, &b, sizeof(double));
+  const int l = simt::lane_id(), col = l & 15;
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = (l >> 4) + 4 * reg;
+    double acc = c[reg];
+    for (int k = 0; k < 4; ++k) {
+      double av, bv;
+      memcpy(&av, simt::wave_slot_a(k * 16 + row), 8);
+      memcpy(&bv, simt::wave_slot_b(k * 16 + col), 8);
+      acc = fma(av, bv, acc);
+    }
+    c[reg] = acc;
+  }
+  simt::wave_gather_end();
+  return c;
+}
