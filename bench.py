@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- walker*local-energy evals/sec and ms per VMC step on MI355X.
+
+One "step" is the evaluation-mode VMC iteration of the reference (fit.py:60-113 with
+NoOptimizer): `n_sub` Metropolis sub-steps (value-only psi) + one local
+energy per walker + the cross-GPU energy mean/variance (one RCCL all-gather of a 56-byte
+record).  Workload = BASELINE.json configs[1]: LiH (4 e-), PauliNet ansatz, 4096 walkers per
+GPU (weak scaling), synthetic walkers and random-init weights, float32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the forward-Laplacian
+linear layer) against the exact-f32 MFMA peak; `cpu_baseline` is the PyTorch-CPU oracle timed
+on this box's host cores on a bounded sample (a reported baseline, not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deepqmc_amd import MolecularHamiltonian, Molecule  # noqa: E402
+from deepqmc_amd import parallel  # noqa: E402
+from deepqmc_amd.sampling import DecorrSampler  # noqa: E402
+from deepqmc_amd.wf import NeuralNetworkWaveFunction  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+def cpu_baseline(hamil, spec_name, params, n_sub, budget_s=20.0):
+    """The oracle ("port" of the reference's JAX-CPU path: same per-walker algorithm,
+    reverse-forward Hessian-trace Laplacian, float64 PyTorch on all host cores) timed on a
+    bounded sample of the same workload."""
+    from deepqmc_amd.sampling import synthetic_walkers
+    from deepqmc_amd.spec import ANSATZES
+    from oracle import geom, physics
+    from oracle import wf as owf
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = ANSATZES[spec_name]()
+    p = owf.to_torch(params)
+    mol = hamil.mol
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    R, Z = T(mol.coords), T(mol.charges)
+    r = T(synthetic_walkers(hamil, 64, seed=7))
+    # warm-up + per-walker costs
+    physics.batch_local_energy(p, spec, r[:1], R, Z, hamil.n_up, geom.F32_EPS)
+    t0 = time.perf_counter()
+    n_e = 0
+    while time.perf_counter() - t0 < budget_s * 0.6 and n_e < r.shape[0]:
+        physics.batch_local_energy(p, spec, r[n_e:n_e + 1], R, Z, hamil.n_up, geom.F32_EPS)
+        n_e += 1
+    t_eloc = (time.perf_counter() - t0) / n_e
+    t0 = time.perf_counter()
+    n_w = 0
+    while time.perf_counter() - t0 < budget_s * 0.4 and n_w < r.shape[0]:
+        physics.batch_wave_function(p, spec, r[n_w:n_w + 1], R, hamil.n_up, geom.F32_EPS)
+        n_w += 1
+    t_wf = (time.perf_counter() - t0) / n_w
+    per_walker_step = n_sub * t_wf + t_eloc
+    return {
+        'value': 1.0 / per_walker_step, 'unit': 'walker*E_loc evals/s (VMC step incl. %d sub-steps)' % n_sub,
+        'eloc_only_evals_per_s': 1.0 / t_eloc, 'cores': torch.get_num_threads(), 'kind': 'port',
+        'sample': f'{n_e} local energies + {n_w} psi evaluations, one walker at a time, PyTorch-CPU float64 '
+                  f'oracle (reference JAX-CPU path is not runnable in this image)',
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--walkers', type=int, default=4096, help='walkers per GPU')
+    ap.add_argument('--n-sub', type=int, default=30, help='Metropolis sub-steps per VMC step (reference preset 30)')
+    ap.add_argument('--molecule', default='LiH')
+    ap.add_argument('--ansatz', default='paulinet')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+
+    dtype = torch.float32 if args.dtype == 'f32' else torch.float64
+    hamil = MolecularHamiltonian(mol=Molecule.from_name(args.molecule))
+    wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
+    params = wf.init(0, perturb_envelopes=0.05)
+    eng = wf.engine(params)
+    B = args.walkers
+    sampler = DecorrSampler(hamil, wf, length=args.n_sub)
+    state = sampler.init(1000 + rank, params, B)
+    loc_ene = hamil.local_energy(wf)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    def vmc_step(step, state):
+        if args.n_sub > 0:
+            state, pc, _ = sampler.sample(step * world + rank, state, params)
+            r = state['r']
+        else:
+            r = state['r']
+        e, _ = loc_ene(None, params, r)
+        stats = parallel.energy_stats(eng, e)
+        return state, stats
+
+    for s in range(args.warmup):
+        state, stats = vmc_step(s, state)
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        state, stats = vmc_step(args.warmup + s, state)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = B * world / (elapsed / args.steps)
+
+    # ---- pure E_loc throughput (n_sub = 0), not the headline ----
+    r = state['r']
+    for _ in range(2):
+        loc_ene(None, params, r)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    n_rep = max(5, args.steps)
+    for _ in range(n_rep):
+        loc_ene(None, params, r)
+    torch.cuda.synchronize(device)
+    eloc_only = B * world / ((time.perf_counter() - t0) / n_rep)
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, same workload ----
+    eng.timing(True)
+    eng.timing_reset()
+    for s in range(3):
+        state, stats = vmc_step(10_000 + s, state)
+    torch.cuda.synchronize(device)
+    rep = eng.timing_report()
+    eng.timing(False)
+    lin = rep.get('linear', {'ms': 0.0, 'launches': 0, 'flops': 0.0})
+    total_ms = sum(v['ms'] for v in rep.values()) or 1.0
+    achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
+    roofline = {
+        'bound': 'mfma', 'kernel': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
+        'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+        'traffic': None,
+        'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
+        'share_of_kernel_time': lin['ms'] / total_ms,
+        'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items()},
+    }
+
+    if rank == 0:
+        out = {
+            'metric': 'walker*local-energy evals/sec (VMC step: n_sub Metropolis sub-steps + E_loc + energy reduction)',
+            'value': value, 'unit': 'walker*E_loc evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
+            'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, {B} walkers/GPU, '
+                                   f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats',
+                       'walkers_per_gpu': B, 'n_sub': args.n_sub, 'parallelism': f'walker-dp{world}'},
+            'eloc_only_evals_per_s': eloc_only,
+            'energy': stats,
+            'flops_per_eloc': (3 * hamil.n_elec + 2) * eng.program.flops_per_walker,
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(hamil, args.ansatz, params, args.n_sub)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

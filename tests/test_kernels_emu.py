@@ -62,3 +62,56 @@ def test_emu_f32_energy():
     sign, logpsi = eng.wf_eval(torch.as_tensor(r32))
     np.testing.assert_array_equal(sign.numpy(), ref['sign'])
     np.testing.assert_allclose(logpsi.numpy(), ref['log'], rtol=1e-5, atol=1e-5)
+
+
+def test_emu_metropolis_bit_exact_and_stats():
+    """MCMC kernels (propose / accept / tau / stats / energy record) through the emulator."""
+    from oracle import sampling as osamp
+    from oracle import wf as owf
+    B, n_sub = 6, 3
+    spec, mol, h, eng, r0, it = _setup(paulinet, 'LiH', torch.float64, B)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    rng = np.random.default_rng(0)
+    noise = rng.standard_normal((n_sub, B, h.n_elec, 3))
+    unif = rng.random((n_sub, B))
+    sign0, log0 = eng.wf_eval(torch.as_tensor(r0))
+    st = {'r': torch.as_tensor(r0).clone(), 'log': log0.clone(), 'sign': sign0.clone(),
+          'age': torch.zeros(B, dtype=torch.int32), 'tau': torch.full((1,), 0.3, dtype=torch.float64)}
+    stats, acc = eng.mcmc_steps(st, n_sub, max_age=1, target_acceptance=0.57, noise=noise, unif=unif, return_accept=True)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    ost = {'r': T(r0), 'sign': T(sign0.numpy()), 'log': T(log0.numpy()), 'age': torch.zeros(B, dtype=torch.int64), 'tau': 0.3}
+    ost, ostats, oacc = osamp.decorr_sample(owf.to_torch(tree), spec, ost, T(mol.coords), h.n_up, geom.F32_EPS,
+                                            T(noise), T(unif), max_age=1, target_acceptance=0.57)
+    np.testing.assert_array_equal(acc.numpy().astype(bool), oacc.numpy())
+    np.testing.assert_array_equal(st['age'].numpy(), ost['age'].numpy())
+    np.testing.assert_allclose(st['r'].numpy(), ost['r'].numpy(), rtol=0, atol=1e-13)
+    np.testing.assert_array_equal(st['sign'].numpy(), ost['sign'].numpy().astype(np.int32))
+    for k in ostats:
+        np.testing.assert_allclose(stats[k], ostats[k], rtol=1e-10, atol=1e-10, err_msg=k)
+    # device RNG path runs and produces sane numbers
+    stats2 = eng.mcmc_steps(st, 2, seed=7)
+    assert 0.0 <= stats2['sampling/acceptance'] <= 1.0
+    # energy record + merge
+    e, _ = eng.local_energy(st['r'])
+    rec = eng.energy_record(e)
+    x = e.numpy()
+    np.testing.assert_allclose(rec, [B, B, x.sum(), x.sum(), ((x - x.mean()) ** 2).sum(), x.min(), x.max()], rtol=1e-10)
+    m = eng.merge_energy_records(np.stack([eng.energy_record(e[:2].contiguous()), eng.energy_record(e[2:].contiguous())]))
+    ref = osamp.energy_stats(T(x))
+    for k in ref:
+        np.testing.assert_allclose(m[k], ref[k], rtol=1e-10, err_msg=k)
+
+
+def test_emu_rng_moments():
+    """Philox4x32-10 + Box-Muller: mean/variance of the device noise (emulated)."""
+    import ctypes
+    spec, mol, h, eng, r0, it = _setup(paulinet, 'LiH', torch.float32, 512)
+    r0 = r0.astype(np.float32)
+    sign0, log0 = eng.wf_eval(torch.as_tensor(r0))
+    st = {'r': torch.as_tensor(r0).clone(), 'log': log0.clone(), 'sign': sign0.clone(),
+          'age': torch.zeros(512, dtype=torch.int32), 'tau': torch.full((1,), 1.0, dtype=torch.float32)}
+    # target_acceptance None keeps tau = 1, so r' - r of accepted walkers is the raw noise
+    stats, acc = eng.mcmc_steps(st, 1, target_acceptance=None, seed=42, return_accept=True)
+    moved = (st['r'].numpy() - r0)[acc.numpy()[0].astype(bool)].reshape(-1)
+    assert moved.size > 300
+    assert abs(moved.mean()) < 0.15 and 0.5 < moved.std() < 1.3
