@@ -34,41 +34,53 @@ from deepqmc_amd.wf import NeuralNetworkWaveFunction  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def cpu_baseline(hamil, spec_name, params, n_sub, budget_s=20.0):
-    """The oracle ("port" of the reference's JAX-CPU path: same per-walker algorithm,
-    reverse-forward Hessian-trace Laplacian, float64 PyTorch on all host cores) timed on a
-    bounded sample of the same workload."""
+def _cpu_worker(args):
+    """One single-threaded oracle process: times psi and local-energy evaluations."""
+    molname, spec_name, seed, n_sub, budget_s, widx = args
+    import torch as _t
+    _t.set_num_threads(1)
+    from deepqmc_amd.params import init_params
     from deepqmc_amd.sampling import synthetic_walkers
     from deepqmc_amd.spec import ANSATZES
     from oracle import geom, physics
     from oracle import wf as owf
-    torch.set_num_threads(os.cpu_count() or 1)
+    hamil = MolecularHamiltonian(mol=Molecule.from_name(molname))
     spec = ANSATZES[spec_name]()
-    p = owf.to_torch(params)
-    mol = hamil.mol
-    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
-    R, Z = T(mol.coords), T(mol.charges)
-    r = T(synthetic_walkers(hamil, 64, seed=7))
-    # warm-up + per-walker costs
-    physics.batch_local_energy(p, spec, r[:1], R, Z, hamil.n_up, geom.F32_EPS)
-    t0 = time.perf_counter()
-    n_e = 0
-    while time.perf_counter() - t0 < budget_s * 0.6 and n_e < r.shape[0]:
-        physics.batch_local_energy(p, spec, r[n_e:n_e + 1], R, Z, hamil.n_up, geom.F32_EPS)
+    p = owf.to_torch(init_params(spec, hamil.n_up, hamil.n_down, hamil.n_nuc, seed=seed, perturb_envelopes=0.05))
+    T = lambda a: _t.as_tensor(np.asarray(a), dtype=_t.float64)
+    R, Z = T(hamil.mol.coords), T(hamil.mol.charges)
+    r = T(synthetic_walkers(hamil, 256, seed=100 + widx))
+    physics.batch_local_energy(p, spec, r[:1], R, Z, hamil.n_up, geom.F32_EPS)      # warm-up
+    t0, n_e = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.6 * budget_s:
+        physics.batch_local_energy(p, spec, r[n_e % 256:n_e % 256 + 1], R, Z, hamil.n_up, geom.F32_EPS)
         n_e += 1
-    t_eloc = (time.perf_counter() - t0) / n_e
-    t0 = time.perf_counter()
-    n_w = 0
-    while time.perf_counter() - t0 < budget_s * 0.4 and n_w < r.shape[0]:
-        physics.batch_wave_function(p, spec, r[n_w:n_w + 1], R, hamil.n_up, geom.F32_EPS)
+    t_e = time.perf_counter() - t0
+    t0, n_w = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 0.4 * budget_s:
+        physics.batch_wave_function(p, spec, r[n_w % 256:n_w % 256 + 1], R, hamil.n_up, geom.F32_EPS)
         n_w += 1
-    t_wf = (time.perf_counter() - t0) / n_w
-    per_walker_step = n_sub * t_wf + t_eloc
+    t_w = time.perf_counter() - t0
+    return n_e, t_e, n_w, t_w
+
+
+def cpu_baseline(molname, spec_name, n_sub, budget_s=20.0):
+    """The oracle ("port" of the reference's JAX-CPU path: same per-walker algorithm,
+    Hessian-trace Laplacian by forward-over-reverse autodiff, float64 PyTorch) timed on this
+    box's host cores: one single-threaded process per core (<= 64), a bounded sample each."""
+    import multiprocessing as mp
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    with mp.get_context('spawn').Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(molname, spec_name, 0, n_sub, budget_s, w) for w in range(cores)])
+    eloc_rate = sum(n_e / t_e for n_e, t_e, _, _ in res)      # aggregate over processes
+    wf_rate = sum(n_w / t_w for _, _, n_w, t_w in res)
+    per_walker_step = n_sub / wf_rate + 1.0 / eloc_rate
     return {
         'value': 1.0 / per_walker_step, 'unit': 'walker*E_loc evals/s (VMC step incl. %d sub-steps)' % n_sub,
-        'eloc_only_evals_per_s': 1.0 / t_eloc, 'cores': torch.get_num_threads(), 'kind': 'port',
-        'sample': f'{n_e} local energies + {n_w} psi evaluations, one walker at a time, PyTorch-CPU float64 '
-                  f'oracle (reference JAX-CPU path is not runnable in this image)',
+        'eloc_only_evals_per_s': eloc_rate, 'psi_evals_per_s': wf_rate, 'cores': cores, 'kind': 'port',
+        'sample': f'{sum(x[0] for x in res)} local energies + {sum(x[2] for x in res)} psi evaluations in '
+                  f'{budget_s:.0f} s over {cores} single-threaded processes, PyTorch-CPU float64 oracle '
+                  f'(the reference JAX-CPU path is not runnable in this image)',
     }
 
 
@@ -83,6 +95,9 @@ def main():
     ap.add_argument('--ansatz', default='paulinet')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
+    ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
+    ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -101,6 +116,11 @@ def main():
     wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
+    if args.fused_lds_kb:
+        eng.set_option('fused_lds_kb', args.fused_lds_kb)
+    if args.fused_wt:
+        eng.set_option('fused_wt', args.fused_wt)
+    eng.set_option('fused', args.fused)
     B = args.walkers
     sampler = DecorrSampler(hamil, wf, length=args.n_sub)
     state = sampler.init(1000 + rank, params, B)
@@ -157,11 +177,16 @@ def main():
     torch.cuda.synchronize(device)
     rep = eng.timing_report()
     eng.timing(False)
-    lin = rep.get('linear', {'ms': 0.0, 'launches': 0, 'flops': 0.0})
+    names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
+             'fused_psi': 'k_fused_value (LDS-resident psi evaluation of the Metropolis loop, v_mfma_f32_16x16x4_f32)'}
+    cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
+    dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
+    lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
     total_ms = sum(v['ms'] for v in rep.values()) or 1.0
     achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
     roofline = {
-        'bound': 'mfma', 'kernel': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
+        'bound': 'mfma', 'kernel': names[dom],
+        'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
         'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
         'traffic': None,
         'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
@@ -184,7 +209,7 @@ def main():
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(hamil, args.ansatz, params, args.n_sub)
+            out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -51,6 +51,7 @@ struct dqmc_ctx {
                    double* stats7) = 0;
   virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
+  virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
   // timing
   bool timing = false;
@@ -115,6 +116,15 @@ struct Engine : dqmc_ctx {
   int32_t* d_nacc = nullptr;
   double* d_acc = nullptr;     // [1] acceptance, then [7] stats, then [7] energy record
   std::vector<real> wtmp;
+  // fused value-only plan
+  bool fused_enabled = true;
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0;
+  size_t fused_lds = 0, fused_lds_budget = 64 * 1024, wpk_cap = 0;
+  std::vector<dqmc::FusedBuf> fbufs_h;
+  dqmc_op* d_ops = nullptr;
+  dqmc::FusedBuf* d_fbufs = nullptr;
+  long* d_wpk_off = nullptr;
+  real* d_wpk = nullptr;
 
   ~Engine() override {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -125,6 +135,10 @@ struct Engine : dqmc_ctx {
     if (d_mc) (void)hipFree(d_mc);
     if (d_nacc) (void)hipFree(d_nacc);
     if (d_acc) (void)hipFree(d_acc);
+    if (d_ops) (void)hipFree(d_ops);
+    if (d_fbufs) (void)hipFree(d_fbufs);
+    if (d_wpk_off) (void)hipFree(d_wpk_off);
+    if (d_wpk) (void)hipFree(d_wpk);
   }
 
   int init(const dqmc_system* s, const double* charges, const dqmc_buf* b, int nb, const dqmc_op* o, int no,
@@ -149,7 +163,9 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipStreamSynchronize(st));
     int rc = validate();
     if (rc) return rc;
-    return set_weights(w, nw);
+    rc = set_weights(w, nw);
+    if (rc) return rc;
+    return build_fused_plan();
   }
 
   int validate() {
@@ -207,6 +223,152 @@ struct Engine : dqmc_ctx {
     for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
     HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (fused_n_ops > 0) return pack_fused_weights();
+    return DQMC_OK;
+  }
+
+  // ---- fused value-only evaluation (kernel_fused.hip) -----------------------------------
+  // Ops [0, fused_n_ops) (everything up to and including ORBITALS) run in one kernel on a tile
+  // of WT walkers with LDS-resident buffers; buffers read by later ops stay in the workspace.
+  int option(const char* name, int value) override {
+    const std::string s(name);
+    if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
+    if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
+    if (s == "fused_lds_kb") { fused_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
+    return fail(DQMC_E_ARG, "unknown option " + s);
+  }
+
+  // LDS placement of the buffers for a tile of WT walkers: first-fit over live intervals.
+  size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb) const {
+    const int nb = (int)bufs.size(), no = fused_n_ops;
+    std::vector<int> first(nb, 1 << 30), last(nb, -1);
+    auto touch = [&](int b, int k, bool write) {
+      if (b < 0) return;
+      if (write && k < first[b]) first[b] = k;
+      if (k < first[b]) first[b] = k;
+      if (k > last[b]) last[b] = k;
+    };
+    for (int k = 0; k < (int)ops.size(); ++k) {
+      const int32_t* i = ops[k].i;
+      switch (ops[k].kind) {
+        case DQMC_OP_FEAT_EN: case DQMC_OP_FEAT_EE: touch(i[0], k, true); break;
+        case DQMC_OP_LINEAR:
+          for (int p = 0; p < i[0]; ++p) touch(i[1 + 4 * p], k, false);
+          touch(i[17], k, true); touch(i[25], k, false); break;
+        case DQMC_OP_SPIN_MEAN: case DQMC_OP_ROW_SUM: touch(i[0], k, false); touch(i[1], k, true); break;
+        case DQMC_OP_CONV: touch(i[0], k, false); touch(i[1], k, false); touch(i[2], k, true); break;
+        case DQMC_OP_EDGE_SUM: touch(i[0], k, false); touch(i[2], k, true); break;
+        case DQMC_OP_ORBITALS: touch(i[0], k, false); touch(i[1], k, true); break;
+        case DQMC_OP_SLOGDET: touch(i[0], k, false); break;
+        case DQMC_OP_FINAL: touch(i[0], k, false); break;
+        default: break;
+      }
+    }
+    fb.assign(nb, dqmc::FusedBuf{});
+    struct Seg { size_t off, len; int until; };
+    std::vector<Seg> live;
+    size_t peak = 0;
+    for (int k = 0; k < no; ++k) {
+      for (int b = 0; b < nb; ++b) {
+        if (first[b] != k) continue;
+        dqmc::FusedBuf& f = fb[b];
+        f.rows = bufs[b].rows; f.width = bufs[b].width;
+        if (last[b] >= no) { f.is_global = 1; continue; }   // consumed by a later kernel: HBM
+        f.is_global = 0;
+        f.stride = bufs[b].width + 2;
+        const size_t len = ((size_t)WT * f.rows * f.stride + 3) / 4 * 4;
+        size_t off = 0;
+        for (bool moved = true; moved;) {
+          moved = false;
+          for (const Seg& s : live)
+            if (off < s.off + s.len && s.off < off + len) { off = s.off + s.len; moved = true; }
+        }
+        f.off = (int)off;
+        live.push_back(Seg{off, len, last[b]});
+        if (off + len > peak) peak = off + len;
+      }
+      for (size_t q = 0; q < live.size();)
+        if (live[q].until <= k) live.erase(live.begin() + q); else ++q;
+    }
+    return peak * sizeof(real);
+  }
+
+  int build_fused_plan() {
+    fused_n_ops = 0;
+    int n_f = -1;
+    for (int k = 0; k < (int)ops.size(); ++k) {
+      if (ops[k].kind == DQMC_OP_ORBITALS) { n_f = k + 1; break; }
+      if (ops[k].kind == DQMC_OP_ATTENTION || ops[k].kind == DQMC_OP_SLOGDET || ops[k].kind == DQMC_OP_FINAL) return DQMC_OK;
+    }
+    if (n_f < 0) return DQMC_OK;
+    fused_n_ops = n_f;
+    fused_WT = 0;
+    const int cand[] = {32, 16, 8, 4, 2, 1};
+    for (int WT : cand) {
+      if (fused_wt_req > 0 && WT != fused_wt_req) continue;
+      std::vector<dqmc::FusedBuf> fb;
+      const size_t bytes = fused_layout(WT, fb);
+      if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused_lds_budget)) { fused_WT = WT; fused_lds = bytes; fbufs_h = fb; break; }
+    }
+    if (fused_WT == 0) { fused_n_ops = 0; return DQMC_OK; }   // does not fit: layered path only
+    if (!d_ops) {
+      HIP_TRY(hipMalloc((void**)&d_ops, sizeof(dqmc_op) * ops.size()));
+      HIP_TRY(hipMalloc((void**)&d_fbufs, sizeof(dqmc::FusedBuf) * bufs.size()));
+      HIP_TRY(hipMalloc((void**)&d_wpk_off, sizeof(long) * ops.size()));
+      HIP_TRY(hipMemcpy(d_ops, ops.data(), sizeof(dqmc_op) * ops.size(), hipMemcpyHostToDevice));
+    }
+    if (dqmc::fused_set_lds_limit<real>(fused_lds) != 0) { fused_n_ops = 0; return DQMC_OK; }
+    return pack_fused_weights();
+  }
+
+  // Fragment-major copy of the Linear weights: [k/4][column block][lane] so that one wave load
+  // of 64 consecutive elements is exactly the MFMA B operand (B[k = l>>4][col = l&15]).
+  int pack_fused_weights() {
+    std::vector<long> offs(ops.size(), 0);
+    std::vector<real> pk;
+    for (int k = 0; k < fused_n_ops; ++k) {
+      if (ops[k].kind != DQMC_OP_LINEAR) continue;
+      const int32_t* i = ops[k].i;
+      const int ldw = pad4(i[21]), NCB = (ldw + 15) / 16;
+      int krows = 0;
+      for (int p = 0; p < i[0]; ++p) krows += pad4(i[3 + 4 * p]);
+      offs[k] = (long)pk.size();
+      const real* W = wtmp.data() + i[22];
+      for (int ks = 0; ks < krows / 4; ++ks)
+        for (int cb = 0; cb < NCB; ++cb)
+          for (int l = 0; l < 64; ++l) {
+            const int row = ks * 4 + (l >> 4), col = cb * 16 + (l & 15);
+            pk.push_back(col < ldw ? W[(size_t)row * ldw + col] : (real)0);
+          }
+    }
+    if (pk.size() > wpk_cap) {
+      if (d_wpk) HIP_TRY(hipFree(d_wpk));
+      HIP_TRY(hipMalloc((void**)&d_wpk, sizeof(real) * pk.size()));
+      wpk_cap = pk.size();
+    }
+    HIP_TRY(hipMemcpyAsync(d_wpk, pk.data(), sizeof(real) * pk.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_wpk_off, offs.data(), sizeof(long) * offs.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQMC_OK;
+  }
+
+  int run_fused(const real* r, const real* R, int B, dqmc::LaneInfo li) {
+    for (size_t b = 0; b < bufs.size(); ++b) fbufs_h[b].goff = (long)buf_off[b];
+    HIP_TRY(hipMemcpyAsync(d_fbufs, fbufs_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
+    dqmc::FusedArgs<real> a{};
+    a.ops = d_ops; a.n_ops = fused_n_ops; a.fbufs = d_fbufs; a.wpk_off = d_wpk_off;
+    a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
+    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps;
+    double flops = 0;
+    for (int k = 0; k < fused_n_ops; ++k)
+      if (ops[k].kind == DQMC_OP_LINEAR) {
+        int ktot = 0;
+        for (int p = 0; p < ops[k].i[0]; ++p) ktot += ops[k].i[3 + 4 * p];
+        flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
+      }
+    t_begin("fused_psi", flops);
+    dqmc::launch_fused_value<real>(st, a, (B + fused_WT - 1) / fused_WT, fused_lds);
+    t_end();
     return DQMC_OK;
   }
 
@@ -244,7 +406,14 @@ struct Engine : dqmc_ctx {
     if (!lanes_supported(li.TP)) return fail(DQMC_E_UNSUPPORTED, "no kernel instance for " + std::to_string(li.TP) + " lanes");
     int rc = plan(B, li.TP);
     if (rc) return rc;
-    for (const dqmc_op& op : ops) {
+    size_t first_op = 0;
+    if (!laplacian && fused_enabled && fused_n_ops > 0) {
+      rc = run_fused(r, R, B, li);
+      if (rc) return rc;
+      first_op = (size_t)fused_n_ops;
+    }
+    for (size_t opi = first_op; opi < ops.size(); ++opi) {
+      const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
       switch (op.kind) {
         case DQMC_OP_FEAT_EN:
@@ -299,7 +468,7 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_EDGE_SUM:
           t_begin("graph", 0);
           dqmc::launch_edge_sum<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[2]), bufs[i[2]].width, i[3],
-                                      d_it + i[4], i[5], i[6], (double)op.f[0], B, li);
+                                      d_it + i[4], i[5], i[6], 1.0 / (double)(i[1] > 0 ? i[1] : 1), B, li);
           t_end();
           break;
         case DQMC_OP_ROW_SUM:
@@ -523,6 +692,10 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
   return ctx->debug_read(buf, out, n);
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
+int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
+  return ctx->option(name, value);
+}
 
 int dqmc_timing_enable(dqmc_ctx* ctx, int enable) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");

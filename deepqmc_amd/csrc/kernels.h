@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/dqmc.h"
 #include "common.h"
 
 namespace dqmc {
@@ -51,6 +52,33 @@ template <typename real> struct LinArgs {
   int T, TP;
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
+
+// ---- kernel_fused.hip ----
+struct FusedBuf {
+  int off;        // LDS offset in elements (LDS-resident buffers)
+  int stride;     // LDS row stride in elements (width + 2)
+  int rows;       // rows per walker
+  int width;
+  int is_global;  // 1: lives in the HBM workspace (read by later kernels)
+  long goff;      // byte offset of the buffer in the workspace
+};
+template <typename real> struct FusedArgs {
+  const ::dqmc_op* ops;   // device copy of the program, executed up to and including ORBITALS
+  int n_ops;
+  const FusedBuf* fbufs;  // device
+  const long* wpk_off;    // device: per op, offset of its fragment-major packed weights
+  const real* w;          // plain weights (biases, envelope parameters)
+  const real* wpk;        // packed weights: [k/4][col block][64 lanes]
+  const int32_t* itable;
+  char* ws;               // HBM workspace base
+  const real* r;          // [B][N][3]
+  const real* R;          // [n_nuc][3]
+  int B, WT, n_up, n_nuc, K;
+  LaneInfo li;
+  double eps;
+};
+template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes);
+template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 
 // ---- kernels_head.hip ----
 template <typename real>

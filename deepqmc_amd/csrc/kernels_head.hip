@@ -168,6 +168,95 @@ __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, in
   for (int t = li.T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
 }
 
+// Small-matrix variant (N <= 4: H2, LiH, Be ...): one thread per (walker, determinant), the
+// matrix, its inverse and one derivative lane at a time in registers; row swaps are predicated
+// so every index is a compile-time constant.  Same pivoting rule and sign convention as above.
+template <typename real, int N>
+__global__ void __launch_bounds__(256) k_slogdet_small(const real* __restrict__ orb, int orb_width,
+                                                       double* __restrict__ logdet, int32_t* __restrict__ sign_k,
+                                                       long n_mat, LaneInfo li) {
+  const long bk = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (bk >= n_mat) return;
+  const real* base = orb + bk * li.TP * orb_width;
+  double A[N][N], Inv[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) { A[i][j] = (double)base[i * N + j]; Inv[i][j] = (i == j) ? 1.0 : 0.0; }
+  double logabs = 0.0;
+  int sgn = 1;
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    int best = p;
+    double bv = fabs(A[p][p]);
+#pragma unroll
+    for (int i = p + 1; i < N; ++i) {
+      const double v = fabs(A[i][p]);
+      if (v > bv) { bv = v; best = i; }
+    }
+#pragma unroll
+    for (int i = p + 1; i < N; ++i) {
+      const bool sw = (best == i);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double a0 = A[p][j], a1 = A[i][j], b0 = Inv[p][j], b1 = Inv[i][j];
+        A[p][j] = sw ? a1 : a0; A[i][j] = sw ? a0 : a1;
+        Inv[p][j] = sw ? b1 : b0; Inv[i][j] = sw ? b0 : b1;
+      }
+    }
+    if (best != p) sgn = -sgn;
+    const double piv = A[p][p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) sgn = 0;
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { A[p][j] *= ip; Inv[p][j] *= ip; }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i == p) continue;
+      const double f = A[i][p];
+#pragma unroll
+      for (int j = 0; j < N; ++j) { A[i][j] -= f * A[p][j]; Inv[i][j] -= f * Inv[p][j]; }
+    }
+  }
+  logdet[bk * li.TP] = logabs;
+  sign_k[bk] = sgn;
+  if (li.T == 1) return;
+  double tr2_sum = 0.0;
+  for (int t = 1; t < li.T; ++t) {
+    const real* At = base + (long)t * orb_width;
+    double D[N][N], M[N][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) D[i][j] = (double)At[i * N + j];
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int l = 0; l < N; ++l) {
+        double m = 0.0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) m += Inv[i][j] * D[j][l];
+        M[i][l] = m;
+        if (i == l) tr += m;
+      }
+    if (t < li.T - 1) {
+      double t2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int l = 0; l < N; ++l) t2 += M[i][l] * M[l][i];
+      tr2_sum += t2;
+      logdet[bk * li.TP + t] = tr;
+    } else {
+      logdet[bk * li.TP + t] = tr - tr2_sum;
+    }
+  }
+  for (int t = li.T; t < li.TP; ++t) logdet[bk * li.TP + t] = 0.0;
+}
+
 // CI sum, cusps, Jastrow, and (Laplacian mode) the local energy.  One thread per walker;
 // double arithmetic (the cancellation Delta + |grad|^2 is the sensitive spot).
 template <typename real>
@@ -301,7 +390,18 @@ template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li) {
   const unsigned grid = (unsigned)((long)B * K);
-  if (li.N <= 8)
+  const long n_mat = (long)B * K;
+  const unsigned gsm = (unsigned)((n_mat + 255) / 256);
+  if (li.N == 2)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 2>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
+                       sign_k, n_mat, li);
+  else if (li.N == 3)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 3>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
+                       sign_k, n_mat, li);
+  else if (li.N == 4)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 4>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
+                       sign_k, n_mat, li);
+  else if (li.N <= 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
                        sign_k, K, li);
   else if (li.N <= 16)

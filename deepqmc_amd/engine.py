@@ -182,6 +182,9 @@ class Engine:
         self._check(self.lib.dqmc_debug_read(self._ctx, idx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
         return out
 
+    def set_option(self, name: str, value: int):
+        self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
+
     def timing(self, enable=True):
         self._check(self.lib.dqmc_timing_enable(self._ctx, int(enable)))
 

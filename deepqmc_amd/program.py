@@ -297,7 +297,7 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
                 t = uf[5:]
                 tab, S = conv_tab[t]
                 n_send = n_up if t == 'up' else n_down
-                b.ops.append(Op(OP_EDGE_SUM, [e, -1, cbuf, c_col, tab, S, e_dim], [1.0 / max(n_send, 1), 0, 0, 0],
+                b.ops.append(Op(OP_EDGE_SUM, [e, max(n_send, 1), cbuf, c_col, tab, S, e_dim], [0, 0, 0, 0],
                                 note=f'layer {l} edge_{t} mean'))
                 c_col += e_dim
             else:

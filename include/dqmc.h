@@ -78,8 +78,8 @@ enum dqmc_op_kind {
    * int [N][S][2] (edge row, sender; -1 = none) [5]=S [6]=width.
    * out[i] = sum_s we[row(i,s)] * hx[send(i,s)] (gnn/graph.py:226-335). */
   DQMC_OP_CONV = 5,
-  /* i: as CONV without node buf ([1] unused).  f: [0]=scale.  out[i] = scale *
-   * sum_s e[row(i,s)] (EdgeSum, gnn/update_features.py:109-159). */
+  /* i: as CONV with [1]=divisor instead of a node buf.  out[i] = sum_s e[row(i,s)] / divisor
+   * (EdgeSum with normalize, gnn/update_features.py:109-159). */
   DQMC_OP_EDGE_SUM = 6,
   /* i: [0]=src buf [1]=dst buf (rows = 1).  Sum over all rows (Jastrow sum_first,
    * wf/omni.py:35-40). */
@@ -172,6 +172,11 @@ int dqmc_merge_energy_stats(const double* records_host, int n_ranks, double* out
 int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out_host, size_t n);
 /* Lanes (TP) used by the last evaluation. */
 int dqmc_debug_lanes(dqmc_ctx* ctx);
+/* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
+ * MCMC) with the single LDS-resident kernel instead of one launch per op (0 keeps every
+ * activation buffer readable by dqmc_debug_read); "fused_wt": walkers per workgroup tile
+ * (0 = automatic); "fused_lds_kb": LDS budget per workgroup for the automatic choice. */
+int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 
 /* Per-kernel timing (HIP events on the context's stream).  enable != 0 starts recording
  * every launch; dqmc_timing_get returns total ms / launch count / algorithmic flops of the

@@ -194,7 +194,7 @@ class Interp:
             out[:, i, :, c0:c0 + W] = self._ll(acc)
 
     def op_6(self, op):  # EDGE_SUM
-        eb, _, dst, c0, tab, S, W = op.i[:7]
+        eb, div, dst, c0, tab, S, W = op.i[:7]
         out = self.bufs[dst]
         for i in range(self.N):
             acc = np.zeros((self.B, self.TP, W))
@@ -202,7 +202,7 @@ class Interp:
                 row = self.it[tab + 2 * (i * S + s)]
                 if row >= 0:
                     acc += self.bufs[eb][:, row, :, :W]
-            out[:, i, :, c0:c0 + W] = acc * op.f[0]
+            out[:, i, :, c0:c0 + W] = acc / div
 
     def op_7(self, op):  # ROW_SUM
         src, dst = op.i[:2]

@@ -54,6 +54,11 @@ inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
 }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+namespace simt { char* dyn_smem(size_t ensure_bytes); }
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)simt::dyn_smem(0);
+
 namespace simt {
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
 void sync_block();
@@ -67,7 +72,8 @@ int lane_id();
 }  // namespace simt
 
 template <typename K, typename... Args>
-inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t, hipStream_t, Args... args) {
+inline void hipLaunchKernelGGL(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t, Args... args) {
+  simt::dyn_smem(dyn_lds);
   simt::run_grid(grid, block, [=]() { kernel(args...); });
 }
 

@@ -57,6 +57,14 @@ void wave_sync() {
 
 int lane_id() { return fibers[cur].linear & 63; }
 
+char* dyn_smem(size_t ensure_bytes) {
+  static std::vector<char> buf;
+  if (ensure_bytes > buf.size()) buf.resize(ensure_bytes);
+  // poison on (re)size requests so that uninitialised LDS reads show up as NaN
+  if (ensure_bytes) memset(buf.data(), 0xFF, buf.size());
+  return buf.data();
+}
+
 void sync_block() {
   const unsigned g = bar_gen;
   if (++bar_arrived == live) { bar_arrived = 0; ++bar_gen; return; }

@@ -1,0 +1,40 @@
+"""The fused LDS-resident psi kernel (kernel_fused.hip) against the one-launch-per-op path and
+the oracle, through the SIMT emulator: same program, same weights, ragged last tile."""
+import numpy as np
+import pytest
+import torch
+
+from deepqmc_amd.engine import Engine
+from deepqmc_amd.hamil import MolecularHamiltonian
+from deepqmc_amd.molecule import Molecule
+from deepqmc_amd.params import init_params
+from deepqmc_amd.spec import ferminet, paulinet
+from oracle import geom
+from oracle.program_interp import Interp
+from simt_util import emu_lib
+from test_program_interp import make_walkers
+
+
+@pytest.mark.parametrize('spec_fn,dtype,wt', [(paulinet, torch.float64, 0), (paulinet, torch.float32, 4), (ferminet, torch.float64, 2)])
+def test_fused_matches_layered_and_oracle(spec_fn, dtype, wt):
+    spec = spec_fn()
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=dtype, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 11                                     # not a multiple of any tile size
+    r = make_walkers(mol, h.n_elec, B).astype(np.float32 if dtype == torch.float32 else np.float64)
+    rt = torch.as_tensor(r)
+    if wt:
+        eng.set_option('fused_wt', wt)
+    eng.set_option('fused', 1)
+    s1, l1 = eng.wf_eval(rt)
+    eng.set_option('fused', 0)
+    s0, l0 = eng.wf_eval(rt)
+    np.testing.assert_array_equal(s1.numpy(), s0.numpy())
+    tol = 1e-12 if dtype == torch.float64 else 2e-5
+    np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=tol, atol=tol)
+    ref = Interp(eng.program, mol.charges, geom.F32_EPS).run(r.astype(np.float64), mol.coords.astype(r.dtype).astype(np.float64), laplacian=False)
+    np.testing.assert_array_equal(s1.numpy(), ref['sign'])
+    tol = 1e-11 if dtype == torch.float64 else 2e-5
+    np.testing.assert_allclose(l1.numpy(), ref['log'], rtol=tol, atol=tol)
