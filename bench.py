@@ -97,6 +97,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
+    ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
     ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
     args = ap.parse_args()
 
@@ -121,6 +122,8 @@ def main():
     if args.fused_wt:
         eng.set_option('fused_wt', args.fused_wt)
     eng.set_option('fused', args.fused)
+    if args.fused_dbg:
+        eng.set_option('fused_dbg', args.fused_dbg)
     B = args.walkers
     sampler = DecorrSampler(hamil, wf, length=args.n_sub)
     state = sampler.init(1000 + rank, params, B)

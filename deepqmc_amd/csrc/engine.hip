@@ -118,8 +118,8 @@ struct Engine : dqmc_ctx {
   std::vector<real> wtmp;
   // fused value-only plan
   bool fused_enabled = true;
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0;
-  size_t fused_lds = 0, fused_lds_budget = 64 * 1024, wpk_cap = 0;
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0;
+  size_t fused_lds = 0, fused_lds_budget = 48 * 1024, wpk_cap = 0;
   std::vector<dqmc::FusedBuf> fbufs_h;
   dqmc_op* d_ops = nullptr;
   dqmc::FusedBuf* d_fbufs = nullptr;
@@ -234,6 +234,7 @@ struct Engine : dqmc_ctx {
     const std::string s(name);
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
+    if (s == "fused_dbg") { fused_dbg = value; return DQMC_OK; }
     if (s == "fused_lds_kb") { fused_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
     return fail(DQMC_E_ARG, "unknown option " + s);
   }
@@ -358,7 +359,7 @@ struct Engine : dqmc_ctx {
     dqmc::FusedArgs<real> a{};
     a.ops = d_ops; a.n_ops = fused_n_ops; a.fbufs = d_fbufs; a.wpk_off = d_wpk_off;
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
-    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps;
+    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps; a.dbg = fused_dbg;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)
       if (ops[k].kind == DQMC_OP_LINEAR) {

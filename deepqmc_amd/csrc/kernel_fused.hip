@@ -10,34 +10,29 @@
 // floats, i.e. 2 mod 4 => the 16 rows x 2 k of a half-wave hit 32 distinct banks), B fragments
 // from a fragment-major packed copy of the weights in L2 (one coalesced 256-byte load per
 // 16x4 tile), v_mfma_f32_16x16x4_f32 accumulation, bias/activation/residual fused in the store.
+//
+// Address spaces are kept explicit for the compiler: LDS is only ever indexed through the
+// dynamic-LDS symbol with 32-bit element offsets (ds_read/ds_write, never flat_*), HBM/L2 only
+// through the kernel-argument pointers.
 #include "common.h"
 #include "kernels.h"
-#include "../../include/dqmc.h"
 
 namespace dqmc {
 
-template <typename real> struct BufView {
-  real* lds;     // nullptr for a global buffer
-  real* glb;     // global base (walker 0 of the tile), layout [walker][rows][width]
-  int stride;    // row stride in elements
-  int rows;      // rows per walker
+struct BufRef {
+  int lds;      // element offset in LDS, or -1: the buffer lives in the HBM workspace
+  long goff;    // byte offset in the workspace (HBM buffers)
+  int stride;   // row stride in elements
+  int rows;     // rows per walker
   int width;
 };
 
-template <typename real>
-__device__ __forceinline__ BufView<real> view(const FusedArgs<real>& a, real* smem, int b, int w0) {
+template <typename real> __device__ __forceinline__ BufRef bufref(const FusedArgs<real>& a, int b) {
   const FusedBuf fb = a.fbufs[b];
-  BufView<real> v;
-  v.rows = fb.rows; v.width = fb.width;
-  if (fb.is_global) {
-    v.lds = nullptr;
-    v.glb = reinterpret_cast<real*>(a.ws + fb.goff) + (long)w0 * fb.rows * fb.width;
-    v.stride = fb.width;
-  } else {
-    v.lds = smem + fb.off;
-    v.glb = nullptr;
-    v.stride = fb.stride;
-  }
+  BufRef v;
+  v.rows = fb.rows; v.width = fb.width; v.goff = fb.goff;
+  v.lds = fb.is_global ? -1 : fb.off;
+  v.stride = fb.is_global ? fb.width : fb.stride;
   return v;
 }
 
@@ -47,89 +42,141 @@ template <typename real> __device__ __forceinline__ real act_value(int act, real
   return v;
 }
 
-// y = act(concat(pieces) W + b) (+ residual) on the tile, MFMA 16x16x4.
-template <typename real>
-__device__ void fused_linear(const FusedArgs<real>& a, real* smem, const dqmc_op& op, long wpk_off, int nw, int w0) {
+// One unit of a fused linear layer: MA row blocks x 2 column blocks of
+// y = act(concat(pieces) W + b) (+ residual) on the tile.  The k loop is branch-free
+// (out-of-range rows / column blocks read a valid dummy location and are dropped at the store)
+// and the B fragments of the next 4 k-steps are in flight while the current 4 are multiplied.
+template <typename real, int MA>
+__device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, const dqmc_op& op, const real* wpk, int nw,
+                                                  int w0, int rb0, int cg) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
   typedef typename Mfma<real>::acc_t acc_t;
-  constexpr int MRW = 4, NRW = 2;
+  constexpr int NRW = 2, KC = 4;
   const int32_t* i = op.i;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-  const int nrows = i[20], nout = i[21];
-  const int ldw = (nout + 3) / 4 * 4;
-  const int Rtot = nw * nrows;
-  const int NRB = (Rtot + 15) / 16, NCB = (ldw + 15) / 16;
-  const int n_rg = (NRB + MRW - 1) / MRW, n_cg = (NCB + NRW - 1) / NRW;
-  const BufView<real> dst = view<real>(a, smem, i[17], w0);
-  const real* bias = i[23] >= 0 ? a.w + i[23] : nullptr;
-  const bool has_res = i[25] >= 0;
-  BufView<real> res = dst;
-  if (has_res) res = view<real>(a, smem, i[25], w0);
-  const real res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
-  const real* wpk = a.wpk + wpk_off;
-
-  for (int u = wave; u < n_rg * n_cg; u += n_waves) {
-    const int rg = u / n_cg, cg = u - rg * n_cg;
-    acc_t acc[MRW][NRW];
+  const int lane = threadIdx.x & 63;
+  const int nrows = i[20];
+  const int ldw = (i[21] + 3) / 4 * 4;
+  const int Rtot = nw * nrows, NCB = (ldw + 15) / 16;
+  int cbi[NRW];
 #pragma unroll
-    for (int x = 0; x < MRW; ++x)
+  for (int y = 0; y < NRW; ++y) cbi[y] = (cg * NRW + y < NCB) ? cg * NRW + y : NCB - 1;
+  // A rows of this lane: (walker, row) of the MA row blocks
+  int a_wl[MA], a_rr[MA];
 #pragma unroll
-      for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
-    int ks0 = 0;
-    for (int p = 0; p < i[0]; ++p) {
-      const BufView<real> src = view<real>(a, smem, i[1 + 4 * p], w0);
-      const int r0 = i[2 + 4 * p], Kp = (i[3 + 4 * p] + 3) / 4 * 4, bc = i[4 + 4 * p];
-      const real* ap[MRW];
+  for (int x = 0; x < MA; ++x) {
+    int m = (rb0 + x) * 16 + (lane & 15);
+    if (m >= Rtot) m = 0;                                 // dummy row, result discarded
+    a_wl[x] = m / nrows;
+    a_rr[x] = m - a_wl[x] * nrows;
+  }
+  acc_t acc[MA][NRW];
 #pragma unroll
-      for (int x = 0; x < MRW; ++x) {
-        const int m = (rg * MRW + x) * 16 + (lane & 15);
-        if (m < Rtot) {
-          const int wl = m / nrows, rr = m - wl * nrows;
-          ap[x] = src.lds + (long)(wl * src.rows + r0 + (bc ? 0 : rr)) * src.stride + (lane >> 4);
-        } else {
-          ap[x] = nullptr;
-        }
-      }
-      const int KS = Kp / 4;
-#pragma unroll 4
-      for (int ks = 0; ks < KS; ++ks) {
-        real fb[NRW], fa[MRW];
+  for (int x = 0; x < MA; ++x)
 #pragma unroll
-        for (int y = 0; y < NRW; ++y) {
-          const int cb = cg * NRW + y;
-          fb[y] = cb < NCB ? wpk[((long)(ks0 + ks) * NCB + cb) * 64 + lane] : (real)0;
-        }
+    for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
+  int ks0 = 0;
+  for (int p = 0; p < i[0]; ++p) {
+    const BufRef src = bufref<real>(a, i[1 + 4 * p]);
+    const int r0 = i[2 + 4 * p], Kp = (i[3 + 4 * p] + 3) / 4 * 4, bc = i[4 + 4 * p];
+    int ao[MA];
 #pragma unroll
-        for (int x = 0; x < MRW; ++x) fa[x] = ap[x] != nullptr ? ap[x][ks * 4] : (real)0;
+    for (int x = 0; x < MA; ++x)
+      ao[x] = src.lds + (a_wl[x] * src.rows + r0 + (bc ? 0 : a_rr[x])) * src.stride + (lane >> 4);
+    const int KS = Kp / 4;
+    const int kstride = NCB * 64;
+    const real* wp0 = wpk + (ks0 * NCB + cbi[0]) * 64 + lane;
+    const real* wp1 = wpk + (ks0 * NCB + cbi[1]) * 64 + lane;
+    real fbn[KC][NRW];
 #pragma unroll
-        for (int x = 0; x < MRW; ++x)
-#pragma unroll
-          for (int y = 0; y < NRW; ++y) acc[x][y] = Mfma<real>::run(fa[x], fb[y], acc[x][y]);
-      }
-      ks0 += KS;
+    for (int kk = 0; kk < KC; ++kk) {
+      const int ks = kk < KS ? kk : KS - 1;
+      fbn[kk][0] = wp0[ks * kstride];
+      fbn[kk][1] = wp1[ks * kstride];
     }
-    // epilogue: bias + activation + residual, store to LDS or HBM
+    for (int kc = 0; kc < KS; kc += KC) {
+      real fb[KC][NRW];
 #pragma unroll
-    for (int x = 0; x < MRW; ++x)
+      for (int kk = 0; kk < KC; ++kk) { fb[kk][0] = fbn[kk][0]; fb[kk][1] = fbn[kk][1]; }
+      if (kc + KC < KS) {
+#pragma unroll
+        for (int kk = 0; kk < KC; ++kk) {
+          const int ks = (kc + KC + kk < KS) ? kc + KC + kk : KS - 1;
+          fbn[kk][0] = wp0[ks * kstride];
+          fbn[kk][1] = wp1[ks * kstride];
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < KC; ++kk) {
+        if (kc + kk < KS) {
+          real fa[MA];
+#pragma unroll
+          for (int x = 0; x < MA; ++x) fa[x] = smem[ao[x] + (kc + kk) * 4];
+#pragma unroll
+          for (int x = 0; x < MA; ++x) {
+            acc[x][0] = Mfma<real>::run(fa[x], fb[kk][0], acc[x][0]);
+            acc[x][1] = Mfma<real>::run(fa[x], fb[kk][1], acc[x][1]);
+          }
+        }
+      }
+    }
+    ks0 += KS;
+  }
+  // epilogue: bias + activation + residual, store to LDS or HBM
+  const BufRef dst = bufref<real>(a, i[17]);
+  const bool has_res = i[25] >= 0;
+  BufRef res = dst;
+  if (has_res) res = bufref<real>(a, i[25]);
+  const real res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
+  const int act = i[24], col0 = i[19];
+  real* dst_g = reinterpret_cast<real*>(a.ws + dst.goff) + (long)w0 * dst.rows * dst.width;
+#pragma unroll
+  for (int y = 0; y < NRW; ++y) {
+    const int col = (cg * NRW + y) * 16 + (lane & 15);
+    if (col >= ldw) continue;
+    const real bv = i[23] >= 0 ? a.w[i[23] + col] : (real)0;
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
 #pragma unroll
       for (int rgi = 0; rgi < 4; ++rgi) {
-        const int m = (rg * MRW + x) * 16 + Mfma<real>::row_of(lane, rgi);
+        const int m = (rb0 + x) * 16 + Mfma<real>::row_of(lane, rgi);
         if (m >= Rtot) continue;
         const int wl = m / nrows, rr = m - wl * nrows;
-#pragma unroll
-        for (int y = 0; y < NRW; ++y) {
-          const int col = (cg * NRW + y) * 16 + (lane & 15);
-          if (col >= ldw) continue;
-          real v = acc[x][y][rgi];
-          if (bias != nullptr) v += bias[col];
-          v = act_value<real>(i[24], v);
-          if (has_res) {
-            const long ro = (long)(wl * res.rows + i[26] + rr) * res.stride + i[19] + col;
-            v = ((res.lds ? res.lds[ro] : res.glb[ro]) + v) * res_scale;
-          }
-          const long o = (long)(wl * dst.rows + i[18] + rr) * dst.stride + i[19] + col;
-          if (dst.lds) dst.lds[o] = v; else dst.glb[o] = v;
+        real v = act_value<real>(act, acc[x][y][rgi] + bv);
+        if (has_res) {
+          const int ro = (wl * res.rows + i[26] + rr) * res.stride + col0 + col;
+          v = (smem[res.lds + ro] + v) * res_scale;      // residual inputs are LDS-resident (engine plan)
         }
+        const int o = (wl * dst.rows + i[18] + rr) * dst.stride + col0 + col;
+        if (dst.lds >= 0) smem[dst.lds + o] = v;
+        else dst_g[o] = v;
       }
+  }
+}
+
+// Work decomposition of one linear layer over the waves of the workgroup: units of
+// (rows_per_unit row blocks) x (2 column blocks), rows_per_unit chosen so that there are at
+// least as many units as waves whenever the layer is big enough.
+template <typename real>
+__device__ __forceinline__ void fused_linear(const FusedArgs<real>& a, const dqmc_op& op, int wpk_off, int nw, int w0) {
+  const int32_t* i = op.i;
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const int ldw = (i[21] + 3) / 4 * 4;
+  const int Rtot = nw * i[20];
+  const int NRB = (Rtot + 15) / 16, NCB = (ldw + 15) / 16;
+  const int n_cg = (NCB + 1) / 2;
+  int rpu = NRB * n_cg / n_waves;
+  rpu = rpu < 1 ? 1 : (rpu > 4 ? 4 : rpu);
+  const int n_rg = (NRB + rpu - 1) / rpu;
+  const real* wpk = a.wpk + wpk_off;
+  for (int u = wave; u < n_rg * n_cg; u += n_waves) {
+    const int rg = u / n_cg, cg = u - rg * n_cg;
+    const int rb0 = rg * rpu;
+    const int ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
+    if (ma == 1) fused_linear_unit<real, 1>(a, op, wpk, nw, w0, rb0, cg);
+    else if (ma == 2) fused_linear_unit<real, 2>(a, op, wpk, nw, w0, rb0, cg);
+    else if (ma == 3) fused_linear_unit<real, 3>(a, op, wpk, nw, w0, rb0, cg);
+    else fused_linear_unit<real, 4>(a, op, wpk, nw, w0, rb0, cg);
   }
 }
 
@@ -149,24 +196,24 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
     const int32_t* i = op.i;
     switch (op.kind) {
       case DQMC_OP_FEAT_EN: {
-        const BufView<real> x = view<real>(a, smem, i[0], w0);
+        const BufRef x = bufref<real>(a, i[0]);
         for (int e = tid; e < nw * N * n_nuc; e += nthr) {
           const int n = e % n_nuc, q = e / n_nuc, el = q % N, wl = q / N;
           double d[3], f[4];
           for (int c = 0; c < 3; ++c) d[c] = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c];
           pair_feature_lane(d, a.eps, el, -1, 0, li, i[1] != 0, f);
-          real* row = x.lds + (long)(wl * N + el) * x.stride;
-          for (int c = 0; c < 4; ++c) row[4 * n + c] = (real)f[c];
+          const int row = x.lds + (wl * N + el) * x.stride;
+          for (int c = 0; c < 4; ++c) smem[row + 4 * n + c] = (real)f[c];
           if (n == 0) {
             int c = 4 * n_nuc;
-            if (i[2]) row[c++] = (real)(el < n_up ? 1.0 : -1.0);
-            for (; c < x.width; ++c) row[c] = (real)0;
+            if (i[2]) smem[row + c++] = (real)(el < n_up ? 1.0 : -1.0);
+            for (; c < x.width; ++c) smem[row + c] = (real)0;
           }
         }
         break;
       }
       case DQMC_OP_FEAT_EE: {
-        const BufView<real> eb = view<real>(a, smem, i[0], w0);
+        const BufRef eb = bufref<real>(a, i[0]);
         const int32_t* pairs = a.itable + i[1];
         const int n_rows = i[2];
         for (int e = tid; e < nw * n_rows; e += nthr) {
@@ -175,31 +222,31 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
           double d[3], f[4];
           for (int c = 0; c < 3; ++c) d[c] = (double)r[(wl * N + rc) * 3 + c] - (double)r[(wl * N + sd) * 3 + c];
           pair_feature_lane(d, a.eps, rc, sd, 0, li, i[3] != 0, f);
-          real* row = eb.lds + (long)(wl * n_rows + kr) * eb.stride;
-          for (int c = 0; c < 4; ++c) row[c] = (real)f[c];
+          const int row = eb.lds + (wl * n_rows + kr) * eb.stride;
+          for (int c = 0; c < 4; ++c) smem[row + c] = (real)f[c];
         }
         break;
       }
       case DQMC_OP_LINEAR:
-        fused_linear<real>(a, smem, op, a.wpk_off[k], nw, w0);
+        fused_linear<real>(a, op, (int)a.wpk_off[k], nw, w0);
         break;
       case DQMC_OP_SPIN_MEAN: {
-        const BufView<real> x = view<real>(a, smem, i[0], w0), m = view<real>(a, smem, i[1], w0);
+        const BufRef x = bufref<real>(a, i[0]), m = bufref<real>(a, i[1]);
         for (int e = tid; e < nw * 2 * x.width; e += nthr) {
           const int c = e % x.width, q = e / x.width, which = q & 1, wl = q >> 1;
           const int i0 = which ? n_up : 0, i1 = which ? N : n_up;
           real acc = 0;
-          for (int el = i0; el < i1; ++el) acc += x.lds[(long)(wl * N + el) * x.stride + c];
-          m.lds[(long)(wl * 2 + which) * m.stride + c] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
+          for (int el = i0; el < i1; ++el) acc += smem[x.lds + (wl * N + el) * x.stride + c];
+          smem[m.lds + (wl * 2 + which) * m.stride + c] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
         }
         break;
       }
       case DQMC_OP_CONV:
       case DQMC_OP_EDGE_SUM: {
         const bool conv = op.kind == DQMC_OP_CONV;
-        const BufView<real> we = view<real>(a, smem, i[0], w0), out = view<real>(a, smem, i[2], w0);
-        BufView<real> hx = we;
-        if (conv) hx = view<real>(a, smem, i[1], w0);
+        const BufRef we = bufref<real>(a, i[0]), out = bufref<real>(a, i[2]);
+        BufRef hx = we;
+        if (conv) hx = bufref<real>(a, i[1]);
         const real scale = conv ? (real)1 : (real)(1.0 / (double)(i[1] > 0 ? i[1] : 1));
         const int32_t* tab = a.itable + i[4];
         const int S = i[5], W = i[6], col0 = i[3];
@@ -209,39 +256,40 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
           for (int s = 0; s < S; ++s) {
             const int row = tab[2 * (el * S + s)], snd = tab[2 * (el * S + s) + 1];
             if (row < 0) continue;
-            const real ev = we.lds[(long)(wl * we.rows + row) * we.stride + c];
-            acc += conv ? ev * hx.lds[(long)(wl * N + snd) * hx.stride + c] : ev;
+            const real ev = smem[we.lds + (wl * we.rows + row) * we.stride + c];
+            acc += conv ? ev * smem[hx.lds + (wl * N + snd) * hx.stride + c] : ev;
           }
-          out.lds[(long)(wl * N + el) * out.stride + col0 + c] = acc * scale;
+          smem[out.lds + (wl * N + el) * out.stride + col0 + c] = acc * scale;
         }
         break;
       }
       case DQMC_OP_ROW_SUM: {
-        const BufView<real> x = view<real>(a, smem, i[0], w0), s = view<real>(a, smem, i[1], w0);
+        const BufRef x = bufref<real>(a, i[0]), s = bufref<real>(a, i[1]);
         for (int e = tid; e < nw * x.width; e += nthr) {
           const int c = e % x.width, wl = e / x.width;
           real acc = 0;
-          for (int el = 0; el < x.rows; ++el) acc += x.lds[(long)(wl * x.rows + el) * x.stride + c];
-          s.lds[(long)wl * s.stride + c] = acc;
+          for (int el = 0; el < x.rows; ++el) acc += smem[x.lds + (wl * x.rows + el) * x.stride + c];
+          smem[s.lds + wl * s.stride + c] = acc;
         }
         break;
       }
       case DQMC_OP_ORBITALS: {
-        const BufView<real> bf = view<real>(a, smem, i[0], w0), orb = view<real>(a, smem, i[1], w0);
+        const BufRef bf = bufref<real>(a, i[0]), orb = bufref<real>(a, i[1]);
+        real* orb_g = reinterpret_cast<real*>(a.ws + orb.goff) + (long)w0 * orb.rows * orb.width;
         const int KN = K * N;
         for (int e = tid; e < nw * N * KN; e += nthr) {
           const int kmu = e % KN, q = e / KN, el = q % N, wl = q / N;
           const int kd = kmu / N, mu = kmu - kd * N;
-          const real* pi = a.w + (el < n_up ? i[2] : i[3]) + (long)kmu * n_nuc;
-          const real* ze = a.w + (el < n_up ? i[4] : i[5]) + (long)kmu * n_nuc;
+          const real* pi = a.w + (el < n_up ? i[2] : i[3]) + kmu * n_nuc;
+          const real* ze = a.w + (el < n_up ? i[4] : i[5]) + kmu * n_nuc;
           double e0 = 0;
           for (int n = 0; n < n_nuc; ++n) {
             double d2 = a.eps;
             for (int c = 0; c < 3; ++c) { const double d = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += d * d; }
             e0 += (double)pi[n] * exp(-fabs((double)ze[n]) * sqrt(d2));
           }
-          const double b0 = (double)bf.lds[(long)(wl * N + el) * bf.stride + kmu];
-          orb.glb[(long)(wl * K + kd) * orb.width + el * N + mu] = (real)(e0 * b0);
+          const double b0 = (double)smem[bf.lds + (wl * N + el) * bf.stride + kmu];
+          orb_g[(wl * K + kd) * orb.width + el * N + mu] = (real)(e0 * b0);
         }
         break;
       }

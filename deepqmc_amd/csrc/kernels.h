@@ -74,6 +74,7 @@ template <typename real> struct FusedArgs {
   const real* r;          // [B][N][3]
   const real* R;          // [n_nuc][3]
   int B, WT, n_up, n_nuc, K;
+  int dbg;                // ablation switches (profiling only; 0 in production)
   LaneInfo li;
   double eps;
 };
