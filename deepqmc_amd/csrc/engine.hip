@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/dqmc.h"
@@ -118,13 +119,15 @@ struct Engine : dqmc_ctx {
   std::vector<real> wtmp;
   // fused value-only plan
   bool fused_enabled = true;
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0;
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 0;
   size_t fused_lds = 0, fused_lds_budget = 48 * 1024, wpk_cap = 0;
   std::vector<dqmc::FusedBuf> fbufs_h;
+  std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
   dqmc_op* d_ops = nullptr;
   dqmc::FusedBuf* d_fbufs = nullptr;
-  long* d_wpk_off = nullptr;
+  int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
+  long long* d_prof = nullptr;
 
   ~Engine() override {
     for (auto e : ev_pool) (void)hipEventDestroy(e);
@@ -234,51 +237,124 @@ struct Engine : dqmc_ctx {
     const std::string s(name);
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
-    if (s == "fused_dbg") { fused_dbg = value; return DQMC_OK; }
+    if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
+    if (s == "fused_dbg") {
+      fused_dbg = value;
+      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (ops.size() + 2)));
+      return DQMC_OK;
+    }
     if (s == "fused_lds_kb") { fused_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
     return fail(DQMC_E_ARG, "unknown option " + s);
   }
 
   // LDS placement of the buffers for a tile of WT walkers: first-fit over live intervals.
+  // Buffers read / written by an op (buffer granularity; partial writers of one buffer touch
+  // disjoint row or column ranges by construction of the program).
+  static void op_io(const dqmc_op& op, std::vector<int>& rd, std::vector<int>& wr) {
+    const int32_t* i = op.i;
+    rd.clear(); wr.clear();
+    switch (op.kind) {
+      case DQMC_OP_FEAT_EN: case DQMC_OP_FEAT_EE: wr.push_back(i[0]); break;
+      case DQMC_OP_LINEAR:
+        for (int p = 0; p < i[0]; ++p) rd.push_back(i[1 + 4 * p]);
+        if (i[25] >= 0) rd.push_back(i[25]);
+        wr.push_back(i[17]); break;
+      case DQMC_OP_SPIN_MEAN: case DQMC_OP_ROW_SUM: rd.push_back(i[0]); wr.push_back(i[1]); break;
+      case DQMC_OP_CONV: rd.push_back(i[0]); rd.push_back(i[1]); wr.push_back(i[2]); break;
+      case DQMC_OP_EDGE_SUM: rd.push_back(i[0]); wr.push_back(i[2]); break;
+      case DQMC_OP_ORBITALS: rd.push_back(i[0]); wr.push_back(i[1]); break;
+      case DQMC_OP_SLOGDET: rd.push_back(i[0]); break;
+      case DQMC_OP_FINAL: if (i[0] >= 0) rd.push_back(i[0]); break;
+      default: break;
+    }
+  }
+
+  // Dependency levels of ops [0, fused_n_ops): ops of one level are independent and run
+  // without a workgroup barrier between them inside the fused kernel.
+  void fused_schedule() {
+    const int no = fused_n_ops, nb = (int)bufs.size();
+    std::vector<int> lvl(no, 0), wlevel(nb, -1);
+    std::vector<int> rd, wr;
+    if (fused_sched_mode == 0) {
+      // Program order kept (so LDS liveness is what the program compiler laid out); a new level
+      // starts whenever an op reads a buffer written inside the current level.
+      int cur = 0;
+      std::vector<char> written(nb, 0);
+      f_order.resize(no);
+      f_level.assign(no, 0);
+      for (int k = 0; k < no; ++k) {
+        op_io(ops[k], rd, wr);
+        bool dep = false;
+        for (int b : rd) dep = dep || written[b];
+        if (dep) { ++cur; std::fill(written.begin(), written.end(), 0); }
+        for (int b : wr) written[b] = 1;
+        f_order[k] = k;
+        f_level[k] = cur;
+      }
+      return;
+    }
+    for (int k = 0; k < no; ++k) {
+      op_io(ops[k], rd, wr);
+      int l = 0;
+      for (int b : rd) if (wlevel[b] + 1 > l) l = wlevel[b] + 1;
+      for (int b : wr) if (wlevel[b] >= 0 && wlevel[b] > l) l = wlevel[b];   // co-writers share a level or later
+      lvl[k] = l;
+      for (int b : wr) if (l > wlevel[b]) wlevel[b] = l;
+    }
+    // a buffer's readers must come after ALL its writers: raise readers to max writer level + 1
+    for (bool changed = true; changed;) {
+      changed = false;
+      std::fill(wlevel.begin(), wlevel.end(), -1);
+      for (int k = 0; k < no; ++k) { op_io(ops[k], rd, wr); for (int b : wr) if (lvl[k] > wlevel[b]) wlevel[b] = lvl[k]; }
+      for (int k = 0; k < no; ++k) {
+        op_io(ops[k], rd, wr);
+        for (int b : rd) if (wlevel[b] >= 0 && lvl[k] <= wlevel[b]) { lvl[k] = wlevel[b] + 1; changed = true; }
+      }
+    }
+    f_order.resize(no);
+    for (int k = 0; k < no; ++k) f_order[k] = k;
+    std::stable_sort(f_order.begin(), f_order.end(), [&](int x, int y) { return lvl[x] < lvl[y]; });
+    f_level.assign(no, 0);
+    for (int j = 0; j < no; ++j) f_level[j] = lvl[f_order[j]];
+  }
+
+  // LDS placement of the buffers for a tile of WT walkers: first-fit over live level intervals.
+  // The first `meta` bytes of LDS hold the program (ops, buffer table, per-op words).
+  size_t fused_meta_bytes() const {
+    return (size_t)dqmc::fused_meta_bytes(fused_n_ops, (int)bufs.size());
+  }
   size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb) const {
     const int nb = (int)bufs.size(), no = fused_n_ops;
-    std::vector<int> first(nb, 1 << 30), last(nb, -1);
-    auto touch = [&](int b, int k, bool write) {
-      if (b < 0) return;
-      if (write && k < first[b]) first[b] = k;
-      if (k < first[b]) first[b] = k;
-      if (k > last[b]) last[b] = k;
-    };
-    for (int k = 0; k < (int)ops.size(); ++k) {
-      const int32_t* i = ops[k].i;
-      switch (ops[k].kind) {
-        case DQMC_OP_FEAT_EN: case DQMC_OP_FEAT_EE: touch(i[0], k, true); break;
-        case DQMC_OP_LINEAR:
-          for (int p = 0; p < i[0]; ++p) touch(i[1 + 4 * p], k, false);
-          touch(i[17], k, true); touch(i[25], k, false); break;
-        case DQMC_OP_SPIN_MEAN: case DQMC_OP_ROW_SUM: touch(i[0], k, false); touch(i[1], k, true); break;
-        case DQMC_OP_CONV: touch(i[0], k, false); touch(i[1], k, false); touch(i[2], k, true); break;
-        case DQMC_OP_EDGE_SUM: touch(i[0], k, false); touch(i[2], k, true); break;
-        case DQMC_OP_ORBITALS: touch(i[0], k, false); touch(i[1], k, true); break;
-        case DQMC_OP_SLOGDET: touch(i[0], k, false); break;
-        case DQMC_OP_FINAL: touch(i[0], k, false); break;
-        default: break;
-      }
+    const int BIG = 1 << 30;
+    std::vector<int> first(nb, BIG), last(nb, -1);
+    std::vector<int> rd, wr;
+    for (int j = 0; j < no; ++j) {
+      op_io(ops[f_order[j]], rd, wr);
+      for (int b : wr) { if (f_level[j] < first[b]) first[b] = f_level[j]; if (f_level[j] > last[b]) last[b] = f_level[j]; }
+      for (int b : rd) { if (f_level[j] < first[b]) first[b] = f_level[j]; if (f_level[j] > last[b]) last[b] = f_level[j]; }
+    }
+    for (int k = no; k < (int)ops.size(); ++k) {      // consumers after the fused range: keep in HBM
+      op_io(ops[k], rd, wr);
+      for (int b : rd) last[b] = BIG;
     }
     fb.assign(nb, dqmc::FusedBuf{});
     struct Seg { size_t off, len; int until; };
     std::vector<Seg> live;
-    size_t peak = 0;
-    for (int k = 0; k < no; ++k) {
+    const size_t base = fused_meta_bytes() / sizeof(real);
+    size_t peak = base;
+    const int n_levels = no ? f_level[no - 1] + 1 : 0;
+    for (int l = 0; l < n_levels; ++l) {
+      for (size_t q = 0; q < live.size();)
+        if (live[q].until < l) live.erase(live.begin() + q); else ++q;
       for (int b = 0; b < nb; ++b) {
-        if (first[b] != k) continue;
+        if (first[b] != l) continue;
         dqmc::FusedBuf& f = fb[b];
         f.rows = bufs[b].rows; f.width = bufs[b].width;
-        if (last[b] >= no) { f.is_global = 1; continue; }   // consumed by a later kernel: HBM
+        if (last[b] == BIG) { f.is_global = 1; continue; }
         f.is_global = 0;
         f.stride = bufs[b].width + 2;
         const size_t len = ((size_t)WT * f.rows * f.stride + 3) / 4 * 4;
-        size_t off = 0;
+        size_t off = base;
         for (bool moved = true; moved;) {
           moved = false;
           for (const Seg& s : live)
@@ -288,8 +364,6 @@ struct Engine : dqmc_ctx {
         live.push_back(Seg{off, len, last[b]});
         if (off + len > peak) peak = off + len;
       }
-      for (size_t q = 0; q < live.size();)
-        if (live[q].until <= k) live.erase(live.begin() + q); else ++q;
     }
     return peak * sizeof(real);
   }
@@ -303,8 +377,9 @@ struct Engine : dqmc_ctx {
     }
     if (n_f < 0) return DQMC_OK;
     fused_n_ops = n_f;
+    fused_schedule();
     fused_WT = 0;
-    const int cand[] = {32, 16, 8, 4, 2, 1};
+    const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
     for (int WT : cand) {
       if (fused_wt_req > 0 && WT != fused_wt_req) continue;
       std::vector<dqmc::FusedBuf> fb;
@@ -312,28 +387,35 @@ struct Engine : dqmc_ctx {
       if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused_lds_budget)) { fused_WT = WT; fused_lds = bytes; fbufs_h = fb; break; }
     }
     if (fused_WT == 0) { fused_n_ops = 0; return DQMC_OK; }   // does not fit: layered path only
+    for (int k = 0; k < fused_n_ops; ++k)                     // residual inputs must be LDS-resident
+      if (ops[k].kind == DQMC_OP_LINEAR && ops[k].i[25] >= 0 && fbufs_h[ops[k].i[25]].is_global) { fused_n_ops = 0; return DQMC_OK; }
     if (!d_ops) {
       HIP_TRY(hipMalloc((void**)&d_ops, sizeof(dqmc_op) * ops.size()));
       HIP_TRY(hipMalloc((void**)&d_fbufs, sizeof(dqmc::FusedBuf) * bufs.size()));
-      HIP_TRY(hipMalloc((void**)&d_wpk_off, sizeof(long) * ops.size()));
-      HIP_TRY(hipMemcpy(d_ops, ops.data(), sizeof(dqmc_op) * ops.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMalloc((void**)&d_wpk_off, 2 * sizeof(int32_t) * ops.size()));
     }
+    std::vector<dqmc_op> sched(fused_n_ops);
+    for (int j = 0; j < fused_n_ops; ++j) sched[j] = ops[f_order[j]];
+    HIP_TRY(hipMemcpy(d_ops, sched.data(), sizeof(dqmc_op) * fused_n_ops, hipMemcpyHostToDevice));
     if (dqmc::fused_set_lds_limit<real>(fused_lds) != 0) { fused_n_ops = 0; return DQMC_OK; }
     return pack_fused_weights();
   }
 
   // Fragment-major copy of the Linear weights: [k/4][column block][lane] so that one wave load
   // of 64 consecutive elements is exactly the MFMA B operand (B[k = l>>4][col = l&15]).
+  // Per scheduled op two words go to the device: packed-weight offset and "barrier after".
   int pack_fused_weights() {
-    std::vector<long> offs(ops.size(), 0);
+    std::vector<int32_t> words(2 * (size_t)fused_n_ops, 0);
     std::vector<real> pk;
-    for (int k = 0; k < fused_n_ops; ++k) {
-      if (ops[k].kind != DQMC_OP_LINEAR) continue;
-      const int32_t* i = ops[k].i;
+    for (int j = 0; j < fused_n_ops; ++j) {
+      const dqmc_op& op = ops[f_order[j]];
+      words[2 * j + 1] = (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) ? 1 : 0;
+      if (op.kind != DQMC_OP_LINEAR) continue;
+      const int32_t* i = op.i;
       const int ldw = pad4(i[21]), NCB = (ldw + 15) / 16;
       int krows = 0;
       for (int p = 0; p < i[0]; ++p) krows += pad4(i[3 + 4 * p]);
-      offs[k] = (long)pk.size();
+      words[2 * j] = (int32_t)pk.size();
       const real* W = wtmp.data() + i[22];
       for (int ks = 0; ks < krows / 4; ++ks)
         for (int cb = 0; cb < NCB; ++cb)
@@ -348,7 +430,7 @@ struct Engine : dqmc_ctx {
       wpk_cap = pk.size();
     }
     HIP_TRY(hipMemcpyAsync(d_wpk, pk.data(), sizeof(real) * pk.size(), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_wpk_off, offs.data(), sizeof(long) * offs.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_wpk_off, words.data(), sizeof(int32_t) * words.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return DQMC_OK;
   }
@@ -357,9 +439,9 @@ struct Engine : dqmc_ctx {
     for (size_t b = 0; b < bufs.size(); ++b) fbufs_h[b].goff = (long)buf_off[b];
     HIP_TRY(hipMemcpyAsync(d_fbufs, fbufs_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
     dqmc::FusedArgs<real> a{};
-    a.ops = d_ops; a.n_ops = fused_n_ops; a.fbufs = d_fbufs; a.wpk_off = d_wpk_off;
+    a.ops = d_ops; a.n_ops = fused_n_ops; a.fbufs = d_fbufs; a.n_bufs = (int)bufs.size(); a.op_words = d_wpk_off;
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
-    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps; a.dbg = fused_dbg;
+    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)
       if (ops[k].kind == DQMC_OP_LINEAR) {
@@ -590,6 +672,13 @@ struct Engine : dqmc_ctx {
       const size_t cnt = (size_t)last_B * sys.n_det * last_TP;
       if (n != cnt) return fail(DQMC_E_ARG, "size mismatch");
       HIP_TRY(hipMemcpy(out, d_ws + off_logdet, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+      return DQMC_OK;
+    }
+    if (buf == -3) {   // per-op shader-clock stamps of the fused kernel (workgroup 0)
+      if (!d_prof || n != (size_t)fused_n_ops + 1) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
+      std::vector<long long> tmp(n);
+      HIP_TRY(hipMemcpy(tmp.data(), d_prof, sizeof(long long) * n, hipMemcpyDeviceToHost));
+      for (size_t k = 0; k < n; ++k) out[k] = (double)tmp[k];
       return DQMC_OK;
     }
     if (buf == -2) {

@@ -11,9 +11,14 @@
 // from a fragment-major packed copy of the weights in L2 (one coalesced 256-byte load per
 // 16x4 tile), v_mfma_f32_16x16x4_f32 accumulation, bias/activation/residual fused in the store.
 //
+// Latency structure (what the SQ counters said mattered): the program itself (ops, buffer
+// table) is copied to LDS once so per-op metadata is a ds_read away, ops arrive grouped in
+// dependency levels (engine.hip: fused_schedule) and only level boundaries carry a workgroup
+// barrier, and the linear "units" of a whole level are dealt round-robin to the waves.
+//
 // Address spaces are kept explicit for the compiler: LDS is only ever indexed through the
-// dynamic-LDS symbol with 32-bit element offsets (ds_read/ds_write, never flat_*), HBM/L2 only
-// through the kernel-argument pointers.
+// dynamic-LDS symbol (ds_read/ds_write, never flat_*), HBM/L2 only through kernel-argument
+// pointers.
 #include "common.h"
 #include "kernels.h"
 
@@ -27,14 +32,18 @@ struct BufRef {
   int width;
 };
 
-template <typename real> __device__ __forceinline__ BufRef bufref(const FusedArgs<real>& a, int b) {
-  const FusedBuf fb = a.fbufs[b];
-  BufRef v;
-  v.rows = fb.rows; v.width = fb.width; v.goff = fb.goff;
-  v.lds = fb.is_global ? -1 : fb.off;
-  v.stride = fb.is_global ? fb.width : fb.stride;
-  return v;
-}
+// q = m / n, r = m % n for 0 <= m < 2^22, n >= 1 without the ~25-instruction integer division.
+struct FastDiv {
+  int n;
+  float inv;
+  __device__ __forceinline__ explicit FastDiv(int n_) : n(n_), inv(1.0f / (float)n_) {}
+  __device__ __forceinline__ void divmod(int m, int& q, int& r) const {
+    q = (int)((float)m * inv);
+    r = m - q * n;
+    if (r < 0) { r += n; --q; }
+    if (r >= n) { r -= n; ++q; }
+  }
+};
 
 template <typename real> __device__ __forceinline__ real act_value(int act, real v) {
   if (act == 1) return r_tanh<real>(v);
@@ -42,13 +51,28 @@ template <typename real> __device__ __forceinline__ real act_value(int act, real
   return v;
 }
 
+// LDS-resident program: [ops][buffer table][op words], then the activation buffers.
+template <typename real> struct Meta {
+  const dqmc_op* ops;
+  const FusedBuf* bufs;
+  const int32_t* words;
+  __device__ __forceinline__ BufRef buf(int b) const {
+    const FusedBuf fb = bufs[b];
+    BufRef v;
+    v.rows = fb.rows; v.width = fb.width; v.goff = fb.goff;
+    v.lds = fb.is_global ? -1 : fb.off;
+    v.stride = fb.is_global ? fb.width : fb.stride;
+    return v;
+  }
+};
+
 // One unit of a fused linear layer: MA row blocks x 2 column blocks of
 // y = act(concat(pieces) W + b) (+ residual) on the tile.  The k loop is branch-free
 // (out-of-range rows / column blocks read a valid dummy location and are dropped at the store)
 // and the B fragments of the next 4 k-steps are in flight while the current 4 are multiplied.
 template <typename real, int MA>
-__device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, const dqmc_op& op, const real* wpk, int nw,
-                                                  int w0, int rb0, int cg) {
+__device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, const Meta<real>& mt, const dqmc_op& op,
+                                                  const real* wpk, int nw, int w0, int rb0, int cg) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   typedef typename Mfma<real>::acc_t acc_t;
@@ -56,6 +80,7 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   const int32_t* i = op.i;
   const int lane = threadIdx.x & 63;
   const int nrows = i[20];
+  const FastDiv fd(nrows);
   const int ldw = (i[21] + 3) / 4 * 4;
   const int Rtot = nw * nrows, NCB = (ldw + 15) / 16;
   int cbi[NRW];
@@ -67,8 +92,7 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   for (int x = 0; x < MA; ++x) {
     int m = (rb0 + x) * 16 + (lane & 15);
     if (m >= Rtot) m = 0;                                 // dummy row, result discarded
-    a_wl[x] = m / nrows;
-    a_rr[x] = m - a_wl[x] * nrows;
+    fd.divmod(m, a_wl[x], a_rr[x]);
   }
   acc_t acc[MA][NRW];
 #pragma unroll
@@ -77,7 +101,7 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
     for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
   int ks0 = 0;
   for (int p = 0; p < i[0]; ++p) {
-    const BufRef src = bufref<real>(a, i[1 + 4 * p]);
+    const BufRef src = mt.buf(i[1 + 4 * p]);
     const int r0 = i[2 + 4 * p], Kp = (i[3 + 4 * p] + 3) / 4 * 4, bc = i[4 + 4 * p];
     int ao[MA];
 #pragma unroll
@@ -87,46 +111,54 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
     const int kstride = NCB * 64;
     const real* wp0 = wpk + (ks0 * NCB + cbi[0]) * 64 + lane;
     const real* wp1 = wpk + (ks0 * NCB + cbi[1]) * 64 + lane;
-    real fbn[KC][NRW];
+    // Software pipeline over chunks of KC k-steps: the B fragments (L2) and the A fragments (LDS)
+    // of chunk c+1 are issued before the MFMAs of chunk c.  k-steps past the end are clamped to
+    // a valid address and their B fragment zeroed, so the loop body has no branches.
+    real fbn[KC][NRW], fan[KC][MA];
 #pragma unroll
     for (int kk = 0; kk < KC; ++kk) {
       const int ks = kk < KS ? kk : KS - 1;
-      fbn[kk][0] = wp0[ks * kstride];
-      fbn[kk][1] = wp1[ks * kstride];
+      const real z = kk < KS ? (real)1 : (real)0;
+      fbn[kk][0] = wp0[ks * kstride] * z;
+      fbn[kk][1] = wp1[ks * kstride] * z;
+#pragma unroll
+      for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
     }
     for (int kc = 0; kc < KS; kc += KC) {
-      real fb[KC][NRW];
+      real fb[KC][NRW], fa[KC][MA];
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) { fb[kk][0] = fbn[kk][0]; fb[kk][1] = fbn[kk][1]; }
+      for (int kk = 0; kk < KC; ++kk) {
+        fb[kk][0] = fbn[kk][0]; fb[kk][1] = fbn[kk][1];
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
+      }
       if (kc + KC < KS) {
 #pragma unroll
         for (int kk = 0; kk < KC; ++kk) {
-          const int ks = (kc + KC + kk < KS) ? kc + KC + kk : KS - 1;
-          fbn[kk][0] = wp0[ks * kstride];
-          fbn[kk][1] = wp1[ks * kstride];
+          const bool ok = kc + KC + kk < KS;
+          const int ks = ok ? kc + KC + kk : KS - 1;
+          const real z = ok ? (real)1 : (real)0;
+          fbn[kk][0] = wp0[ks * kstride] * z;
+          fbn[kk][1] = wp1[ks * kstride] * z;
+#pragma unroll
+          for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
         }
       }
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
-        if (kc + kk < KS) {
-          real fa[MA];
+      for (int kk = 0; kk < KC; ++kk)
 #pragma unroll
-          for (int x = 0; x < MA; ++x) fa[x] = smem[ao[x] + (kc + kk) * 4];
-#pragma unroll
-          for (int x = 0; x < MA; ++x) {
-            acc[x][0] = Mfma<real>::run(fa[x], fb[kk][0], acc[x][0]);
-            acc[x][1] = Mfma<real>::run(fa[x], fb[kk][1], acc[x][1]);
-          }
+        for (int x = 0; x < MA; ++x) {
+          acc[x][0] = Mfma<real>::run(fa[kk][x], fb[kk][0], acc[x][0]);
+          acc[x][1] = Mfma<real>::run(fa[kk][x], fb[kk][1], acc[x][1]);
         }
-      }
     }
     ks0 += KS;
   }
   // epilogue: bias + activation + residual, store to LDS or HBM
-  const BufRef dst = bufref<real>(a, i[17]);
+  const BufRef dst = mt.buf(i[17]);
   const bool has_res = i[25] >= 0;
   BufRef res = dst;
-  if (has_res) res = bufref<real>(a, i[25]);
+  if (has_res) res = mt.buf(i[25]);     // residual inputs are LDS-resident (engine plan)
   const real res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
   const int act = i[24], col0 = i[19];
   real* dst_g = reinterpret_cast<real*>(a.ws + dst.goff) + (long)w0 * dst.rows * dst.width;
@@ -141,12 +173,10 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
       for (int rgi = 0; rgi < 4; ++rgi) {
         const int m = (rb0 + x) * 16 + Mfma<real>::row_of(lane, rgi);
         if (m >= Rtot) continue;
-        const int wl = m / nrows, rr = m - wl * nrows;
+        int wl, rr;
+        fd.divmod(m, wl, rr);
         real v = act_value<real>(act, acc[x][y][rgi] + bv);
-        if (has_res) {
-          const int ro = (wl * res.rows + i[26] + rr) * res.stride + col0 + col;
-          v = (smem[res.lds + ro] + v) * res_scale;      // residual inputs are LDS-resident (engine plan)
-        }
+        if (has_res) v = (smem[res.lds + (wl * res.rows + i[26] + rr) * res.stride + col0 + col] + v) * res_scale;
         const int o = (wl * dst.rows + i[18] + rr) * dst.stride + col0 + col;
         if (dst.lds >= 0) smem[dst.lds + o] = v;
         else dst_g[o] = v;
@@ -154,11 +184,12 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   }
 }
 
-// Work decomposition of one linear layer over the waves of the workgroup: units of
-// (rows_per_unit row blocks) x (2 column blocks), rows_per_unit chosen so that there are at
-// least as many units as waves whenever the layer is big enough.
+// Units of one linear layer: (rows_per_unit row blocks) x (2 column blocks); rows_per_unit is
+// chosen so that there are at least as many units as waves whenever the layer is big enough.
+// `uoff` = units already dealt in this dependency level (keeps the waves evenly loaded).
 template <typename real>
-__device__ __forceinline__ void fused_linear(const FusedArgs<real>& a, const dqmc_op& op, int wpk_off, int nw, int w0) {
+__device__ __forceinline__ int fused_linear(const FusedArgs<real>& a, const Meta<real>& mt, const dqmc_op& op, int wpk_off,
+                                            int nw, int w0, int uoff) {
   const int32_t* i = op.i;
   const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int ldw = (i[21] + 3) / 4 * 4;
@@ -168,37 +199,64 @@ __device__ __forceinline__ void fused_linear(const FusedArgs<real>& a, const dqm
   int rpu = NRB * n_cg / n_waves;
   rpu = rpu < 1 ? 1 : (rpu > 4 ? 4 : rpu);
   const int n_rg = (NRB + rpu - 1) / rpu;
+  const int n_units = n_rg * n_cg;
   const real* wpk = a.wpk + wpk_off;
-  for (int u = wave; u < n_rg * n_cg; u += n_waves) {
+  int first = (wave - uoff) % n_waves;
+  if (first < 0) first += n_waves;
+  for (int u = first; u < n_units; u += n_waves) {
     const int rg = u / n_cg, cg = u - rg * n_cg;
     const int rb0 = rg * rpu;
     const int ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
-    if (ma == 1) fused_linear_unit<real, 1>(a, op, wpk, nw, w0, rb0, cg);
-    else if (ma == 2) fused_linear_unit<real, 2>(a, op, wpk, nw, w0, rb0, cg);
-    else if (ma == 3) fused_linear_unit<real, 3>(a, op, wpk, nw, w0, rb0, cg);
-    else fused_linear_unit<real, 4>(a, op, wpk, nw, w0, rb0, cg);
+    if (ma == 1) fused_linear_unit<real, 1>(a, mt, op, wpk, nw, w0, rb0, cg);
+    else if (ma == 2) fused_linear_unit<real, 2>(a, mt, op, wpk, nw, w0, rb0, cg);
+    else if (ma == 3) fused_linear_unit<real, 3>(a, mt, op, wpk, nw, w0, rb0, cg);
+    else fused_linear_unit<real, 4>(a, mt, op, wpk, nw, w0, rb0, cg);
   }
+  return n_units;
 }
 
 template <typename real>
 __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  // ---- program -> LDS ----
+  const int o_bufs = fused_meta_off_bufs(a.n_ops), o_words = fused_meta_off_words(a.n_ops, a.n_bufs);
+  {
+    int32_t* dst = reinterpret_cast<int32_t*>(smem_raw);
+    const int n_op_w = a.n_ops * (int)(sizeof(dqmc_op) / 4), n_buf_w = a.n_bufs * (int)(sizeof(FusedBuf) / 4);
+    const int32_t* s_ops = reinterpret_cast<const int32_t*>(a.ops);
+    const int32_t* s_buf = reinterpret_cast<const int32_t*>(a.fbufs);
+    for (int e = tid; e < n_op_w; e += nthr) dst[e] = s_ops[e];
+    for (int e = tid; e < n_buf_w; e += nthr) dst[o_bufs / 4 + e] = s_buf[e];
+    for (int e = tid; e < 2 * a.n_ops; e += nthr) dst[o_words / 4 + e] = a.op_words[e];
+  }
+  __syncthreads();
+  Meta<real> mt;
+  mt.ops = reinterpret_cast<const dqmc_op*>(smem_raw);
+  mt.bufs = reinterpret_cast<const FusedBuf*>(smem_raw + o_bufs);
+  mt.words = reinterpret_cast<const int32_t*>(smem_raw + o_words);
+
   const int w0 = blockIdx.x * a.WT;
   const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
   const int N = a.li.N, n_up = a.n_up, n_nuc = a.n_nuc, K = a.K;
-  const int tid = threadIdx.x, nthr = blockDim.x;
   const real* r = a.r + (long)w0 * N * 3;
   LaneInfo li = a.li;   // T = TP = 1
+  const FastDiv fdN(N);
+  int uoff = 0;
+  if (a.prof != nullptr && blockIdx.x == 0 && tid == 0) a.prof[0] = clock64();
 
   for (int k = 0; k < a.n_ops; ++k) {
-    const dqmc_op& op = a.ops[k];
+    const dqmc_op& op = mt.ops[k];
     const int32_t* i = op.i;
     switch (op.kind) {
       case DQMC_OP_FEAT_EN: {
-        const BufRef x = bufref<real>(a, i[0]);
+        const BufRef x = mt.buf(i[0]);
+        const FastDiv fdn(n_nuc);
         for (int e = tid; e < nw * N * n_nuc; e += nthr) {
-          const int n = e % n_nuc, q = e / n_nuc, el = q % N, wl = q / N;
+          int q, n, wl, el;
+          fdn.divmod(e, q, n);
+          fdN.divmod(q, wl, el);
           double d[3], f[4];
           for (int c = 0; c < 3; ++c) d[c] = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c];
           pair_feature_lane(d, a.eps, el, -1, 0, li, i[1] != 0, f);
@@ -213,11 +271,13 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
         break;
       }
       case DQMC_OP_FEAT_EE: {
-        const BufRef eb = bufref<real>(a, i[0]);
+        const BufRef eb = mt.buf(i[0]);
         const int32_t* pairs = a.itable + i[1];
         const int n_rows = i[2];
+        const FastDiv fdr(n_rows);
         for (int e = tid; e < nw * n_rows; e += nthr) {
-          const int kr = e % n_rows, wl = e / n_rows;
+          int wl, kr;
+          fdr.divmod(e, wl, kr);
           const int rc = pairs[2 * kr], sd = pairs[2 * kr + 1];
           double d[3], f[4];
           for (int c = 0; c < 3; ++c) d[c] = (double)r[(wl * N + rc) * 3 + c] - (double)r[(wl * N + sd) * 3 + c];
@@ -228,12 +288,15 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
         break;
       }
       case DQMC_OP_LINEAR:
-        fused_linear<real>(a, op, (int)a.wpk_off[k], nw, w0);
+        uoff += fused_linear<real>(a, mt, op, mt.words[2 * k], nw, w0, uoff);
         break;
       case DQMC_OP_SPIN_MEAN: {
-        const BufRef x = bufref<real>(a, i[0]), m = bufref<real>(a, i[1]);
+        const BufRef x = mt.buf(i[0]), m = mt.buf(i[1]);
+        const FastDiv fdw(x.width);
         for (int e = tid; e < nw * 2 * x.width; e += nthr) {
-          const int c = e % x.width, q = e / x.width, which = q & 1, wl = q >> 1;
+          int q, c;
+          fdw.divmod(e, q, c);
+          const int which = q & 1, wl = q >> 1;
           const int i0 = which ? n_up : 0, i1 = which ? N : n_up;
           real acc = 0;
           for (int el = i0; el < i1; ++el) acc += smem[x.lds + (wl * N + el) * x.stride + c];
@@ -244,14 +307,17 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
       case DQMC_OP_CONV:
       case DQMC_OP_EDGE_SUM: {
         const bool conv = op.kind == DQMC_OP_CONV;
-        const BufRef we = bufref<real>(a, i[0]), out = bufref<real>(a, i[2]);
+        const BufRef we = mt.buf(i[0]), out = mt.buf(i[2]);
         BufRef hx = we;
-        if (conv) hx = bufref<real>(a, i[1]);
+        if (conv) hx = mt.buf(i[1]);
         const real scale = conv ? (real)1 : (real)(1.0 / (double)(i[1] > 0 ? i[1] : 1));
         const int32_t* tab = a.itable + i[4];
         const int S = i[5], W = i[6], col0 = i[3];
+        const FastDiv fdw(W);
         for (int e = tid; e < nw * N * W; e += nthr) {
-          const int c = e % W, q = e / W, el = q % N, wl = q / N;
+          int q, c, wl, el;
+          fdw.divmod(e, q, c);
+          fdN.divmod(q, wl, el);
           real acc = 0;
           for (int s = 0; s < S; ++s) {
             const int row = tab[2 * (el * S + s)], snd = tab[2 * (el * S + s) + 1];
@@ -264,9 +330,11 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
         break;
       }
       case DQMC_OP_ROW_SUM: {
-        const BufRef x = bufref<real>(a, i[0]), s = bufref<real>(a, i[1]);
+        const BufRef x = mt.buf(i[0]), s = mt.buf(i[1]);
+        const FastDiv fdw(x.width);
         for (int e = tid; e < nw * x.width; e += nthr) {
-          const int c = e % x.width, wl = e / x.width;
+          int wl, c;
+          fdw.divmod(e, wl, c);
           real acc = 0;
           for (int el = 0; el < x.rows; ++el) acc += smem[x.lds + (wl * x.rows + el) * x.stride + c];
           smem[s.lds + wl * s.stride + c] = acc;
@@ -274,12 +342,15 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
         break;
       }
       case DQMC_OP_ORBITALS: {
-        const BufRef bf = bufref<real>(a, i[0]), orb = bufref<real>(a, i[1]);
+        const BufRef bf = mt.buf(i[0]), orb = mt.buf(i[1]);
         real* orb_g = reinterpret_cast<real*>(a.ws + orb.goff) + (long)w0 * orb.rows * orb.width;
         const int KN = K * N;
+        const FastDiv fdk(KN);
         for (int e = tid; e < nw * N * KN; e += nthr) {
-          const int kmu = e % KN, q = e / KN, el = q % N, wl = q / N;
-          const int kd = kmu / N, mu = kmu - kd * N;
+          int q, kmu, wl, el, kd, mu;
+          fdk.divmod(e, q, kmu);
+          fdN.divmod(q, wl, el);
+          fdN.divmod(kmu, kd, mu);
           const real* pi = a.w + (el < n_up ? i[2] : i[3]) + kmu * n_nuc;
           const real* ze = a.w + (el < n_up ? i[4] : i[5]) + kmu * n_nuc;
           double e0 = 0;
@@ -296,7 +367,11 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
       default:
         break;
     }
-    __syncthreads();
+    if (mt.words[2 * k + 1]) {   // end of a dependency level
+      __syncthreads();
+      uoff = 0;
+    }
+    if (a.prof != nullptr && blockIdx.x == 0 && tid == 0) a.prof[k + 1] = clock64();
   }
 }
 

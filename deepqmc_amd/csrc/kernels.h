@@ -63,10 +63,11 @@ struct FusedBuf {
   long goff;      // byte offset of the buffer in the workspace
 };
 template <typename real> struct FusedArgs {
-  const ::dqmc_op* ops;   // device copy of the program, executed up to and including ORBITALS
+  const ::dqmc_op* ops;   // device: the scheduled ops (dependency-level order), up to ORBITALS
   int n_ops;
   const FusedBuf* fbufs;  // device
-  const long* wpk_off;    // device: per op, offset of its fragment-major packed weights
+  int n_bufs;
+  const int32_t* op_words; // device: per scheduled op {packed-weight offset, barrier-after flag}
   const real* w;          // plain weights (biases, envelope parameters)
   const real* wpk;        // packed weights: [k/4][col block][64 lanes]
   const int32_t* itable;
@@ -74,10 +75,18 @@ template <typename real> struct FusedArgs {
   const real* r;          // [B][N][3]
   const real* R;          // [n_nuc][3]
   int B, WT, n_up, n_nuc, K;
-  int dbg;                // ablation switches (profiling only; 0 in production)
+  long long* prof;        // optional: shader-clock stamp per op of workgroup 0 (profiling only, else nullptr)
   LaneInfo li;
   double eps;
 };
+// Layout of the program copy at the start of the fused kernel's LDS (16-byte aligned sections).
+__host__ __device__ inline int fused_meta_off_bufs(int n_ops) { return ((int)sizeof(::dqmc_op) * n_ops + 15) / 16 * 16; }
+__host__ __device__ inline int fused_meta_off_words(int n_ops, int n_bufs) {
+  return fused_meta_off_bufs(n_ops) + ((int)sizeof(FusedBuf) * n_bufs + 15) / 16 * 16;
+}
+__host__ __device__ inline int fused_meta_bytes(int n_ops, int n_bufs) {
+  return fused_meta_off_words(n_ops, n_bufs) + (8 * n_ops + 15) / 16 * 16;
+}
 template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes);
 template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 

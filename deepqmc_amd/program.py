@@ -190,17 +190,38 @@ class _Builder:
         """hkext.MLP as a chain of LINEAR ops; hidden activations go to fresh buffers with
         `tmp_rows` rows per walker (row offsets preserved).  The residual applies to the
         last layer only (it wraps the whole MLP, hkext.py:130-137)."""
+        for step in self.mlp_steps(prefix, mspec, pieces, in_dim, out_dim, dst, dst_r0, dst_col0, nrows, tmp_rows,
+                                   res, res_r0, res_scale):
+            step()
+
+    def mlp_steps(self, prefix, mspec: MLPSpec, pieces, in_dim, out_dim, dst, dst_r0, dst_col0, nrows, tmp_rows,
+                  res=-1, res_r0=0, res_scale=1.0):
+        """The LINEAR ops of one MLP as a list of thunks, so that independent MLPs can be emitted
+        in lockstep (ops of equal depth adjacent => one dependency level in the fused kernel).
+        Hidden buffers hold just the `nrows` rows of the segment (`tmp_rows` is unused)."""
         dims = mspec.dims(in_dim, out_dim)
-        cur = pieces
+        state = {'cur': pieces}
+        steps = []
         for k, dim in enumerate(dims):
             last = k == len(dims) - 1
             act = mspec.layer_act(k, len(dims))
-            if last:
-                self.linear(f'{prefix}/linear_{k}', cur, dst, dst_r0, dst_col0, nrows, act, res, res_r0, res_scale)
-            else:
-                hb = self.buf(f'{prefix}/hidden_{k}', tmp_rows, dim)
-                self.linear(f'{prefix}/linear_{k}', cur, hb, dst_r0, 0, nrows, act)
-                cur = [(hb, dst_r0, dim, 0)]
+
+            def step(k=k, dim=dim, last=last, act=act):
+                if last:
+                    self.linear(f'{prefix}/linear_{k}', state['cur'], dst, dst_r0, dst_col0, nrows, act, res, res_r0, res_scale)
+                else:
+                    hb = self.buf(f'{prefix}/hidden_{k}', nrows, dim)
+                    self.linear(f'{prefix}/linear_{k}', state['cur'], hb, 0, 0, nrows, act)
+                    state['cur'] = [(hb, 0, dim, 0)]
+            steps.append(step)
+        return steps
+
+    @staticmethod
+    def lockstep(*chains):
+        for k in range(max(len(c) for c in chains)):
+            for c in chains:
+                if k < len(c):
+                    c[k]()
 
 
 def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int) -> Program:
@@ -277,8 +298,7 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
                 pieces.append((x, 0, x_dim, 0))
             elif uf in ('node_up', 'node_down'):
                 if mean < 0:
-                    mean = b.buf(f'l{l}/mean', 2, x_dim)
-                    b.ops.append(Op(OP_SPIN_MEAN, [x, mean, n_up], note=f'layer {l} spin means'))
+                    mean = b.buf(f'l{l}/mean', 2, x_dim)     # the SPIN_MEAN op is emitted right before g
                 pieces.append((mean, 0 if uf == 'node_up' else 1, x_dim, 1))
             elif uf.startswith('conv_'):
                 t = uf[5:]
@@ -287,9 +307,10 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
                 we = b.names.get(f'l{l}/we')
                 if we is None:
                     we = b.buf(f'l{l}/we', n_edge_rows, E)
-                b.mlp(f'{base}/w_{t}', spec.w, [(e, r0, e_dim, 0)], e_dim, E, we, r0, 0, nr, n_edge_rows)
                 hx = b.buf(f'l{l}/hx_{t}', N, E)
-                b.mlp(f'{base}/h_{t}', spec.h, [(x, 0, x_dim, 0)], x_dim, E, hx, 0, 0, N, N)
+                b.lockstep(
+                    b.mlp_steps(f'{base}/w_{t}', spec.w, [(e, r0, e_dim, 0)], e_dim, E, we, r0, 0, nr, n_edge_rows),
+                    b.mlp_steps(f'{base}/h_{t}', spec.h, [(x, 0, x_dim, 0)], x_dim, E, hx, 0, 0, N, N))
                 tab, S = conv_tab[t]
                 b.ops.append(Op(OP_CONV, [we, hx, cbuf, c_col, tab, S, E], note=f'layer {l} conv_{t}'))
                 c_col += E
@@ -305,6 +326,8 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
         if cbuf >= 0:
             pieces.append((cbuf, 0, c_width, 0))
         assert sum(p[2] for p in pieces) == row['cat']
+        if mean >= 0:
+            b.ops.append(Op(OP_SPIN_MEAN, [x, mean, n_up], note=f'layer {l} spin means'))
         xn = b.buf(f'x{l + 1}', N, D)
         resid = spec.electron_residual_normalize is not None and x_dim == D
         b.mlp(f'{ln}/~/g', spec.g, pieces, row['cat'], D, xn, 0, 0, N, N,
