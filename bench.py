@@ -99,7 +99,7 @@ def main():
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
     ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
-    ap.add_argument('--fused-sched', type=int, default=0, help='1: reorder ops into full dependency levels (more LDS)')
+    ap.add_argument('--fused-sched', type=int, default=-1, help='0: keep program order; 1 (library default): reorder ops into full dependency levels (more LDS)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -118,7 +118,7 @@ def main():
     wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
-    if args.fused_sched:
+    if args.fused_sched >= 0:
         eng.set_option('fused_sched', args.fused_sched)
     if args.fused_lds_kb:
         eng.set_option('fused_lds_kb', args.fused_lds_kb)

@@ -119,8 +119,10 @@ struct Engine : dqmc_ctx {
   std::vector<real> wtmp;
   // fused value-only plan
   bool fused_enabled = true;
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 0;
-  size_t fused_lds = 0, fused_lds_budget = 48 * 1024, wpk_cap = 0;
+  // measured on MI355X (LiH/PauliNet, 4096 walkers): full dependency levels + 4-walker tiles
+  // (2 workgroups per CU) is the fastest configuration of the latency-bound fused kernel
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 1;
+  size_t fused_lds = 0, fused_lds_budget = 80 * 1024, wpk_cap = 0;
   std::vector<dqmc::FusedBuf> fbufs_h;
   std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
   dqmc_op* d_ops = nullptr;
@@ -212,7 +214,13 @@ struct Engine : dqmc_ctx {
         }
         case DQMC_OP_SLOGDET: ok = okb(i[0]) && bufs[i[0]].rows == sys.n_det && bufs[i[0]].width >= N * N && N <= 44; break;
         case DQMC_OP_FINAL: ok = (i[0] < 0 || (okb(i[0]) && bufs[i[0]].rows == 1)) && (i[1] < 0 || (size_t)(i[1] + sys.n_det) <= n_weights) && i[3] >= 0 && (size_t)(i[3] + 2) <= n_weights && i[2] >= 0 && i[2] <= 2; break;
-        case DQMC_OP_ATTENTION: return fail(DQMC_E_UNSUPPORTED, "attention op is not built in this round");
+        case DQMC_OP_ATTENTION:
+          ok = i[4] >= 1 && i[5] >= 1;
+          for (int q = 0; ok && q < 4; ++q) ok = okb(i[q]) && bufs[i[q]].rows == N && bufs[i[q]].width >= i[4] * i[5];
+          if (ok) ok = bufs[i[0]].width == bufs[i[1]].width && bufs[i[0]].width == bufs[i[2]].width && bufs[i[0]].width == bufs[i[3]].width;
+          if (ok && dqmc::attention_lds_bytes<real>(N, i[5]) > (size_t)160 * 1024)
+            return fail(DQMC_E_UNSUPPORTED, "attention tile set (N, head_dim) exceeds the 160 KiB LDS");
+          break;
         default: ok = false;
       }
       if (!ok) return fail(DQMC_E_ARG, "malformed op #" + std::to_string(k) + " kind " + std::to_string(op.kind));
@@ -554,6 +562,15 @@ struct Engine : dqmc_ctx {
                                       d_it + i[4], i[5], i[6], 1.0 / (double)(i[1] > 0 ? i[1] : 1), B, li);
           t_end();
           break;
+        case DQMC_OP_ATTENTION: {
+          // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
+          t_begin("attention", 2.0 * B * i[4] * (double)N * N * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
+          const int rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
+                                                        i[4], i[5], B, li);
+          t_end();
+          if (rc2) return fail(DQMC_E_HIP, "attention launch failed");
+          break;
+        }
         case DQMC_OP_ROW_SUM:
           t_begin("graph", 0);
           dqmc::launch_row_sum<real>(st, bptr(i[0]), bptr(i[1]), B, bufs[i[0]].rows, bufs[i[0]].width, li);

@@ -99,6 +99,13 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   for (int x = 0; x < MA; ++x)
 #pragma unroll
     for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
+  // bias: issued now so that its L2 round trip overlaps the k loop instead of following it
+  real bias_v[NRW];
+#pragma unroll
+  for (int y = 0; y < NRW; ++y) {
+    const int col = cbi[y] * 16 + (lane & 15);
+    bias_v[y] = (i[23] >= 0 && col < ldw) ? a.w[i[23] + col] : (real)0;
+  }
   int ks0 = 0;
   for (int p = 0; p < i[0]; ++p) {
     const BufRef src = mt.buf(i[1 + 4 * p]);
@@ -166,7 +173,7 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   for (int y = 0; y < NRW; ++y) {
     const int col = (cg * NRW + y) * 16 + (lane & 15);
     if (col >= ldw) continue;
-    const real bv = i[23] >= 0 ? a.w[i[23] + col] : (real)0;
+    const real bv = bias_v[y];
 #pragma unroll
     for (int x = 0; x < MA; ++x)
 #pragma unroll

@@ -90,6 +90,13 @@ __host__ __device__ inline int fused_meta_bytes(int n_ops, int n_bufs) {
 template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes);
 template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 
+// ---- kernel_attention.hip ----
+// returns 0, or -1 if the (N, head_dim) tile set does not fit the 160 KiB LDS, -2 on a HIP error
+template <typename real>
+int launch_attention(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd,
+                     int B, LaneInfo li);
+template <typename real> size_t attention_lds_bytes(int N, int hd);
+
 // ---- kernels_head.hip ----
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,

@@ -1,0 +1,41 @@
+"""Psiformer (attention layers) through the SIMT emulator: forward-Laplacian attention kernel,
+log-rescaled input features, spin feature, projection -- against the NumPy interpreter."""
+import numpy as np
+import torch
+
+from deepqmc_amd.engine import Engine
+from deepqmc_amd.hamil import MolecularHamiltonian
+from deepqmc_amd.molecule import Molecule
+from deepqmc_amd.params import init_params
+from deepqmc_amd.spec import AnsatzSpec, MLPSpec, psiformer
+from oracle import geom
+from oracle.program_interp import Interp
+from simt_util import emu_lib
+from test_program_interp import make_walkers
+import dataclasses
+
+
+def small_psiformer():
+    """Psiformer with a narrow embedding so the emulated run stays short (same op set)."""
+    return dataclasses.replace(psiformer(), embedding_dim=32, n_interactions=2, n_determinants=4)
+
+
+def test_psiformer_emu_f64():
+    spec = small_psiformer()
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    for name, idx in eng.program.buf_names.items():
+        np.testing.assert_allclose(eng.debug_read(name, B), it.bufs[idx], rtol=1e-9, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+    val = it.run(r, mol.coords, laplacian=False)
+    sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+    np.testing.assert_array_equal(sign.numpy(), val['sign'])
+    np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-11, atol=1e-11)
