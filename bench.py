@@ -98,6 +98,7 @@ def main():
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
+    ap.add_argument('--fused-occ', type=int, default=0, help='register budget of the fused kernel: workgroups per CU (2..4)')
     ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
     ap.add_argument('--fused-sched', type=int, default=-1, help='0: keep program order; 1 (library default): reorder ops into full dependency levels (more LDS)')
     args = ap.parse_args()
@@ -120,6 +121,8 @@ def main():
     eng = wf.engine(params)
     if args.fused_sched >= 0:
         eng.set_option('fused_sched', args.fused_sched)
+    if args.fused_occ:
+        eng.set_option('fused_occ', args.fused_occ)
     if args.fused_lds_kb:
         eng.set_option('fused_lds_kb', args.fused_lds_kb)
     if args.fused_wt:

@@ -121,7 +121,7 @@ struct Engine : dqmc_ctx {
   bool fused_enabled = true;
   // measured on MI355X (LiH/PauliNet, 4096 walkers): full dependency levels + 4-walker tiles
   // (2 workgroups per CU) is the fastest configuration of the latency-bound fused kernel
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 1;
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 1, fused_occ = 2;
   size_t fused_lds = 0, fused_lds_budget = 80 * 1024, wpk_cap = 0;
   std::vector<dqmc::FusedBuf> fbufs_h;
   std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
@@ -245,10 +245,11 @@ struct Engine : dqmc_ctx {
     const std::string s(name);
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
+    if (s == "fused_occ") { fused_occ = value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
       fused_dbg = value;
-      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (ops.size() + 2)));
+      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80)));
       return DQMC_OK;
     }
     if (s == "fused_lds_kb") { fused_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
@@ -421,16 +422,22 @@ struct Engine : dqmc_ctx {
       if (op.kind != DQMC_OP_LINEAR) continue;
       const int32_t* i = op.i;
       const int ldw = pad4(i[21]), NCB = (ldw + 15) / 16;
-      int krows = 0;
-      for (int p = 0; p < i[0]; ++p) krows += pad4(i[3 + 4 * p]);
+      // quad-interleaved: [piece][quad of 4 k-steps][column block][lane][k-step in quad]; every
+      // piece is zero padded to whole quads, so one 16-byte load per lane feeds 4 MFMA k-steps
       words[2 * j] = (int32_t)pk.size();
       const real* W = wtmp.data() + i[22];
-      for (int ks = 0; ks < krows / 4; ++ks)
-        for (int cb = 0; cb < NCB; ++cb)
-          for (int l = 0; l < 64; ++l) {
-            const int row = ks * 4 + (l >> 4), col = cb * 16 + (l & 15);
-            pk.push_back(col < ldw ? W[(size_t)row * ldw + col] : (real)0);
-          }
+      int row0 = 0;
+      for (int p = 0; p < i[0]; ++p) {
+        const int KS = pad4(i[3 + 4 * p]) / 4, NQ = (KS + 3) / 4;
+        for (int q = 0; q < NQ; ++q)
+          for (int cb = 0; cb < NCB; ++cb)
+            for (int l = 0; l < 64; ++l)
+              for (int jj = 0; jj < 4; ++jj) {
+                const int ks = q * 4 + jj, row = row0 + ks * 4 + (l >> 4), col = cb * 16 + (l & 15);
+                pk.push_back((ks < KS && col < ldw) ? W[(size_t)row * ldw + col] : (real)0);
+              }
+        row0 += KS * 4;
+      }
     }
     if (pk.size() > wpk_cap) {
       if (d_wpk) HIP_TRY(hipFree(d_wpk));
@@ -458,7 +465,7 @@ struct Engine : dqmc_ctx {
         flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
       }
     t_begin("fused_psi", flops);
-    dqmc::launch_fused_value<real>(st, a, (B + fused_WT - 1) / fused_WT, fused_lds);
+    dqmc::launch_fused_value<real>(st, a, (B + fused_WT - 1) / fused_WT, fused_lds, fused_occ);
     t_end();
     return DQMC_OK;
   }
@@ -692,7 +699,7 @@ struct Engine : dqmc_ctx {
       return DQMC_OK;
     }
     if (buf == -3) {   // per-op shader-clock stamps of the fused kernel (workgroup 0)
-      if (!d_prof || n != (size_t)fused_n_ops + 1) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
+      if (!d_prof || n > 9 * ops.size() + 80) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
       std::vector<long long> tmp(n);
       HIP_TRY(hipMemcpy(tmp.data(), d_prof, sizeof(long long) * n, hipMemcpyDeviceToHost));
       for (size_t k = 0; k < n; ++k) out[k] = (double)tmp[k];

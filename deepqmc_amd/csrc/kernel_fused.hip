@@ -72,13 +72,15 @@ template <typename real> struct Meta {
 // and the B fragments of the next 4 k-steps are in flight while the current 4 are multiplied.
 template <typename real, int MA>
 __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, const Meta<real>& mt, const dqmc_op& op,
-                                                  const real* wpk, int nw, int w0, int rb0, int cg) {
+                                                  const real* wpk, int nw, int w0, int rb0, int cg, int slot) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   typedef typename Mfma<real>::acc_t acc_t;
-  constexpr int NRW = 2, KC = 4;
+  constexpr int NRW = 2;
   const int32_t* i = op.i;
   const int lane = threadIdx.x & 63;
+  const bool stamp = a.prof != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  if (stamp) a.prof[64 + 8 * slot + 0] = clock64();
   const int nrows = i[20];
   const FastDiv fd(nrows);
   const int ldw = (i[21] + 3) / 4 * 4;
@@ -106,7 +108,8 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
     const int col = cbi[y] * 16 + (lane & 15);
     bias_v[y] = (i[23] >= 0 && col < ldw) ? a.w[i[23] + col] : (real)0;
   }
-  int ks0 = 0;
+  if (stamp) a.prof[64 + 8 * slot + 1] = clock64();
+  int q0 = 0;
   for (int p = 0; p < i[0]; ++p) {
     const BufRef src = mt.buf(i[1 + 4 * p]);
     const int r0 = i[2 + 4 * p], Kp = (i[3 + 4 * p] + 3) / 4 * 4, bc = i[4 + 4 * p];
@@ -115,52 +118,67 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
     for (int x = 0; x < MA; ++x)
       ao[x] = src.lds + (a_wl[x] * src.rows + r0 + (bc ? 0 : a_rr[x])) * src.stride + (lane >> 4);
     const int KS = Kp / 4;
-    const int kstride = NCB * 64;
-    const real* wp0 = wpk + (ks0 * NCB + cbi[0]) * 64 + lane;
-    const real* wp1 = wpk + (ks0 * NCB + cbi[1]) * 64 + lane;
-    // Software pipeline over chunks of KC k-steps: the B fragments (L2) and the A fragments (LDS)
-    // of chunk c+1 are issued before the MFMAs of chunk c.  k-steps past the end are clamped to
-    // a valid address and their B fragment zeroed, so the loop body has no branches.
-    real fbn[KC][NRW], fan[KC][MA];
+    const int NQ = (KS + 3) / 4;                 // quads of 4 k-steps; the packed weights are zero padded
+    // B fragments: one 16-byte load per lane = 4 consecutive k-steps of one 16-column block
+    // (fragment-major, quad-interleaved packing, engine.hip: pack_fused_weights).  A ring of D quads
+    // (16 k-steps) stays in flight to cover the L2 round trip; A fragments (LDS) run one quad ahead.
+    constexpr int D = 4;
+    const Vec4<real>* wq[NRW];
 #pragma unroll
-    for (int kk = 0; kk < KC; ++kk) {
+    for (int y = 0; y < NRW; ++y) wq[y] = reinterpret_cast<const Vec4<real>*>(wpk) + ((long)(q0 * NCB + cbi[y]) * 64 + lane);
+    const int qstride = NCB * 64;
+    Vec4<real> ring[D][NRW];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (d < NQ) {                                // wave-uniform; short layers load only what they use
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ring[d][y] = wq[y][(long)d * qstride];
+      }
+    }
+    if (stamp && p == 0) { a.prof[64 + 8 * slot + 2] = clock64(); a.prof[64 + 8 * slot + 6] = (long long)(ring[0][0].v[0] != 0); a.prof[64 + 8 * slot + 3] = clock64(); }
+    real fan[4][MA];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
       const int ks = kk < KS ? kk : KS - 1;
-      const real z = kk < KS ? (real)1 : (real)0;
-      fbn[kk][0] = wp0[ks * kstride] * z;
-      fbn[kk][1] = wp1[ks * kstride] * z;
 #pragma unroll
       for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
     }
-    for (int kc = 0; kc < KS; kc += KC) {
-      real fb[KC][NRW], fa[KC][MA];
+    for (int q = 0; q < NQ; q += D) {
 #pragma unroll
-      for (int kk = 0; kk < KC; ++kk) {
-        fb[kk][0] = fbn[kk][0]; fb[kk][1] = fbn[kk][1];
+      for (int d = 0; d < D; ++d) {
+        if (q + d < NQ) {                          // wave-uniform
+          Vec4<real> cur[NRW];
 #pragma unroll
-        for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
-      }
-      if (kc + KC < KS) {
+          for (int y = 0; y < NRW; ++y) cur[y] = ring[d][y];
+          if (q + d + D < NQ) {
 #pragma unroll
-        for (int kk = 0; kk < KC; ++kk) {
-          const bool ok = kc + KC + kk < KS;
-          const int ks = ok ? kc + KC + kk : KS - 1;
-          const real z = ok ? (real)1 : (real)0;
-          fbn[kk][0] = wp0[ks * kstride] * z;
-          fbn[kk][1] = wp1[ks * kstride] * z;
+            for (int y = 0; y < NRW; ++y) ring[d][y] = wq[y][(long)(q + d + D) * qstride];
+          }
+          real fa[4][MA];
 #pragma unroll
-          for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {         // A fragments of the next quad (clamped past the end)
+            int ks = (q + d + 1) * 4 + kk;
+            ks = ks < KS ? ks : KS - 1;
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) {
+              acc[x][0] = Mfma<real>::run(fa[kk][x], cur[0].v[kk], acc[x][0]);
+              acc[x][1] = Mfma<real>::run(fa[kk][x], cur[1].v[kk], acc[x][1]);
+            }
         }
       }
-#pragma unroll
-      for (int kk = 0; kk < KC; ++kk)
-#pragma unroll
-        for (int x = 0; x < MA; ++x) {
-          acc[x][0] = Mfma<real>::run(fa[kk][x], fb[kk][0], acc[x][0]);
-          acc[x][1] = Mfma<real>::run(fa[kk][x], fb[kk][1], acc[x][1]);
-        }
     }
-    ks0 += KS;
+    q0 += NQ;
   }
+  if (stamp) a.prof[64 + 8 * slot + 4] = clock64();
   // epilogue: bias + activation + residual, store to LDS or HBM
   const BufRef dst = mt.buf(i[17]);
   const bool has_res = i[25] >= 0;
@@ -169,26 +187,89 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
   const real res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
   const int act = i[24], col0 = i[19];
   real* dst_g = reinterpret_cast<real*>(a.ws + dst.goff) + (long)w0 * dst.rows * dst.width;
+  // phase 1: destination / residual row offsets of the 4*MA rows this lane holds (once, not per column)
+  int d_off[MA][4], r_off[MA][4];
+  bool r_ok[MA][4];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) {
+      int m = (rb0 + x) * 16 + Mfma<real>::row_of(lane, rgi);
+      r_ok[x][rgi] = m < Rtot;
+      if (m >= Rtot) m = 0;
+      int wl, rr;
+      fd.divmod(m, wl, rr);
+      d_off[x][rgi] = (wl * dst.rows + i[18] + rr) * dst.stride + col0;
+      r_off[x][rgi] = res.lds + (wl * res.rows + i[26] + rr) * res.stride + col0;
+    }
+  int colv[NRW];
+  bool c_ok[NRW];
 #pragma unroll
   for (int y = 0; y < NRW; ++y) {
-    const int col = (cg * NRW + y) * 16 + (lane & 15);
-    if (col >= ldw) continue;
-    const real bv = bias_v[y];
+    colv[y] = (cg * NRW + y) * 16 + (lane & 15);
+    c_ok[y] = colv[y] < ldw;
+    if (!c_ok[y]) colv[y] = 0;
+  }
+  // phase 2: residual reads issued together (valid dummy addresses for masked elements)
+  real rv[MA][4][NRW];
+  if (has_res) {
 #pragma unroll
     for (int x = 0; x < MA; ++x)
 #pragma unroll
-      for (int rgi = 0; rgi < 4; ++rgi) {
-        const int m = (rb0 + x) * 16 + Mfma<real>::row_of(lane, rgi);
-        if (m >= Rtot) continue;
-        int wl, rr;
-        fd.divmod(m, wl, rr);
-        real v = act_value<real>(act, acc[x][y][rgi] + bv);
-        if (has_res) v = (smem[res.lds + (wl * res.rows + i[26] + rr) * res.stride + col0 + col] + v) * res_scale;
-        const int o = (wl * dst.rows + i[18] + rr) * dst.stride + col0 + col;
-        if (dst.lds >= 0) smem[dst.lds + o] = v;
-        else dst_g[o] = v;
-      }
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) rv[x][rgi][y] = smem[r_off[x][rgi] + colv[y]];
   }
+  // phase 3: bias + activation (+ residual) in registers
+  real ov[MA][4][NRW];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+      for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = acc[x][y][rgi] + bias_v[y];
+  if (act == 1) {                                  // wave-uniform: one branch around the whole batch
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = r_tanh<real>(ov[x][rgi][y]);
+  } else if (act == 2) {
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = act_value<real>(2, ov[x][rgi][y]);
+  }
+  if (has_res) {
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = (rv[x][rgi][y] + ov[x][rgi][y]) * res_scale;
+  }
+  // phase 4: stores; the LDS / HBM choice is wave-uniform
+  if (dst.lds >= 0) {
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y)
+          if (r_ok[x][rgi] && c_ok[y]) smem[dst.lds + d_off[x][rgi] + colv[y]] = ov[x][rgi][y];
+  } else {
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y)
+          if (r_ok[x][rgi] && c_ok[y]) dst_g[d_off[x][rgi] + colv[y]] = ov[x][rgi][y];
+  }
+  if (stamp) a.prof[64 + 8 * slot + 5] = clock64();
 }
 
 // Units of one linear layer: (rows_per_unit row blocks) x (2 column blocks); rows_per_unit is
@@ -196,7 +277,7 @@ __device__ __forceinline__ void fused_linear_unit(const FusedArgs<real>& a, cons
 // `uoff` = units already dealt in this dependency level (keeps the waves evenly loaded).
 template <typename real>
 __device__ __forceinline__ int fused_linear(const FusedArgs<real>& a, const Meta<real>& mt, const dqmc_op& op, int wpk_off,
-                                            int nw, int w0, int uoff) {
+                                            int nw, int w0, int uoff, int slot) {
   const int32_t* i = op.i;
   const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const int ldw = (i[21] + 3) / 4 * 4;
@@ -214,16 +295,16 @@ __device__ __forceinline__ int fused_linear(const FusedArgs<real>& a, const Meta
     const int rg = u / n_cg, cg = u - rg * n_cg;
     const int rb0 = rg * rpu;
     const int ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
-    if (ma == 1) fused_linear_unit<real, 1>(a, mt, op, wpk, nw, w0, rb0, cg);
-    else if (ma == 2) fused_linear_unit<real, 2>(a, mt, op, wpk, nw, w0, rb0, cg);
-    else if (ma == 3) fused_linear_unit<real, 3>(a, mt, op, wpk, nw, w0, rb0, cg);
-    else fused_linear_unit<real, 4>(a, mt, op, wpk, nw, w0, rb0, cg);
+    if (ma == 1) fused_linear_unit<real, 1>(a, mt, op, wpk, nw, w0, rb0, cg, slot);
+    else if (ma == 2) fused_linear_unit<real, 2>(a, mt, op, wpk, nw, w0, rb0, cg, slot);
+    else if (ma == 3) fused_linear_unit<real, 3>(a, mt, op, wpk, nw, w0, rb0, cg, slot);
+    else fused_linear_unit<real, 4>(a, mt, op, wpk, nw, w0, rb0, cg, slot);
   }
   return n_units;
 }
 
 template <typename real>
-__global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
+__device__ __forceinline__ void fused_body(const FusedArgs<real>& a) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -295,7 +376,7 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
         break;
       }
       case DQMC_OP_LINEAR:
-        uoff += fused_linear<real>(a, mt, op, mt.words[2 * k], nw, w0, uoff);
+        uoff += fused_linear<real>(a, mt, op, mt.words[2 * k], nw, w0, uoff, k);
         break;
       case DQMC_OP_SPIN_MEAN: {
         const BufRef x = mt.buf(i[0]), m = mt.buf(i[1]);
@@ -382,16 +463,26 @@ __global__ void __launch_bounds__(256) k_fused_value(const FusedArgs<real> a) {
   }
 }
 
-template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused_value<real>), dim3((unsigned)n_blocks), dim3(256), lds_bytes, st, a);
+// OCC = workgroups (of 4 waves) the register allocation must leave room for per CU: the kernel is
+// latency bound, so co-resident workgroups are what hides the per-op latency chains.
+template <typename real, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_fused_value(const FusedArgs<real> a) { fused_body<real>(a); }
+
+template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes, int occ) {
+  const dim3 g((unsigned)n_blocks), b(256);
+  if (occ >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused_value<real, 4>), g, b, lds_bytes, st, a);
+  else if (occ == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused_value<real, 3>), g, b, lds_bytes, st, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused_value<real, 2>), g, b, lds_bytes, st, a);
 }
 template <typename real> int fused_set_lds_limit(size_t lds_bytes) {
-  return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_value<real>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_value<real, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_value<real, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_value<real, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  return rc;
 }
 
-template void launch_fused_value<float>(hipStream_t, const FusedArgs<float>&, int, size_t);
-template void launch_fused_value<double>(hipStream_t, const FusedArgs<double>&, int, size_t);
+template void launch_fused_value<float>(hipStream_t, const FusedArgs<float>&, int, size_t, int);
+template void launch_fused_value<double>(hipStream_t, const FusedArgs<double>&, int, size_t, int);
 template int fused_set_lds_limit<float>(size_t);
 template int fused_set_lds_limit<double>(size_t);
 

@@ -87,7 +87,7 @@ __host__ __device__ inline int fused_meta_off_words(int n_ops, int n_bufs) {
 __host__ __device__ inline int fused_meta_bytes(int n_ops, int n_bufs) {
   return fused_meta_off_words(n_ops, n_bufs) + (8 * n_ops + 15) / 16 * 16;
 }
-template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes);
+template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes, int occ);
 template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 
 // ---- kernel_attention.hip ----

@@ -20,10 +20,14 @@ for _ in range(3):
     eng.wf_eval(r)
 torch.cuda.synchronize()
 n_f = next(k for k, op in enumerate(eng.program.ops) if op.kind == 8) + 1
-out = np.empty(n_f + 1)
+out = np.zeros(64 + 8 * n_f + 8)
 eng._check(eng.lib.dqmc_debug_read(eng._ctx, -3, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
-d = np.diff(out)
-print('total cycles (wg 0):', out[-1] - out[0], ' = %.1f us at 2.4 GHz' % ((out[-1] - out[0]) / 2400))
+d = np.diff(out[:n_f + 1])
+print('total cycles (wg 0):', out[n_f] - out[0], ' = %.1f us at 2.4 GHz' % ((out[n_f] - out[0]) / 2400))
+for k in range(n_f):
+    u = out[64 + 8 * k: 64 + 8 * k + 6]
+    if u[0] > 0:
+        print('unit', k, [int(x) for x in np.diff(u)])
 kinds = {1: 'FEAT_EN', 2: 'FEAT_EE', 3: 'LINEAR', 4: 'SPIN_MEAN', 5: 'CONV', 6: 'EDGE_SUM', 7: 'ROW_SUM', 8: 'ORBITALS'}
 # the kernel executes ops in level order; we do not know the order here, so print raw slots
 for k, c in enumerate(d):
