@@ -1,11 +1,20 @@
-"""CPU oracle: a float64 PyTorch restatement of the reference's local-energy / MCMC path.
+"""CPU oracle: a float64 PyTorch/NumPy restatement of the reference's local-energy / MCMC path.
 
 TEST INFRASTRUCTURE ONLY.  Nothing under `deepqmc_amd/` imports this package; only
 `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may.  Each function
 cites the reference file:line it restates.  The reference itself (JAX/haiku, Python>=3.12)
-cannot be imported in this environment, so the oracle is pinned against
-the reference's parameter-free golden vectors (tests/golden/, generated by
-tests/golden/make_golden.py from /root/reference/tests/*.npz) and by three independent
-Laplacian evaluations agreeing with each other.  Parameter-dependent goldens of the
-reference need its PRNG + haiku initialisation stream: see DESIGN.md "parity status".
+cannot be imported in this environment.
+
+Parity status: PINNED.  The oracle reproduces
+  * the reference's parameter-free goldens (edge construction/ordering, Coulomb terms,
+    Hamiltonian integers, geometries) -- tests/test_oracle_golden.py, and
+  * its parameter-DEPENDENT goldens test_wf/test_psi.npz (log|psi| to 6e-7), test_laplace_psi.npz
+    (Laplacian to 6e-8 relative, quantum force to 5e-7), test_hamil/test_local_energy_Molecular_.npz
+    (E_loc to 1.4e-7 relative; the reference's own tolerance is 2e-4) and the CI weights of
+    test_grad_psi.npz -- tests/test_reference_goldens.py, by emulating JAX's threefry PRNG and
+    haiku's initialisation order for the reference's test ansatz (oracle/jaxrng.py,
+    oracle/ref_test_ansatz.py).
+Not pinned: the sampler goldens (need jax.random.normal/categorical/orthogonal streams and the
+reference's electron initialiser), hk.MultiHeadAttention / LayerNorm semantics (no reference
+test instantiates the Psiformer configs), ECP values (pyscf tables absent).
 """
