@@ -13,8 +13,11 @@ Parity status: PINNED.  The oracle reproduces
     (E_loc to 1.4e-7 relative; the reference's own tolerance is 2e-4) and the CI weights of
     test_grad_psi.npz -- tests/test_reference_goldens.py, by emulating JAX's threefry PRNG and
     haiku's initialisation order for the reference's test ansatz (oracle/jaxrng.py,
-    oracle/ref_test_ansatz.py).
-Not pinned: the sampler goldens (need jax.random.normal/categorical/orthogonal streams and the
-reference's electron initialiser), hk.MultiHeadAttention / LayerNorm semantics (no reference
-test instantiates the Psiformer configs), ECP values (pyscf tables absent).
+    oracle/ref_test_ansatz.py), and
+  * its sampler goldens test_sampling/test_sampler_{init,sample}_{Metropolis,DecorrMetropolis}_.npz:
+    psi of the 10 initial walkers, then 4 x sample(PRNGKey(step)) through oracle/sampling.py driven by
+    the emulated jax.random.split/normal/uniform streams -- ages and tau exactly, positions to 1e-12.
+Not pinned: the Langevin sampler golden (sampler not restated), the electron initialiser
+(jax.random.categorical/orthogonal), hk.MultiHeadAttention / LayerNorm semantics (no reference test
+instantiates the Psiformer configs), ECP values (pyscf tables absent).
 """

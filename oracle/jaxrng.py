@@ -107,6 +107,13 @@ class JaxRNG:
         return np.clip(out, np.nextafter(lower, np.inf), np.nextafter(upper, -np.inf))
 
 
+    def normal(self, key, shape, dtype=np.float64):
+        """jax.random.normal: sqrt(2) * erfinv(U(nextafter(-1, 0), 1))."""
+        lo = np.nextafter(dtype(-1.0), dtype(0.0))
+        u = self.uniform(key, shape, dtype, lo, dtype(1.0))
+        return (np.sqrt(2.0) * erfinv(u.astype(np.float64))).astype(dtype)
+
+
 class HaikuInit:
     """hk.PRNGSequence + the initialisers the reference's test ansatz uses."""
 

@@ -16,12 +16,16 @@ from . import geom
 from .physics import batch_wave_function
 
 
-def metropolis_step(params, spec, state: dict, R, n_up, eps, noise, unif, max_age=None, target_acceptance=0.57):
+def metropolis_step(params, spec, state: dict, R, n_up, eps, noise, unif, max_age=None, target_acceptance=0.57,
+                    psi_fn=None):
     """One MetropolisSampler.sample (electron_samplers.py:140-152).  `state` holds
     r[B,N,3], sign[B], log[B], age[B] (int), tau (float)."""
     r, tau = state['r'], state['tau']
     r_prop = r + tau * noise                                            # :102-104
-    sign_p, log_p = batch_wave_function(params, spec, r_prop, R, n_up, eps)
+    if psi_fn is not None:          # any batched wave function r[B,N,3] -> (sign[B], log[B])
+        sign_p, log_p = psi_fn(r_prop)
+    else:
+        sign_p, log_p = batch_wave_function(params, spec, r_prop, R, n_up, eps)
     log_prob = 2 * (log_p - state['log'])                               # :106-107
     accepted = log_prob > torch.log(unif)                               # :118 (NaN -> False)
     if max_age is not None:
@@ -55,14 +59,14 @@ def sampler_stats(state: dict, acceptance: float, eps: float):
     }
 
 
-def decorr_sample(params, spec, state, R, n_up, eps, noise, unif, max_age=None, target_acceptance=0.57):
+def decorr_sample(params, spec, state, R, n_up, eps, noise, unif, max_age=None, target_acceptance=0.57, psi_fn=None):
     """DecorrSampler.sample (electron_samplers.py:347-357): `length` = noise.shape[0]
     Metropolis sub-steps, stats of the last one.  Returns (state, stats, accept[n_sub,B])."""
     acc_hist = []
     acceptance = 0.0
     for k in range(noise.shape[0]):
         state, accepted, acceptance = metropolis_step(
-            params, spec, state, R, n_up, eps, noise[k], unif[k], max_age, target_acceptance)
+            params, spec, state, R, n_up, eps, noise[k], unif[k], max_age, target_acceptance, psi_fn)
         acc_hist.append(accepted)
     return state, sampler_stats(state, acceptance, eps), torch.stack(acc_hist)
 

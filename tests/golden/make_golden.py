@@ -42,6 +42,14 @@ def main():
     out['hamil_E_loc'] = np.load(f'{REF}/test_hamil/test_local_energy_Molecular_.npz')['E_loc']
     d = np.load(f'{REF}/test_wf/test_grad_psi.npz')
     out['wf_grad_conf_coeff_w'] = d['neural_network_wave_function/~/conf_coeff:w']
+    # sampler goldens (tests/test_sampling.py): initial state and state/stats after 4 sample() calls
+    for tag in ('Metropolis', 'DecorrMetropolis'):
+        d = np.load(f'{REF}/test_sampling/test_sampler_init_{tag}_.npz')
+        for k in d.files:
+            out[f'sampler_init_{tag}_{k}'] = d[k]
+        d = np.load(f'{REF}/test_sampling/test_sampler_sample_{tag}_.npz')
+        for k in d.files:
+            out[f'sampler_sample_{tag}_{k}'] = d[k]
     np.savez(OUT, **out)
     for k, v in out.items():
         print(k, np.asarray(v).shape)
