@@ -1,0 +1,54 @@
+"""Batch-level callers of the hot path: `compute_local_energy` (reference
+src/deepqmc/loss/energy.py:19-60) and `compute_psi_ratio` (loss/overlap.py:19-99), with the
+reference's `[molecule, electronic state, walker]` batch axes.  The molecule and state axes are
+host loops over HIP contexts (one per state's parameter set); the walker axis is the GPU batch.
+Only single-geometry batches (M = 1, the `IdleNucleiSampler` case of the BASELINE configs) are
+accepted.
+"""
+from __future__ import annotations
+
+from typing import Sequence
+
+import torch
+
+from .hamil import STAT_KEYS
+
+
+def _check(r):
+    if r.dim() != 5 or r.shape[0] != 1:
+        raise ValueError('expected r[M=1, S, B, N, 3]')
+
+
+def compute_local_energy(rng, hamil, ansatz, params: Sequence, phys_conf_r: torch.Tensor):
+    """loss/energy.py:19-60: returns (E_loc[M,S,B], stats{key: [M,S]} = per-(molecule,state)
+    means over the walkers, energy.py:59).  `params` = one parameter tree per state."""
+    _check(phys_conf_r)
+    S = phys_conf_r.shape[1]
+    assert len(params) == S
+    es, stats = [], {k: [] for k in STAT_KEYS}
+    for s in range(S):
+        e, st = ansatz.engine(params[s]).local_energy(phys_conf_r[0, s].contiguous(), rng=rng)
+        es.append(e)
+        for k in STAT_KEYS:
+            stats[k].append(st[k].mean())
+    return torch.stack(es)[None], {k: torch.stack(v)[None] for k, v in stats.items()}
+
+
+def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
+    """loss/overlap.py:77-99 + :40-75: R[m, i, j, b] = psi_i(r_b ~ psi_j^2) / psi_j(r_b ~ psi_j^2),
+    computed from log-shifted values (shift = mean log|psi| of each state i over all samples)."""
+    _check(phys_conf_r)
+    S, B = phys_conf_r.shape[1], phys_conf_r.shape[2]
+    sign = torch.empty(S, S, B, dtype=torch.float64, device=phys_conf_r.device)
+    log = torch.empty(S, S, B, dtype=torch.float64, device=phys_conf_r.device)
+    for i in range(S):                       # wave function i ...
+        eng = ansatz.engine(params[i])
+        for j in range(S):                   # ... on the samples of state j
+            sg, lg = eng.wf_eval(phys_conf_r[0, j].contiguous())
+            sign[i, j], log[i, j] = sg.double(), lg.double()
+    mean_log = log.mean(dim=(1, 2))                                   # overlap.py:92-94
+    shifted = log - mean_log[:, None, None]
+    diag = torch.diagonal(shifted, dim1=0, dim2=1).permute(1, 0)     # [S(j), B]
+    log_ratio = shifted - diag[None]
+    sdiag = torch.diagonal(sign, dim1=0, dim2=1).permute(1, 0)
+    return (sign * sdiag[None] * torch.exp(log_ratio))[None]

@@ -71,3 +71,26 @@ class DecorrSampler(MetropolisSampler):
     def __init__(self, hamil, wf, *, length: int = 30, **kw):
         super().__init__(hamil, wf, **kw)
         self.length = length
+
+
+class MultiElectronicStateSampler:
+    """sampling/combined_samplers.py:58-90: one independent Markov chain ensemble per electronic
+    state, each with its own parameter set.  The reference vmaps the sampler over the state axis;
+    here the states are a host loop over HIP contexts.  States/stats gain a leading list axis."""
+
+    def __init__(self, sampler, n_state: int):
+        self.sampler, self.n_state = sampler, n_state
+
+    def init(self, rng, params, electron_batch_size: int, R=None):
+        return [self.sampler.init(int(rng) * self.n_state + s, params[s], electron_batch_size, R)
+                for s in range(self.n_state)]
+
+    def sample(self, rng, state, params, R=None):
+        out = [self.sampler.sample(int(rng) * self.n_state + s, state[s], params[s], R) for s in range(self.n_state)]
+        states, pcs, stats = zip(*out)
+        r = torch.stack([pc.r for pc in pcs])
+        return list(states), PhysicalConfiguration(pcs[0].R, r, torch.zeros(r.shape[:2], dtype=torch.int32, device=r.device)), \
+            {k: [st[k] for st in stats] for k in stats[0]}
+
+    def update(self, state, params, R=None):
+        return [self.sampler.update(state[s], params[s], R) for s in range(self.n_state)]

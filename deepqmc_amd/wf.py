@@ -26,8 +26,8 @@ class NeuralNetworkWaveFunction:
         self.hamil = hamil
         self.spec: AnsatzSpec = ANSATZES[spec]() if isinstance(spec, str) else spec
         self.dtype, self.device, self.norm_eps, self._lib = dtype, device, norm_eps, lib
-        self._engine = None
-        self._params_id = None
+        self._engines = {}       # id(params) -> Engine, most recently used last (one per electronic state)
+        self.max_engines = 8
 
     def init(self, rng=0, phys_conf=None, **kw):
         """types.py:121-133.  `rng`: an integer seed (the JAX key stream is not reproduced)."""
@@ -35,14 +35,21 @@ class NeuralNetworkWaveFunction:
         return init_params(self.spec, h.n_up, h.n_down, h.n_nuc, seed=int(rng), **kw)
 
     def engine(self, params) -> Engine:
-        if self._engine is None:
-            self._engine = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,
-                                  norm_eps=self.norm_eps, lib=self._lib)
-            self._params_id = id(params)
-        elif id(params) != self._params_id:
-            self._engine.set_params(params)
-            self._params_id = id(params)
-        return self._engine
+        """One HIP context per live parameter tree (e.g. per electronic state, the leading `S` axis of
+        the reference's params, wf/base.py:27); the least recently used context is re-targeted with
+        `set_params` once `max_engines` trees are alive."""
+        key = id(params)
+        eng = self._engines.pop(key, None)
+        if eng is None:
+            if len(self._engines) >= self.max_engines:
+                old_key = next(iter(self._engines))
+                eng = self._engines.pop(old_key)
+                eng.set_params(params)
+            else:
+                eng = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,
+                             norm_eps=self.norm_eps, lib=self._lib)
+        self._engines[key] = eng
+        return eng
 
     def apply(self, params, phys_conf, return_mos: bool = False) -> Psi:
         """types.py:135-150 (batched)."""

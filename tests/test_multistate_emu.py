@@ -1,0 +1,53 @@
+"""Multi-state wrappers (reference sampling/combined_samplers.py:58-90, loss/energy.py:19-60,
+loss/overlap.py:40-99) through the SIMT emulator against closed forms / the oracle."""
+import numpy as np
+import torch
+
+from deepqmc_amd import MolecularHamiltonian, Molecule
+from deepqmc_amd import loss
+from deepqmc_amd.sampling import DecorrSampler, MultiElectronicStateSampler, synthetic_walkers
+from deepqmc_amd.wf import NeuralNetworkWaveFunction
+from oracle import geom, physics
+from oracle import wf as owf
+from simt_util import emu_lib
+
+
+def test_two_states_energy_and_psi_ratio():
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = [wf.init(s, perturb_envelopes=0.1) for s in range(2)]
+    B = 3
+    r = torch.as_tensor(np.stack([synthetic_walkers(h, B, seed=10 + s) for s in range(2)]))[None]      # [1,S,B,N,3]
+    E, stats = loss.compute_local_energy(None, h, wf, params, r)
+    assert E.shape == (1, 2, B) and stats['hamil/E_kin'].shape == (1, 2)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    for s in range(2):
+        e_ref, _, _ = physics.batch_local_energy(owf.to_torch(params[s]), wf.spec, r[0, s], T(h.mol.coords), T(h.mol.charges),
+                                                 h.n_up, geom.F32_EPS)
+        np.testing.assert_allclose(E[0, s].numpy(), e_ref.numpy(), rtol=1e-8, atol=1e-8)
+    R = loss.compute_psi_ratio(wf, params, r)
+    assert R.shape == (1, 2, 2, B)
+    np.testing.assert_allclose(R[0, 0, 0].numpy(), 1.0, rtol=1e-12)            # psi_j / psi_j on its own samples
+    np.testing.assert_allclose(R[0, 1, 1].numpy(), 1.0, rtol=1e-12)
+    # oracle: psi_0 on the samples of state 1, log-shifted as in overlap.py:70-75
+    logs = np.zeros((2, 2, B)); signs = np.zeros((2, 2, B))
+    for i in range(2):
+        for j in range(2):
+            sg, lg = physics.batch_wave_function(owf.to_torch(params[i]), wf.spec, r[0, j], T(h.mol.coords), h.n_up, geom.F32_EPS)
+            logs[i, j], signs[i, j] = lg.numpy(), sg.numpy()
+    shifted = logs - logs.mean(axis=(1, 2))[:, None, None]
+    ref01 = signs[0, 1] * signs[1, 1] * np.exp(shifted[0, 1] - shifted[1, 1])
+    np.testing.assert_allclose(R[0, 0, 1].numpy(), ref01, rtol=1e-9)
+
+
+def test_multi_state_sampler_runs():
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = [wf.init(s, perturb_envelopes=0.1) for s in range(2)]
+    ms = MultiElectronicStateSampler(DecorrSampler(h, wf, length=2, tau=0.3), 2)
+    state = ms.init(0, params, 4)
+    state, pc, stats = ms.sample(1, state, params)
+    assert pc.r.shape == (2, 4, 4, 3) and len(stats['sampling/acceptance']) == 2
+    for s in range(2):       # the carried psi is psi of the carried positions, with that state's parameters
+        sg, lg = wf.apply(params[s], state[s]['r'])
+        np.testing.assert_allclose(lg.numpy(), state[s]['psi'].log.numpy(), rtol=1e-12, atol=1e-12)
