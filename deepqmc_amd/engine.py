@@ -133,6 +133,19 @@ class Engine:
         stats = {k: st[i] for i, k in enumerate(STAT_KEYS)}
         return (e, stats, grad) if return_grad else (e, stats)
 
+    def psi_and_grad(self, r, R=None):
+        """(sign, log|psi|, grad log|psi| [B,N,3]) in one forward-Laplacian pass -- what the reference's
+        LangevinSampler obtains with value_and_grad (electron_samplers.py:193-201)."""
+        r = self._t(r)
+        B = r.shape[0]
+        e = torch.empty(B, dtype=self.dtype, device=self.device)
+        grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device)
+        logpsi = torch.empty(B, dtype=self.dtype, device=self.device)
+        sign = torch.empty(B, dtype=torch.int32, device=self.device)
+        self._check(self.lib.dqmc_local_energy(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, e.data_ptr(), None,
+                                               grad.data_ptr(), logpsi.data_ptr(), sign.data_ptr()))
+        return sign, logpsi, grad.reshape(B, self.N, 3)
+
     # ---- sampler ----------------------------------------------------------
     def mcmc_steps(self, state: Dict[str, torch.Tensor], n_sub: int, *, max_age=None, target_acceptance=0.57,
                    seed: int = 0, noise=None, unif=None, R=None, want_stats=True, return_accept=False):

@@ -94,3 +94,68 @@ class MultiElectronicStateSampler:
 
     def update(self, state, params, R=None):
         return [self.sampler.update(state[s], params[s], R) for s in range(self.n_state)]
+
+
+def clean_force(force, r, R, charges, tau):
+    """sampling/sampling_utils.py:72-101 on device tensors (host-side torch glue; the wave-function
+    work is `Engine.psi_and_grad`)."""
+    z = r[:, :, None, :] - R[None, None, :, :]
+    z2 = (z ** 2).sum(-1)
+    idx = z2.argmin(-1)
+    zn = torch.gather(z, 2, idx[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+    z2n = torch.gather(z2, 2, idx[..., None]).squeeze(2)
+    eps = torch.finfo(force.dtype).eps
+    z_unit = zn / torch.linalg.norm(zn, dim=-1, keepdim=True)
+    f_unit = force / torch.clamp(torch.linalg.norm(force, dim=-1, keepdim=True), min=eps)
+    Z2z2 = charges[idx] ** 2 * z2n
+    a = (1 + (f_unit * z_unit).sum(-1)) / 2 + Z2z2 / (10 * (4 + Z2z2))
+    av2tau = a * (force ** 2).sum(-1) * tau
+    factor = 2 / (torch.sqrt(1 + 2 * av2tau) + 1)
+    force = factor[..., None] * force
+    norm_factor = torch.clamp(torch.sqrt(z2n) / (tau * torch.clamp(torch.linalg.norm(force, dim=-1), min=eps)), max=1.0)
+    return force * norm_factor[..., None]
+
+
+class LangevinSampler(MetropolisSampler):
+    """Metropolis-adjusted Langevin sampler (sampling/electron_samplers.py:176-232): drift =
+    cleaned grad log|psi| from one forward-Laplacian pass per proposal, Green's-function ratio in
+    the acceptance.  Propose/accept bookkeeping is torch glue on the device; psi and its gradient
+    come from the HIP engine."""
+
+    def _psi_force(self, eng, r, tau, R=None):
+        sign, log, g = eng.psi_and_grad(r, R)
+        Rt = eng.R if R is None else eng._R(R)
+        Z = torch.as_tensor(self.hamil.mol.charges, dtype=eng.dtype, device=eng.device)
+        return sign, log, clean_force(g, r, Rt, Z, tau)
+
+    def update(self, state, params, R=None):
+        eng = self.wf.engine(params)
+        sign, log, force = self._psi_force(eng, state['r'], state['tau'], R)
+        return {**state, 'psi': Psi(sign, log), 'force': force}
+
+    def sample(self, rng, state, params, R=None, noise=None, unif=None):
+        eng = self.wf.engine(params)
+        r, tau = state['r'], state['tau']
+        gen = torch.Generator(device=eng.device)
+        gen.manual_seed(int(rng))
+        stats = {}
+        for k in range(self.length):
+            xi = torch.randn(r.shape, dtype=eng.dtype, device=eng.device, generator=gen) if noise is None else eng._t(noise[k])
+            u = torch.rand(r.shape[0], dtype=eng.dtype, device=eng.device, generator=gen) if unif is None else eng._t(unif[k])
+            r_prop = r + tau * state['force'] + torch.sqrt(tau) * xi
+            sign_p, log_p, force_p = self._psi_force(eng, r_prop, tau, R)
+            log_G = ((state['force'] + force_p) * ((r - r_prop) + tau / 2 * (state['force'] - force_p))).sum(dim=(1, 2))
+            log_prob = log_G + 2 * (log_p - state['psi'].log)
+            acc = log_prob > torch.log(u)
+            if self.max_age is not None:
+                acc = acc | (state['age'] >= self.max_age)
+            acceptance = acc.to(eng.dtype).mean()
+            if self.target_acceptance is not None:
+                tau = tau / (self.target_acceptance / torch.clamp(acceptance, min=0.05))
+            sel = lambda a, b: torch.where(acc.reshape((-1,) + (1,) * (a.dim() - 1)), a, b)
+            state = {'r': sel(r_prop, r), 'psi': Psi(sel(sign_p, state['psi'].sign), sel(log_p, state['psi'].log)),
+                     'force': sel(force_p, state['force']),
+                     'age': torch.where(acc, torch.zeros_like(state['age']), state['age'] + 1), 'tau': tau}
+            r = state['r']
+            stats = {'sampling/acceptance': float(acceptance), 'sampling/tau': float(tau)}
+        return state, self.phys_conf(eng.R if R is None else R, state['r']), stats

@@ -81,3 +81,46 @@ def energy_stats(e_loc: torch.Tensor):
         'local_energy/min': float(e_loc.min()),
         'local_energy/max': float(e_loc.max()),
     }
+
+
+# ---- Langevin (MALA), reference sampling/electron_samplers.py:176-232 + sampling_utils.py:72-101 ----
+
+def clean_force(force, r, R, charges, tau):
+    """sampling_utils.py:72-101: damp the drift near nuclei (Umrigar-style crossover) and cap its
+    length so that one step cannot overshoot the nearest nucleus."""
+    z = r[:, :, None, :] - R[None, None, :, :]                         # [B,N,n_nuc,3]
+    z2 = (z ** 2).sum(-1)
+    idx = z2.argmin(-1)                                                # nearest nucleus
+    zn = torch.gather(z, 2, idx[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
+    z2n = torch.gather(z2, 2, idx[..., None]).squeeze(2)
+    eps = torch.finfo(force.dtype).eps
+    z_unit = zn / torch.linalg.norm(zn, dim=-1, keepdim=True)
+    f_unit = force / torch.clamp(torch.linalg.norm(force, dim=-1, keepdim=True), min=eps)
+    Z2z2 = charges[idx] ** 2 * z2n
+    a = (1 + (f_unit * z_unit).sum(-1)) / 2 + Z2z2 / (10 * (4 + Z2z2))
+    av2tau = a * (force ** 2).sum(-1) * tau
+    factor = 2 / (torch.sqrt(1 + 2 * av2tau) + 1)
+    force = factor[..., None] * force
+    norm_factor = torch.clamp(torch.sqrt(z2n) / (tau * torch.clamp(torch.linalg.norm(force, dim=-1), min=eps)), max=1.0)
+    return force * norm_factor[..., None]
+
+
+def langevin_step(psi_force_fn, state, R, charges, noise, unif, max_age=None, target_acceptance=0.57):
+    """One LangevinSampler.sample.  psi_force_fn(r[B,N,3]) -> (sign, log, grad log|psi| [B,N,3]).
+    `state` additionally carries 'force' (cleaned with the tau of the step that produced it)."""
+    r, tau = state['r'], state['tau']
+    r_prop = r + tau * state['force'] + math.sqrt(tau) * noise                 # :214-221
+    sign_p, log_p, g = psi_force_fn(r_prop)
+    force_p = clean_force(g, r_prop, R, charges, tau)                          # :204-208 (tau of the previous iteration)
+    log_G = ((state['force'] + force_p) * ((r - r_prop) + tau / 2 * (state['force'] - force_p))).sum(dim=(1, 2))   # :223-232
+    log_prob = log_G + 2 * (log_p - state['log'])
+    accepted = log_prob > torch.log(unif)
+    if max_age is not None:
+        accepted = accepted | (state['age'] >= max_age)
+    acceptance = accepted.to(torch.float64).sum() / accepted.shape[0]
+    new_tau = tau / (target_acceptance / max(float(acceptance), 0.05)) if target_acceptance is not None else tau
+    sel = lambda a, b: torch.where(accepted.reshape((-1,) + (1,) * (a.dim() - 1)), a, b)
+    new = {'r': sel(r_prop, r), 'sign': sel(sign_p, state['sign']), 'log': sel(log_p, state['log']),
+           'force': sel(force_p, state['force']),
+           'age': torch.where(accepted, torch.zeros_like(state['age']), state['age'] + 1), 'tau': new_tau}
+    return new, accepted, float(acceptance)

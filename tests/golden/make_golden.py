@@ -43,7 +43,7 @@ def main():
     d = np.load(f'{REF}/test_wf/test_grad_psi.npz')
     out['wf_grad_conf_coeff_w'] = d['neural_network_wave_function/~/conf_coeff:w']
     # sampler goldens (tests/test_sampling.py): initial state and state/stats after 4 sample() calls
-    for tag in ('Metropolis', 'DecorrMetropolis'):
+    for tag in ('Metropolis', 'DecorrMetropolis', 'Langevin'):
         d = np.load(f'{REF}/test_sampling/test_sampler_init_{tag}_.npz')
         for k in d.files:
             out[f'sampler_init_{tag}_{k}'] = d[k]

@@ -51,3 +51,41 @@ def test_multi_state_sampler_runs():
     for s in range(2):       # the carried psi is psi of the carried positions, with that state's parameters
         sg, lg = wf.apply(params[s], state[s]['r'])
         np.testing.assert_allclose(lg.numpy(), state[s]['psi'].log.numpy(), rtol=1e-12, atol=1e-12)
+
+
+def test_langevin_sampler_matches_oracle():
+    """LangevinSampler (HIP psi + gradient through the emulator, torch bookkeeping) vs the oracle's
+    langevin_step (itself pinned to the reference's Langevin golden) on the same noise."""
+    from deepqmc_amd.sampling import LangevinSampler
+    from oracle import sampling as osamp
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(3, perturb_envelopes=0.1)
+    B, n = 4, 2
+    smp = LangevinSampler(h, wf, tau=0.1)
+    state = smp.init(5, params, B)
+    rng = np.random.default_rng(0)
+    noise, unif = rng.standard_normal((n, B, 4, 3)), rng.random((n, B))
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    p, R, Z = owf.to_torch(params), T(h.mol.coords), T(h.mol.charges)
+
+    def psi_force(rb):
+        sg, lg, gr = [], [], []
+        for x in rb:
+            x = x.clone().requires_grad_(True)
+            s, l = owf.wave_function(p, wf.spec, x, R, h.n_up, geom.F32_EPS)
+            g, = torch.autograd.grad(l, x)
+            sg.append(s); lg.append(l.detach()); gr.append(g)
+        return torch.stack(sg), torch.stack(lg), torch.stack(gr)
+
+    s0, l0, g0 = psi_force(state['r'])
+    ost = {'r': state['r'].clone(), 'sign': s0, 'log': l0, 'force': osamp.clean_force(g0, state['r'], R, Z, 0.1),
+           'age': torch.zeros(B, dtype=torch.int64), 'tau': 0.1}
+    np.testing.assert_allclose(state['force'].numpy(), ost['force'].numpy(), rtol=1e-8, atol=1e-10)
+    for k in range(n):
+        state, _, stats = smp.sample(k, state, params, noise=noise[k:k + 1], unif=unif[k:k + 1])
+        ost, acc, a = osamp.langevin_step(psi_force, ost, R, Z, T(noise[k]), T(unif[k]))
+    np.testing.assert_array_equal(state['age'].numpy(), ost['age'].numpy())
+    np.testing.assert_allclose(state['r'].numpy(), ost['r'].numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(float(state['tau']), ost['tau'], rtol=1e-10)
+    np.testing.assert_allclose(state['psi'].log.numpy(), ost['log'].numpy(), rtol=0, atol=1e-9)
