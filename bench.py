@@ -84,6 +84,22 @@ def cpu_baseline(molname, spec_name, n_sub, budget_s=20.0):
     }
 
 
+def committed_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 counter passes (run_traffic.sh ->
+    tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, gfx950 x2 correction on
+    FETCH_SIZE).  Counters cannot be collected from inside the timed process, so the figure is the
+    one measured for the same workload by the profiling run; None if no such profile is committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*pmc_hbm_traffic*.json')), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if prof.get('workload') == workload and kernel in prof.get('kernels', {}):
+            return prof['kernels'][kernel]['hbm_bytes'], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -193,11 +209,13 @@ def main():
     lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
     total_ms = sum(v['ms'] for v in rep.values()) or 1.0
     achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
+    traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused_value'}[dom],
+                                             f'{args.molecule}/{args.ansatz}/{B}/{args.dtype}')
     roofline = {
         'bound': 'mfma', 'kernel': names[dom],
         'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
         'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-        'traffic': None,
+        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
         'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
         'share_of_kernel_time': lin['ms'] / total_ms,
         'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items()},

@@ -42,6 +42,10 @@ template <typename real> struct Vec4;   // 4 consecutive reals, naturally aligne
 template <> struct __attribute__((aligned(16))) Vec4<float> { float v[4]; };
 template <> struct __attribute__((aligned(32))) Vec4<double> { double v[4]; };
 
+template <typename real> struct Vec2;   // 2 consecutive reals, naturally aligned
+template <> struct __attribute__((aligned(8))) Vec2<float> { float v[2]; };
+template <> struct __attribute__((aligned(16))) Vec2<double> { double v[2]; };
+
 template <typename real> __device__ __forceinline__ real r_tanh(real x);
 // f32 tanh in ~15 VALU instructions (libm tanhf is ~100 and dominated the small layers of the
 // fused kernel): odd polynomial for |x| < 0.25 (truncation < 3e-9), (1 - e)/(1 + e) with

@@ -41,28 +41,36 @@ template <typename real> __device__ __forceinline__ void act_derivs(int act, rea
 
 template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
 
-// MR row blocks x NR column blocks per wave; GPW groups per wave (0: value-only rows).
-template <typename real, int MR, int NR, int GPW>
-__global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
-  constexpr int BM = 64 * MR, BN = 16 * NR, BK = 16;
-  constexpr int AS = BM + 16, BS = BStride<BN>::v;
-  constexpr int GB = GPW > 0 ? MR / GPW : 1;     // row blocks per group
-  constexpr int NBV = (BK * BN / 4 + 255) / 256; // B float4 per thread
+// MR row blocks x NR column blocks per wave; GPW groups per wave (0: value-only rows); the
+// workgroup is 4 waves in M times WN waves in N (WN = 2: 512 threads, BN = 128, so a 128-wide
+// layer reads its A rows from HBM once).  A tile in LDS is row-major with stride BK + 2: the
+// 16 rows x 2 k of a half-wave fragment read land on 32 distinct banks (18*row mod 32 is a
+// permutation of the even banks), and the staging store is two 8-byte writes per thread.
+template <typename real, int MR, int NR, int GPW, int WN>
+__global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
+  constexpr int NT = 256 * WN;
+  constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16;
+  constexpr int AS = BK + 2, BS = BStride<BN>::v;
+  constexpr int GB = GPW > 0 ? MR / GPW : 1;            // row blocks per group
+  constexpr int APT = MR / WN;                          // A float4 per thread and chunk
+  constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
+  static_assert(MR % WN == 0, "MR must be a multiple of WN");
   typedef typename Mfma<real>::acc_t acc_t;
-  __shared__ real As[BK * AS];
+  __shared__ real As[BM * AS];
   __shared__ real Bs[BK * BS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
   const int n_groups = a.B * a.nrows;            // (walker,row) groups == value-mode rows
   const int col_blk0 = blockIdx.y * BN;
 
-  // ---- per-thread A rows: MR float4 per chunk ----
-  int a_row[MR];          // row inside the tile
-  int a_g[MR], a_t[MR];   // group index (b*nrows+rr) and lane t; a_g < 0: out of range
+  // ---- per-thread A rows ----
+  int a_row[APT];         // row inside the tile
+  int a_g[APT], a_t[APT]; // group index (b*nrows+rr) and lane t; a_g < 0: out of range
   const int a_kq = tid & 3;
 #pragma unroll
-  for (int j = 0; j < MR; ++j) {
-    const int row = (tid >> 2) + 64 * j;
+  for (int j = 0; j < APT; ++j) {
+    const int row = (tid >> 2) + (NT / 4) * j;
     a_row[j] = row;
     int g, t;
     if (GPW > 0) {
@@ -86,9 +94,9 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
   int w_row0 = 0;  // first W row of the current piece
   for (int p = 0; p < a.n_pieces; ++p) {
     const LinPiece<real> pc = a.piece[p];
-    const real* a_src[MR];
+    const real* a_src[APT];
 #pragma unroll
-    for (int j = 0; j < MR; ++j) {
+    for (int j = 0; j < APT; ++j) {
       if (a_g[j] >= 0) {
         const int b = a_g[j] / a.nrows, rr = a_g[j] - b * a.nrows;
         const long srow = ((long)b * pc.rpw + pc.r0 + (pc.bcast ? 0 : rr)) * a.TP + a_t[j];
@@ -98,17 +106,17 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[MR], rb_[NBV];
+    Vec4<real> ra[APT], rb_[NBV];
     auto load_chunk = [&](int kc) {
       const int k0 = kc * BK + 4 * a_kq;
 #pragma unroll
-      for (int j = 0; j < MR; ++j) {
+      for (int j = 0; j < APT; ++j) {
         if (a_src[j] != nullptr && k0 < pc.K) ra[j] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
         else ra[j] = Vec4<real>{{0, 0, 0, 0}};
       }
 #pragma unroll
       for (int j = 0; j < NBV; ++j) {
-        const int f = tid + 256 * j;
+        const int f = tid + NT * j;
         const int k = f / (BN / 4), n4 = f % (BN / 4);
         const int kk = kc * BK + k, col = col_blk0 + 4 * n4;
         if (f < BK * BN / 4 && kk < pc.K && col < a.ldw)
@@ -121,28 +129,29 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
     for (int kc = 0; kc < n_chunks; ++kc) {
       __syncthreads();  // previous chunk's fragments have been read
 #pragma unroll
-      for (int j = 0; j < MR; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) As[(4 * a_kq + i) * AS + a_row[j]] = ra[j].v[i];
+      for (int j = 0; j < APT; ++j) {
+        Vec2<real>* dst = reinterpret_cast<Vec2<real>*>(&As[a_row[j] * AS + 4 * a_kq]);
+        dst[0] = Vec2<real>{{ra[j].v[0], ra[j].v[1]}};
+        dst[1] = Vec2<real>{{ra[j].v[2], ra[j].v[3]}};
+      }
 #pragma unroll
       for (int j = 0; j < NBV; ++j) {
-        const int f = tid + 256 * j;
+        const int f = tid + NT * j;
         if (f < BK * BN / 4) {
           const int k = f / (BN / 4), n4 = f % (BN / 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) Bs[k * BS + 4 * n4 + i] = rb_[j].v[i];
+          *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = rb_[j];
         }
       }
       __syncthreads();
       if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const int krow = kk * 4 + (lane >> 4);
+        const int kcol = kk * 4 + (lane >> 4);
         real fa[MR], fb[NR];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) fa[i] = As[krow * AS + wave * (16 * MR) + i * 16 + (lane & 15)];
+        for (int i = 0; i < MR; ++i) fa[i] = As[(wm * (16 * MR) + i * 16 + (lane & 15)) * AS + kcol];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) fb[j] = Bs[krow * BS + j * 16 + (lane & 15)];
+        for (int j = 0; j < NR; ++j) fb[j] = Bs[kcol * BS + wn * (16 * NR) + j * 16 + (lane & 15)];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -154,21 +163,22 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
 
   // ---- epilogue ----
   const int cl = lane & 15;
+  const int col_w0 = col_blk0 + wn * (16 * NR);
   if (GPW > 0) {
 #pragma unroll
     for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
-      const int g = (blockIdx.x * 4 + wave) * GPW + gj;
+      const int g = (blockIdx.x * 4 + wm) * GPW + gj;
       if (g >= n_groups) continue;   // wave-uniform
       const int b = g / a.nrows, rr = g - b * a.nrows;
       const long drow0 = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
       const long rrow0 = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-        const int col = col_blk0 + n * 16 + cl;
+        const int col = col_w0 + n * 16 + cl;
         const bool col_ok = col < a.ldw;
         real v = __shfl(acc[gj * GB][n][0], cl, 64);
         if (a.bias != nullptr && col_ok) v += a.bias[col];
-        real s_part = 0, l_part = 0;
+        real s_part = 0;
 #pragma unroll
         for (int tb = 0; tb < GB; ++tb)
 #pragma unroll
@@ -176,10 +186,8 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
             const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
             const real x = acc[gj * GB + tb][n][rg];
             if (t >= 1 && t < a.T - 1) s_part += x * x;
-            if (t == a.T - 1) l_part = x;
           }
         const real S = quad_sum<real>(s_part);
-        (void)l_part;
         real y, d1, d2;
         act_derivs<real>(a.act, v, y, d1, d2);
 #pragma unroll
@@ -205,14 +213,14 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int m = blockIdx.x * BM + wave * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
+        const int m = blockIdx.x * BM + wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
         if (m >= n_groups) continue;
         const int b = m / a.nrows, rr = m - b * a.nrows;
         const long drow = (long)b * a.rpw_dst + a.r0_dst + rr;
         const long rrow = a.res ? (long)b * a.rpw_res + a.r0_res + rr : 0;
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-          const int col = col_blk0 + n * 16 + cl;
+          const int col = col_w0 + n * 16 + cl;
           if (col >= a.ldw) continue;
           real v = acc[i][n][rg];
           if (a.bias != nullptr) v += a.bias[col];
@@ -225,19 +233,21 @@ __global__ void __launch_bounds__(256) k_linear(const LinArgs<real> a) {
   }
 }
 
-template <typename real, int MR, int NR, int GPW> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
-  constexpr int BM = 64 * MR, BN = 16 * NR;
+template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
+  constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   const long n_groups = (long)a.B * a.nrows;
   const unsigned gx = GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW>), dim3(gx, gy), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
 }
 
 template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, const LinArgs<real>& a) {
   constexpr int NR_MAX = sizeof(real) == 8 ? 2 : 4;   // accumulator registers: MR*NR*4 per lane
-  if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW>(st, a);
-  else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW>(st, a);
-  else launch_cfg<real, MR, 1, GPW>(st, a);
+  constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0 && MR <= 4;
+  if (a.ldw > 64 && WIDE) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, (WIDE ? 2 : 1)>(st, a);
+  else if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, 1>(st, a);
+  else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW, 1>(st, a);
+  else launch_cfg<real, MR, 1, GPW, 1>(st, a);
 }
 
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
