@@ -73,6 +73,26 @@ template <typename real> __device__ __forceinline__ real wave_sum(real v) {
   return v;
 }
 
+// ---- Philox4x32-10 (Salmon et al. 2011), counter-based: (seed, stream, index) -> 4 x u32 ----
+__device__ __forceinline__ void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32(uint64_t seed, uint64_t stream, uint64_t idx, uint32_t out[4]) {
+  uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+__device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // [0,1) with 53 bits
+  return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // Lane-t value of the pair features [rho, d_x, d_y, d_z] (optionally * log1p(rho)/rho) of the
 // difference d = r_recv - r_send (send < 0: a nucleus, no dependence), rho = sqrt(eps + d.d).
 // Reference: gnn/edge_features.py:21-123 + utils.py:79-85; derivative lanes per SURVEY.md

@@ -50,6 +50,8 @@ struct dqmc_ctx {
   virtual int mcmc(void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R, int B, int n_sub,
                    int max_age, double target, uint64_t seed, const void* noise, const void* unif, uint8_t* accept_out,
                    double* stats7) = 0;
+  virtual int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) = 0;
+  virtual int ecp_rotation(uint64_t seed, const void* phi) = 0;
   virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
@@ -130,8 +132,22 @@ struct Engine : dqmc_ctx {
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
+  // effective core potential (dqmc_set_ecp): local terms for k_final, non-local channels per nucleus
+  double* d_ecp_loc = nullptr;
+  double* d_ecp_nl = nullptr;
+  int32_t* d_ecp_nuc = nullptr;
+  int ecp_nt_loc = 0, ecp_n_nl = 0, ecp_L = 0, ecp_nt_nl = 0;
+  uint64_t ecp_seed = 0;
+  const void* ecp_phi = nullptr;
+  char* d_ecp = nullptr;        // quadrature walkers + their psi + psi of the walkers themselves
+  size_t ecp_bytes = 0;
+  size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
 
   ~Engine() override {
+    if (d_ecp_loc) (void)hipFree(d_ecp_loc);
+    if (d_ecp_nl) (void)hipFree(d_ecp_nl);
+    if (d_ecp_nuc) (void)hipFree(d_ecp_nuc);
+    if (d_ecp) (void)hipFree(d_ecp);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (d_w) (void)hipFree(d_w);
     if (d_it) (void)hipFree(d_it);
@@ -246,6 +262,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ = value; return DQMC_OK; }
+    if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
       fused_dbg = value;
@@ -598,6 +615,7 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_FINAL: {
           dqmc::FinalArgs a{};
           a.r = r; a.R = R; a.charges = d_charges;
+          a.ecp_loc = d_ecp_loc; a.ecp_nt = ecp_nt_loc;
           a.logdet = reinterpret_cast<double*>(d_ws + off_logdet);
           a.sign_k = reinterpret_cast<int32_t*>(d_ws + off_signk);
           a.jastrow = i[0] >= 0 ? bptr(i[0]) : nullptr;
@@ -627,7 +645,89 @@ struct Engine : dqmc_ctx {
   }
   int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
                    int32_t* sign) override {
-    return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, (real*)e_loc, (real*)stats, (real*)grad);
+    if (ecp_n_nl == 0)
+      return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, (real*)e_loc, (real*)stats, (real*)grad);
+    return local_energy_ecp((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
+  }
+
+  // Effective core potentials: host tables (ecp/gaussian_type_ecp.py:32-93 layout) -> device.
+  //   loc[n_nuc][3][2][n_t_loc]  r^-1 / r^0 / r^1 terms: [.,term,0,.] exponents, [.,term,1,.] coefficients
+  //   nl [n_nuc][n_l][2][n_t_nl] channels l = 0..n_l-1; nuclei whose block is all zero have no non-local part
+  int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) override {
+    if (n_t_loc < 0 || n_l < 0 || n_t_nl < 0) return fail(DQMC_E_ARG, "negative ECP table size");
+    HIP_TRY(hipStreamSynchronize(st));
+    if (d_ecp_loc) { HIP_TRY(hipFree(d_ecp_loc)); d_ecp_loc = nullptr; }
+    if (d_ecp_nl) { HIP_TRY(hipFree(d_ecp_nl)); d_ecp_nl = nullptr; }
+    if (d_ecp_nuc) { HIP_TRY(hipFree(d_ecp_nuc)); d_ecp_nuc = nullptr; }
+    ecp_nt_loc = ecp_n_nl = ecp_L = ecp_nt_nl = 0;
+    if (loc && n_t_loc > 0) {
+      const size_t n = (size_t)sys.n_nuc * 6 * n_t_loc;
+      HIP_TRY(hipMalloc((void**)&d_ecp_loc, sizeof(double) * n));
+      HIP_TRY(hipMemcpy(d_ecp_loc, loc, sizeof(double) * n, hipMemcpyHostToDevice));
+      ecp_nt_loc = n_t_loc;
+    }
+    if (nl && n_l > 0 && n_t_nl > 0) {
+      const size_t blk = (size_t)n_l * 2 * n_t_nl;
+      std::vector<int32_t> nuc;
+      std::vector<double> compact;
+      for (int a = 0; a < sys.n_nuc; ++a) {          // gaussian_type_ecp.py:121 (nuc_with_nl_pot)
+        bool any = false;
+        for (size_t k = 0; k < blk; ++k) any = any || nl[a * blk + k] != 0.0;
+        if (!any) continue;
+        nuc.push_back(a);
+        compact.insert(compact.end(), nl + a * blk, nl + (a + 1) * blk);
+      }
+      if (!nuc.empty()) {
+        HIP_TRY(hipMalloc((void**)&d_ecp_nl, sizeof(double) * compact.size()));
+        HIP_TRY(hipMalloc((void**)&d_ecp_nuc, sizeof(int32_t) * nuc.size()));
+        HIP_TRY(hipMemcpy(d_ecp_nl, compact.data(), sizeof(double) * compact.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_ecp_nuc, nuc.data(), sizeof(int32_t) * nuc.size(), hipMemcpyHostToDevice));
+        ecp_n_nl = (int)nuc.size(); ecp_L = n_l; ecp_nt_nl = n_t_nl;
+      }
+    }
+    return DQMC_OK;
+  }
+  int ecp_rotation(uint64_t seed, const void* phi) override { ecp_seed = seed; ecp_phi = phi; return DQMC_OK; }
+
+  // E_loc with the non-local ECP term: the Laplacian pass, then 12 N n_nl value-only psi evaluations per
+  // walker in batches of <= ecp_max_cfg quadrature walkers (gaussian_type_ecp.py:161-255).
+  int local_energy_ecp(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi,
+                       int32_t* sign) {
+    const size_t per_walker = (size_t)ecp_n_nl * N * 12;
+    int nbw = (int)(ecp_max_cfg / per_walker);
+    nbw = nbw < 1 ? 1 : (nbw > B ? B : nbw);
+    const size_t n_cfg = (size_t)nbw * per_walker;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_rq = 0, o_lq = o_rq + al(sizeof(real) * n_cfg * N * 3), o_sq = o_lq + al(sizeof(real) * n_cfg),
+                 o_l0 = o_sq + al(sizeof(int32_t) * n_cfg), o_s0 = o_l0 + al(sizeof(real) * B),
+                 tot = o_s0 + al(sizeof(int32_t) * B);
+    if (tot > ecp_bytes) {
+      if (d_ecp) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ecp)); d_ecp = nullptr; ecp_bytes = 0; }
+      hipError_t e = hipMalloc((void**)&d_ecp, tot);
+      if (e != hipSuccess) return fail(DQMC_E_NOMEM, "ECP scratch of " + std::to_string(tot) + " bytes: " + hipGetErrorString(e));
+      ecp_bytes = tot;
+    }
+    real* rq = (real*)(d_ecp + o_rq); real* lq = (real*)(d_ecp + o_lq); int32_t* sq = (int32_t*)(d_ecp + o_sq);
+    real* l0 = logpsi ? logpsi : (real*)(d_ecp + o_l0);
+    int32_t* s0 = sign ? sign : (int32_t*)(d_ecp + o_s0);
+    int rc = run(r, R, B, true, l0, s0, e_loc, stats, grad);
+    if (rc) return rc;
+    dqmc::EcpArgs a{};
+    a.r = r; a.R = R; a.nl_nuc = d_ecp_nuc; a.nl = d_ecp_nl; a.phi = ecp_phi; a.seed = ecp_seed;
+    a.B = B; a.N = N; a.n_nl = ecp_n_nl; a.L = ecp_L; a.n_t = ecp_nt_nl;
+    for (int b0 = 0; b0 < B; b0 += nbw) {
+      a.b0 = b0; a.nb = (B - b0) < nbw ? (B - b0) : nbw;
+      t_begin("ecp", 0);
+      dqmc::launch_ecp_points<real>(st, a, rq);
+      t_end();
+      rc = run(rq, R, (int)((size_t)a.nb * per_walker), false, lq, sq, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      t_begin("ecp", 0);
+      dqmc::launch_ecp_reduce<real>(st, a, lq, sq, l0, s0, e_loc, stats, (real*)nullptr);
+      t_end();
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
   }
 
   int mcmc(void* r_, void* logpsi_, int32_t* sign, int32_t* age, void* tau_, const void* R_, int B, int n_sub,
@@ -777,6 +877,14 @@ int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t
   if (!ctx || !r || !logpsi || !sign || !age || !tau || !R) return fail(DQMC_E_ARG, "null argument");
   return ctx->mcmc(r, logpsi, sign, age, tau, R, B, n_sub, max_age, target_acceptance, seed, noise, unif, accept_out,
                    stats7_host);
+}
+int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l, int n_terms_nl, const double* nl_host) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  return ctx->set_ecp(n_terms_loc, loc_host, n_l, n_terms_nl, nl_host);
+}
+int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  return ctx->ecp_rotation(seed, phi);
 }
 int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, double* out7_host) {
   if (!ctx || !e_loc || !out7_host) return fail(DQMC_E_ARG, "null argument");

@@ -108,7 +108,9 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
 struct FinalArgs {
   const void* r;          // real[B][N][3]
   const void* R;          // real[n_nuc][3]
-  const double* charges;  // device double[n_nuc]
+  const double* charges;  // device double[n_nuc] (valence charges Z_eff when an ECP is set)
+  const double* ecp_loc;  // device double[n_nuc][3][2][ecp_nt] local ECP terms, or nullptr
+  int ecp_nt;
   const double* logdet;   // [B][K][TP]
   const int32_t* sign_k;  // [B][K]
   const void* jastrow;    // real[B][1][TP][jas_width] or nullptr
@@ -128,6 +130,22 @@ struct FinalArgs {
   void* grad;     // real[B][3N]
 };
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a);
+
+// ---- kernels_ecp.hip ----
+struct EcpArgs {
+  const void* r;           // real[B][N][3], all walkers
+  const void* R;           // real[n_nuc][3]
+  const int32_t* nl_nuc;   // device [n_nl]: nuclei with a non-local part
+  const double* nl;        // device [n_nl][L][2][n_t]: exponents ([.,l,0,.]) and coefficients ([.,l,1,.])
+  const void* phi;         // real[B][n_nl][N] rotation angles, or nullptr: Philox(seed)
+  uint64_t seed;
+  int B, N, n_nl, L, n_t;
+  int b0, nb;              // walker chunk of this launch
+};
+template <typename real> void launch_ecp_points(hipStream_t st, const EcpArgs& a, real* rq);
+template <typename real>
+void launch_ecp_reduce(hipStream_t st, const EcpArgs& a, const real* logq, const int32_t* signq, const real* log0,
+                       const int32_t* sign0, real* e_loc, real* stats, real* v_nl_out);
 
 // ---- kernels_mcmc.hip ----
 template <typename real>

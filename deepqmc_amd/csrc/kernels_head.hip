@@ -361,10 +361,19 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
     for (int n = 0; n < a.n_nuc; ++n) {
       double d2 = 0.0;
       for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)R[n * 3 + c]; d2 += d * d; }
-      v_loc -= a.charges[n] / sqrt(d2);                     // reference physics.py:131-133 (plain norm)
+      const double rn = sqrt(d2);
+      v_loc -= a.charges[n] / rn;                           // reference physics.py:131-133 (plain norm)
+      if (a.ecp_loc) {                                      // ecp/gaussian_type_ecp.py:127-159: r^-1, r^0, r^1 Gaussians
+        const double* p = a.ecp_loc + (long)n * 6 * a.ecp_nt;
+        for (int t = 0; t < a.ecp_nt; ++t) {
+          v_loc += p[1 * a.ecp_nt + t] / rn * exp(-p[0 * a.ecp_nt + t] * d2);
+          v_loc += p[3 * a.ecp_nt + t] * exp(-p[2 * a.ecp_nt + t] * d2);
+          v_loc += p[5 * a.ecp_nt + t] * rn * exp(-p[4 * a.ecp_nt + t] * d2);
+        }
+      }
     }
   const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
-  const double e_loc = e_kin + v_loc + v_el + a.e_nuc;      // reference hamil.py:172 (V_nl = 0)
+  const double e_loc = e_kin + v_loc + v_el + a.e_nuc;      // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.stats) {
     real* s = reinterpret_cast<real*>(a.stats);

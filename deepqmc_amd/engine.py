@@ -70,6 +70,12 @@ class Engine:
                                   it.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), p.itable.size)
         self._ctx = ctx
         self._check(rc)
+        self._ecp_phi = None
+        if getattr(hamil, 'pot', None) is not None:     # Gaussian-type ECP tables -> device
+            pot = hamil.pot
+            dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a.size else None
+            self._check(self.lib.dqmc_set_ecp(self._ctx, pot.loc_params.shape[3], dp(pot.loc_params),
+                                              pot.nl_params.shape[1], pot.nl_params.shape[3], dp(pot.nl_params)))
         self.R = torch.as_tensor(hamil.mol.coords, dtype=dtype, device=self.device).contiguous()
 
     # ------------------------------------------------------------------
@@ -117,7 +123,10 @@ class Engine:
         return sign, logpsi
 
     # ---- hamil.local_energy ---------------------------------------------
-    def local_energy(self, phys_conf, rng=None, return_grad=False):
+    def local_energy(self, phys_conf, rng=None, return_grad=False, ecp_phi=None):
+        """`rng` (an int seed or None) keys the random quadrature rotation of the non-local ECP term
+        (hamil.py:166, gaussian_type_ecp.py:221); `ecp_phi` [B, n_ecp_nl, N] overrides it with explicit
+        angles (parity tests).  Both are ignored without an ECP."""
         if isinstance(phys_conf, PhysicalConfiguration):
             r, R = phys_conf.r, phys_conf.R
         else:
@@ -125,6 +134,11 @@ class Engine:
         r = self._t(r)
         B = r.shape[0]
         assert r.shape[1:] == (self.N, 3)
+        if getattr(self.hamil, 'pot', None) is not None:
+            self._ecp_phi = self._t(ecp_phi) if ecp_phi is not None else None      # keep alive during the call
+            seed = int(rng) & (2 ** 64 - 1) if isinstance(rng, (int, np.integer)) else 0
+            self._check(self.lib.dqmc_ecp_rotation(self._ctx, seed,
+                                                   self._ecp_phi.data_ptr() if self._ecp_phi is not None else None))
         e = torch.empty(B, dtype=self.dtype, device=self.device)
         st = torch.empty(6, B, dtype=self.dtype, device=self.device)
         grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device) if return_grad else None

@@ -33,12 +33,13 @@ def get_shell(z) -> int:
 
 
 class MolecularHamiltonian:
-    """hamil.py:70-154.  Only the all-electron Coulomb potential is available in this
-    round (`ecp_type=None`); requesting an ECP raises NotImplementedError (the
-    coefficient tables live in pyscf, which is absent -- SURVEY.md section 8c)."""
+    """hamil.py:70-154.  `ecp_type` selects Gaussian-type ECPs as in the reference; their
+    coefficient tables come from `ecp_tables` (pyscf ECP format, see deepqmc_amd/ecp.py) or, when
+    pyscf is importable, from pyscf exactly as in the reference.  Pseudo-Hamiltonians
+    (`'PH'` types, ecp/pseudo_hamiltonian.py) are not built."""
 
     def __init__(self, *, mol: Molecule, ecp_type: Optional[str] = None,
-                 ecp_mask=None, elec_std: float = 1.0):
+                 ecp_mask=None, elec_std: float = 1.0, ecp_tables=None):
         self.mol = mol
         self.elec_std = elec_std
         self.ecp_type = ecp_type
@@ -48,10 +49,17 @@ class MolecularHamiltonian:
             ecp_mask = list(mol.charges > 2)               # hamil.py:122-124
         assert len(ecp_mask) == len(mol.charges), "Incompatible shape of 'ecp_mask'!"
         self.ecp_mask = np.asarray(ecp_mask, bool)
-        if self.ecp_mask.any():
-            raise NotImplementedError(
-                'effective core potentials are not part of this round (pyscf tables absent)')
-        self.ns_valence = np.asarray(mol.charges, np.float64)   # physics.py:127-129
+        self.pot = None                                         # GaussianTypeECP or None (bare Coulomb)
+        if self.ecp_mask.any():                                 # hamil.py:130-138
+            assert self.ecp_type is not None, 'ECP type must be specified if ECPs are used.'
+            if 'PH' in str(self.ecp_type):
+                raise NotImplementedError('pseudo-Hamiltonian ECPs (ecp/pseudo_hamiltonian.py) are not built')
+            from .ecp import GaussianTypeECP
+            self.pot = (GaussianTypeECP.from_tables(mol.charges, self.ecp_mask, ecp_tables) if ecp_tables is not None
+                        else GaussianTypeECP.from_pyscf(mol.charges, self.ecp_type, self.ecp_mask))
+            self.ns_valence = self.pot.ns_valence
+        else:
+            self.ns_valence = np.asarray(mol.charges, np.float64)   # physics.py:127-129
         n_elec = int(sum(self.ns_valence) - mol.charge)         # hamil.py:142
         assert not (n_elec + mol.spin) % 2
         assert n_elec > 1, 'The system must contain at least two active electrons.'

@@ -132,7 +132,7 @@ class _Builder:
 
     # -- allocation helpers --
     def buf(self, name, rows, width):
-        self.bufs.append((rows, pad4(width)))
+        self.bufs.append((max(rows, 1), pad4(width)))     # an empty edge segment (e.g. one electron per spin) keeps a dummy row
         self.names[name] = len(self.bufs) - 1
         return len(self.bufs) - 1
 
@@ -181,6 +181,8 @@ class _Builder:
             i += list(p)
         i += [0] * (17 - len(i))
         i += [dst, dst_r0, dst_col0, nrows, nout, w_off, b_off, ACT[act], res, res_r0, int(res_scale != 1.0)]
+        if nrows == 0:          # empty segment: the weights stay in the buffer (parameter order), no op
+            return nout
         self.ops.append(Op(OP_LINEAR, i, [0, 0, 0, 0], note or module))
         self.flops += 2.0 * nrows * sum(p[2] for p in pieces) * nout
         return nout

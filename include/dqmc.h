@@ -142,6 +142,24 @@ int dqmc_wf_eval(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logps
 int dqmc_local_energy(dqmc_ctx* ctx, const void* r, const void* R, int B, void* e_loc,
                       void* stats, void* grad, void* logpsi, int32_t* sign);
 
+/* Gaussian-type effective core potential (reference ecp/gaussian_type_ecp.py:32-93 table layout,
+ * :127-159 local part, :161-255 non-local part; replaces GaussianTypeECP.__init__'s pyscf lookup by
+ * caller-supplied tables).  The `charges_host` given to dqmc_create must then be the valence charges
+ * (ns_valence) and dqmc_system.e_nuc the repulsion of those.
+ *   loc_host: double[n_nuc][3][2][n_terms_loc] -- terms r^-1, r^0, r^1; [.,term,0,.] exponents alpha,
+ *             [.,term,1,.] coefficients beta; zero padded (all-zero = no ECP on that nucleus); may be NULL.
+ *   nl_host:  double[n_nuc][n_l][2][n_terms_nl] -- channel l: V_l(r) = sum_k beta_lk exp(-alpha_lk r^2);
+ *             nuclei whose block is all zero have no non-local part; may be NULL.
+ * Afterwards dqmc_local_energy adds the local terms to V_loc and V_nl (12-point icosahedron quadrature,
+ * 12 N n_ecp value-only psi evaluations per walker) to E_loc and stats[3]. */
+int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l, int n_terms_nl,
+                 const double* nl_host);
+/* Random rotation of the quadrature about the electron-nucleus axis for the following
+ * dqmc_local_energy calls (ecp_utils.py:55: uniform in [0, pi/5) per (nucleus, electron); the reference
+ * keys it by fold_in(fold_in(rng, j), i)).  phi: device real[B][n_ecp_nl][N] angles, or NULL to draw them
+ * from Philox4x32-10 keyed by (seed, nucleus, walker, electron). */
+int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi);
+
 /* n_sub Metropolis sub-steps, in place on the sampler state
  * (sampling/electron_samplers.py:102-138,347-357).
  *   r real[B][N][3], logpsi real[B], sign int32[B], age int32[B], tau real[1] (device).

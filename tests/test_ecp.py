@@ -1,0 +1,116 @@
+"""Gaussian-type ECPs (reference ecp/gaussian_type_ecp.py, ecp/ecp_utils.py): quadrature properties of the
+oracle restatement, the pyscf-format table parser, and the HIP path (through the SIMT emulator, float64)
+against the oracle on the same walkers and the same rotation angles.  The coefficient tables are synthetic
+(pyscf's are not available offline -- oracle/ecp.py header)."""
+import math
+
+import numpy as np
+import torch
+
+from deepqmc_amd import MolecularHamiltonian, Molecule
+from deepqmc_amd.ecp import GaussianTypeECP
+from deepqmc_amd.sampling import synthetic_walkers
+from deepqmc_amd.wf import NeuralNetworkWaveFunction
+from oracle import ecp as oecp
+from oracle import geom, physics
+from oracle import wf as owf
+from simt_util import emu_lib
+
+# pyscf ECP format: [n_core, [[-1, [r^-2, r^-1, r^0, r^1 terms]], [0, [.., .., r^0 terms]], [1, ...]]]
+TABLES = {
+    'Li': [2, [[-1, [[], [[5.4104, 1.0]], [[4.6015, -4.6015]], [[2.7052, 5.4104]]]],
+               [0, [[], [], [[1.3302, 6.7529], [0.9, -0.8]]]],
+               [1, [[], [], [[1.25, 0.45]]]]]],
+    'H': [0, [[-1, [[], [[21.24, 1.0]], [[21.78, -10.85]], [[21.24, 21.24]]]],
+              [0, [[], [], [[1.0, 0.0]]]]]],
+}
+
+
+def test_icosahedron_quadrature():
+    pts, th = oecp.unit_icosahedron()
+    assert pts.shape == (12, 3)
+    np.testing.assert_allclose(np.linalg.norm(pts, axis=-1), 1.0, atol=1e-15)
+    # exact for spherical polynomials up to degree 5: <z^2> = 1/3, <x^4> = 1/5, <x^2 y^2> = 1/15, odd -> 0
+    np.testing.assert_allclose((pts[:, 2] ** 2).mean(), 1 / 3, atol=1e-14)
+    np.testing.assert_allclose((pts[:, 0] ** 4).mean(), 1 / 5, atol=1e-14)
+    np.testing.assert_allclose((pts[:, 0] ** 2 * pts[:, 1] ** 2).mean(), 1 / 15, atol=1e-14)
+    np.testing.assert_allclose((pts[:, 0] ** 3 * pts[:, 2] ** 2).mean(), 0.0, atol=1e-14)
+    # Legendre orthogonality under the rule (what makes the l-projection work)
+    P = oecp.legendre_table(3, th)
+    gram = P.T @ P / 12
+    np.testing.assert_allclose(gram, np.diag([1, 1 / 3, 1 / 5]), atol=1e-14)
+    # the first vertex is the electron itself, every vertex keeps the electron-nucleus distance
+    r_i, R_a = torch.tensor([0.3, -1.1, 0.7], dtype=torch.float64), torch.tensor([0.1, 0.2, -0.4], dtype=torch.float64)
+    q = oecp.quadrature_points(r_i, R_a, torch.tensor(0.37, dtype=torch.float64), torch.as_tensor(pts))
+    np.testing.assert_allclose(q[0].numpy(), r_i.numpy(), atol=1e-14)
+    np.testing.assert_allclose(torch.linalg.norm(q - R_a, dim=-1).numpy(), float(torch.linalg.norm(r_i - R_a)), rtol=1e-14)
+    np.testing.assert_allclose(q[1].numpy(), (2 * R_a - r_i).numpy(), atol=1e-14)     # antipode
+
+
+def test_table_parser_and_valence_counts():
+    mol = Molecule.from_name('LiH')
+    pot = GaussianTypeECP.from_tables(mol.charges, [True, False], TABLES)
+    np.testing.assert_array_equal(pot.ns_valence, [1.0, 1.0])
+    assert pot.loc_params.shape == (2, 3, 2, 1) and pot.nl_params.shape == (2, 2, 2, 2)
+    np.testing.assert_allclose(pot.loc_params[0, :, 0, 0], [5.4104, 4.6015, 2.7052])     # exponents r^-1, r^0, r^1
+    np.testing.assert_allclose(pot.loc_params[0, :, 1, 0], [1.0, -4.6015, 5.4104])
+    np.testing.assert_allclose(pot.nl_params[0, 0], [[1.3302, 0.9], [6.7529, -0.8]])
+    np.testing.assert_allclose(pot.nl_params[0, 1], [[1.25, 0.0], [0.45, 0.0]])
+    assert not pot.loc_params[1].any() and not pot.nl_params[1].any()
+    np.testing.assert_array_equal(pot.nuc_with_nl_pot, [0])
+    h = MolecularHamiltonian(mol=mol, ecp_type='synthetic', ecp_tables=TABLES)        # default mask: charges > 2
+    assert (h.n_up, h.n_down) == (1, 1) and list(h.ecp_mask) == [True, False]           # tests/test_hamil PP golden: 1, 1
+    assert h.mol_ecp_shells == [1, 0]
+
+
+def test_s_wave_sees_only_l0():
+    """psi depending on |r_i - R_a| only: every quadrature point has ratio 1, so V_nl = sum_i V_0(r_i)."""
+    R = torch.tensor([[0.0, 0.0, 0.0]], dtype=torch.float64)
+    r = torch.tensor([[0.4, 0.1, -0.3], [-0.2, 0.9, 0.5]], dtype=torch.float64)
+    nl = torch.tensor([[[[1.3, 0.9], [2.0, -0.8]], [[1.25, 0.0], [0.45, 0.0]]]], dtype=torch.float64)
+    psi = lambda rr: (torch.ones(rr.shape[0], dtype=torch.float64), -(rr.norm(dim=-1) ** 2).sum(-1))
+    v = oecp.nonloc_potential(r, R, nl, psi, torch.tensor([[0.1, 0.5]], dtype=torch.float64))
+    d2 = (r ** 2).sum(-1)
+    expect = (2.0 * torch.exp(-1.3 * d2) - 0.8 * torch.exp(-0.9 * d2)).sum()
+    np.testing.assert_allclose(float(v), float(expect), rtol=1e-13)
+
+
+def _hip_vs_oracle(mask, tables, B=2, seed=5):
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol, ecp_type='synthetic', ecp_mask=mask, ecp_tables=tables)
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(0, perturb_envelopes=0.1)
+    N = h.n_elec
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=seed))
+    n_nl = len(h.pot.nuc_with_nl_pot)
+    phi = torch.as_tensor(np.random.default_rng(1).uniform(0, math.pi / 5, (B, n_nl, N)))
+    e, stats = wf.engine(params).local_energy(r, ecp_phi=phi)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    R, p = T(mol.coords), owf.to_torch(params)
+    loc, nl, zv = T(h.pot.loc_params), T(h.pot.nl_params), T(h.ns_valence)
+    e_ref, st_ref, _ = physics.batch_local_energy(p, wf.spec, r, R, zv, h.n_up, geom.F32_EPS)
+    psi = lambda rr: physics.batch_wave_function(p, wf.spec, rr, R, h.n_up, geom.F32_EPS)
+    for b in range(B):
+        v_loc = oecp.local_potential(r[b], R, zv, loc, h.ecp_mask)
+        v_nl = oecp.nonloc_potential(r[b], R, nl, psi, phi[b])
+        np.testing.assert_allclose(float(stats['hamil/V_loc'][b]), float(v_loc), rtol=1e-11)
+        np.testing.assert_allclose(float(stats['hamil/V_nl'][b]), float(v_nl), rtol=1e-8, atol=1e-10)
+        e_b = float(e_ref[b]) - float(st_ref['hamil/V_loc'][b]) + float(v_loc) + float(v_nl)
+        np.testing.assert_allclose(float(e[b]), e_b, rtol=1e-8, atol=1e-8)
+    return h, stats
+
+
+def test_hip_ecp_matches_oracle_valence_only():
+    """Li core removed (n_core = 2): 2 valence electrons, non-local s and p channels on Li."""
+    h, stats = _hip_vs_oracle([True, False], TABLES)
+    assert h.n_elec == 2 and float(stats['hamil/V_nl'].abs().max()) > 1e-6
+
+
+def test_hip_ecp_matches_oracle_two_centres():
+    """ECP tables on both nuclei (Li with n_core = 0 keeps 4 electrons; H local-only plus a zero s channel):
+    exercises the compaction to nuclei with a non-local part and the per-nucleus loop."""
+    t = dict(TABLES)
+    t['Li'] = [0, TABLES['Li'][1]]
+    t['H'] = [0, [TABLES['H'][1][0], [0, [[], [], [[0.7, 0.3]]]]]]
+    h, stats = _hip_vs_oracle([True, True], t, B=1)
+    assert h.n_elec == 4 and len(h.pot.nuc_with_nl_pot) == 2
