@@ -223,7 +223,8 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_EDGE_SUM: ok = okb(i[0]) && okb(i[2]) && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
         case DQMC_OP_ROW_SUM: ok = okb(i[0]) && okb(i[1]) && bufs[i[1]].rows == 1 && bufs[i[0]].width == bufs[i[1]].width; break;
         case DQMC_OP_ORBITALS: {
-          const size_t ne = (size_t)sys.n_det * N * sys.n_nuc;
+          if (i[6] < 0) { ok = false; break; }
+          const size_t ne = (size_t)sys.n_det * N * sys.n_nuc * (i[6] > 0 ? i[6] : 1);
           ok = okb(i[0]) && okb(i[1]) && bufs[i[0]].rows == N && bufs[i[0]].width >= sys.n_det * N && bufs[i[1]].rows == sys.n_det && bufs[i[1]].width >= N * N;
           for (int q = 2; ok && q < 6; ++q) ok = i[q] >= 0 && (size_t)i[q] + ne <= n_weights;
           break;
@@ -234,7 +235,9 @@ struct Engine : dqmc_ctx {
           ok = i[4] >= 1 && i[5] >= 1;
           for (int q = 0; ok && q < 4; ++q) ok = okb(i[q]) && bufs[i[q]].rows == N && bufs[i[q]].width >= i[4] * i[5];
           if (ok) ok = bufs[i[0]].width == bufs[i[1]].width && bufs[i[0]].width == bufs[i[2]].width && bufs[i[0]].width == bufs[i[3]].width;
-          if (ok && dqmc::attention_lds_bytes<real>(N, i[5]) > (size_t)160 * 1024)
+          if (ok) ok = i[6] >= 0 && (i[6] == 0 || (i[7] >= 0 && i[8] >= 0 && (size_t)i[7] + (size_t)i[6] * i[4] * i[5] <= n_weights &&
+                                                   (size_t)i[8] + (size_t)i[6] * i[4] * i[5] <= n_weights));
+          if (ok && dqmc::attention_lds_bytes<real>(N, i[5], i[6]) > (size_t)160 * 1024)
             return fail(DQMC_E_UNSUPPORTED, "attention tile set (N, head_dim) exceeds the 160 KiB LDS");
           break;
         default: ok = false;
@@ -588,9 +591,9 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_ATTENTION: {
           // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
-          t_begin("attention", 2.0 * B * i[4] * (double)N * N * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
+          t_begin("attention", 2.0 * B * i[4] * (double)N * (N + i[6]) * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
           const int rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
-                                                        i[4], i[5], B, li);
+                                                        i[4], i[5], B, li, i[6], d_w + i[7], d_w + i[8]);
           t_end();
           if (rc2) return fail(DQMC_E_HIP, "attention launch failed");
           break;
@@ -603,7 +606,8 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_ORBITALS:
           t_begin("orbitals", 0);
           dqmc::launch_orbitals<real>(st, r, R, bptr(i[0]), bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, d_w + i[2], d_w + i[3],
-                                      d_w + i[4], d_w + i[5], B, sys.n_up, sys.n_nuc, sys.n_det, li, sys.norm_eps);
+                                      d_w + i[4], d_w + i[5], B, sys.n_up, sys.n_nuc, i[6] > 0 ? i[6] : 1, sys.n_det, li,
+                                      sys.norm_eps);
           t_end();
           break;
         case DQMC_OP_SLOGDET:

@@ -439,13 +439,15 @@ __device__ __forceinline__ void fused_body(const FusedArgs<real>& a) {
           fdk.divmod(e, q, kmu);
           fdN.divmod(q, wl, el);
           fdN.divmod(kmu, kd, mu);
-          const real* pi = a.w + (el < n_up ? i[2] : i[3]) + kmu * n_nuc;
-          const real* ze = a.w + (el < n_up ? i[4] : i[5]) + kmu * n_nuc;
+          const int n_env = i[6] > 0 ? i[6] : 1;          // envelopes per nucleus (kernels_head.hip: k_orbitals)
+          const real* pi = a.w + (el < n_up ? i[2] : i[3]) + kmu * n_nuc * n_env;
+          const real* ze = a.w + (el < n_up ? i[4] : i[5]) + kmu * n_nuc * n_env;
           double e0 = 0;
           for (int n = 0; n < n_nuc; ++n) {
             double d2 = a.eps;
             for (int c = 0; c < 3; ++c) { const double d = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += d * d; }
-            e0 += (double)pi[n] * exp(-fabs((double)ze[n]) * sqrt(d2));
+            const double rho = sqrt(d2);
+            for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
           }
           const double b0 = (double)smem[bf.lds + (wl * N + el) * bf.stride + kmu];
           orb_g[(wl * K + kd) * orb.width + el * N + mu] = (real)(e0 * b0);

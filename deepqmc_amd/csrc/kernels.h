@@ -94,14 +94,14 @@ template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 // returns 0, or -1 if the (N, head_dim) tile set does not fit the 160 KiB LDS, -2 on a HIP error
 template <typename real>
 int launch_attention(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd,
-                     int B, LaneInfo li);
-template <typename real> size_t attention_lds_bytes(int N, int hd);
+                     int B, LaneInfo li, int n_const, const real* k_const, const real* v_const);
+template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const);
 
 // ---- kernels_head.hip ----
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
                      int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
-                     int n_up, int n_nuc, int K, LaneInfo li, double eps);
+                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps);
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li);

@@ -9,15 +9,17 @@ namespace dqmc {
 
 // A[b][k][t][i*N + mu] = lane t of envelope(i; k,mu) * backflow(i; k,mu).
 // Envelope: sum_a pi[k*N+mu][a] * exp(-|zeta[k*N+mu][a]| rho_ia)   (reference wf/env.py:57-75,
-// isotropic, per-orbital exponents, one shell per nucleus); it depends on r_i only, so its
+// isotropic, per-orbital exponents; a = nucleus * n_env + e runs over n_env envelopes per nucleus:
+// n_env = 1 is one shell per nucleus, n_env = 3 with pi = 1 the SimplifiedNucleusDependentEnvelopes of
+// env.py:110-226 whose exponents the host reads out of the nuclear stream); it depends on r_i only, so its
 // derivative lanes are the three of electron i and the Laplacian.  Backflow is dense.
 template <typename real>
 __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, const real* __restrict__ R,
                                                   const real* __restrict__ bf, int bf_width, real* __restrict__ orb,
                                                   int orb_width, const real* __restrict__ pi_up,
                                                   const real* __restrict__ pi_dn, const real* __restrict__ ze_up,
-                                                  const real* __restrict__ ze_dn, int B, int n_up, int n_nuc, int K,
-                                                  LaneInfo li, double eps) {
+                                                  const real* __restrict__ ze_dn, int B, int n_up, int n_nuc, int n_env,
+                                                  int K, LaneInfo li, double eps) {
   const int N = li.N, KN = K * N;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N * li.TP * KN;
@@ -30,8 +32,8 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
   const int k = kmu / N, mu = kmu - k * N;
   real out = 0;
   if (t < li.T) {
-    const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc;
-    const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc;
+    const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc * n_env;
+    const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc * n_env;
     double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
     const bool need_d = li.T > 1;
     for (int a = 0; a < n_nuc; ++a) {
@@ -39,12 +41,14 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
       for (int c = 0; c < 3; ++c) d[c] = (double)r[((long)b * N + i) * 3 + c] - (double)R[a * 3 + c];
       const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
       const double rho = sqrt(eps + d2);
-      const double z = fabs((double)ze[a]);
-      const double w = (double)pi[a] * exp(-z * rho);
-      e0 += w;
-      if (need_d) {
-        for (int c = 0; c < 3; ++c) eJ[c] += -z * w * d[c] / rho;
-        eL += w * (z * z * d2 / (rho * rho) - z * (3.0 / rho - d2 / (rho * rho * rho)));
+      for (int ev = 0; ev < n_env; ++ev) {
+        const double z = fabs((double)ze[a * n_env + ev]);
+        const double w = (double)pi[a * n_env + ev] * exp(-z * rho);
+        e0 += w;
+        if (need_d) {
+          for (int c = 0; c < 3; ++c) eJ[c] += -z * w * d[c] / rho;
+          eL += w * (z * z * d2 / (rho * rho) - z * (3.0 / rho - d2 / (rho * rho * rho)));
+        }
       }
     }
     const real* brow = bf + (((long)b * N + i) * li.TP) * bf_width + kmu;
@@ -389,10 +393,10 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
                      int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
-                     int n_up, int n_nuc, int K, LaneInfo li, double eps) {
+                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps) {
   const long total = (long)B * li.N * li.TP * K * li.N;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_orbitals<real>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r, R,
-                     bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, K, li, eps);
+                     bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps);
 }
 
 template <typename real>
@@ -427,7 +431,7 @@ template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
 
 #define DQMC_INST(real)                                                                                              \
   template void launch_orbitals<real>(hipStream_t, const real*, const real*, const real*, int, real*, int,           \
-                                      const real*, const real*, const real*, const real*, int, int, int, int,        \
+                                      const real*, const real*, const real*, const real*, int, int, int, int, int,   \
                                       LaneInfo, double);                                                             \
   template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo);          \
   template void launch_final<real>(hipStream_t, const FinalArgs&);

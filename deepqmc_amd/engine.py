@@ -48,7 +48,8 @@ class Engine:
             raise ValueError('dtype must be float32 or float64')
         # eps under the safe norm is the compute dtype's machine eps (reference utils.py:79-85)
         self.norm_eps = norm_eps if norm_eps is not None else (F32_EPS if dtype == torch.float32 else F64_EPS)
-        self.program: Program = compile_program(spec, params, hamil.n_up, hamil.n_down, hamil.n_nuc)
+        self.program: Program = compile_program(spec, params, hamil.n_up, hamil.n_down, hamil.n_nuc,
+                                                R=hamil.mol.coords, eps=self.norm_eps)
         self.N = hamil.n_up + hamil.n_down
         sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,
                           0 if dtype == torch.float32 else 1, 0, self.norm_eps,
@@ -103,11 +104,15 @@ class Engine:
         R = self._t(R)
         if R.dim() == 3:      # reference tiles R per walker (electron_samplers.py:165-173)
             R = R[0].contiguous()
+        if self.spec.nuclei_tokens and not torch.equal(R, self.R):
+            raise DqmcError('this ansatz folds the nuclear stream at the geometry of its Hamiltonian; '
+                            'build a new engine for a different R')
         return R
 
     def set_params(self, params):
         """New parameter tree after an optimiser step (same structure)."""
-        prog = compile_program(self.spec, params, self.hamil.n_up, self.hamil.n_down, self.hamil.n_nuc)
+        prog = compile_program(self.spec, params, self.hamil.n_up, self.hamil.n_down, self.hamil.n_nuc,
+                               R=self.hamil.mol.coords, eps=self.norm_eps)
         w = np.ascontiguousarray(prog.weights, np.float64)
         self._check(self.lib.dqmc_set_weights(self._ctx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size))
 

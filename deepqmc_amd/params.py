@@ -69,14 +69,28 @@ def layer_dims(spec: AnsatzSpec, n_nuc: int):
     return d0, rows
 
 
+NUC_EMB = f'{GNN}/~/nuclei_embedding'
+NUC_HEAD = f'{OMNI}/~/nuclear_gnn_head'
+NUC_EDGE_MLP = MLPSpec((32,), True, True, 'silu', 'ferminet')       # electron_gnn.py:474-482
+
+
+def nuc_embed_mlp(D: int) -> MLPSpec:
+    return MLPSpec((D,), True, True, 'silu', 'ferminet')            # electron_gnn.py:483-491
+
+
+def attention_feature_name(spec: AnsatzSpec) -> str:
+    return 'combined_node_attention_update_feature' if spec.nuclei_tokens else 'node_attention_electron_update_feature'
+
+
 def param_entries(spec: AnsatzSpec, n_up: int, n_down: int, n_nuc: int):
     """Ordered [(module, leaf, shape, init)] for the whole ansatz."""
     N, K, D, E = n_up + n_down, spec.n_determinants, spec.embedding_dim, spec.two_particle_dim
     ent: List[Tuple[str, str, tuple, str]] = []
     n_env = n_nuc  # one shell per nucleus: per_shell false (wf/env.py:27-32)
     env = f'{WF}/~/exponential_envelopes'
-    for leaf in ('pi_up', 'pi_down', 'zetas_up', 'zetas_down'):
-        ent.append((env, leaf, (K * N, n_env), 'ones'))
+    if spec.envelope == 'exponential':
+        for leaf in ('pi_up', 'pi_down', 'zetas_up', 'zetas_down'):
+            ent.append((env, leaf, (K * N, n_env), 'ones'))
     if spec.conf_coeff == 'linear':
         ent.append((f'{WF}/~/conf_coeff', 'w', (K, 1), 'ones'))
     if spec.cusp is not None and spec.cusp_trainable_alpha:
@@ -84,12 +98,15 @@ def param_entries(spec: AnsatzSpec, n_up: int, n_down: int, n_nuc: int):
         ent.append((cm, 'same_alpha', (), 'alpha'))
         ent.append((cm, 'anti_alpha', (), 'alpha'))
     d0, rows = layer_dims(spec, n_nuc)
+    if spec.nuclei_tokens:        # nuclei embedding: nn edge features + one-hot atom type -> edge_mlp -> sum -> embed_mlp
+        ent += mlp_entries(f'{NUC_EMB}/edge_mlp', NUC_EDGE_MLP, 4 + n_nuc, 32)
+        ent += mlp_entries(f'{NUC_EMB}/embed_mlp', nuc_embed_mlp(D), 32, D)
     if spec.emb_project:
         ent.append((f'{GNN}/~/electron_embedding/linear', 'w', (d0, D), 'hk_linear_w'))
     for l, row in enumerate(rows):
         ln = layer_name(l)
         if spec.layer_kind == 'attention':
-            uf = f'{ln}/~/node_attention_electron_update_feature'
+            uf = f'{ln}/~/{attention_feature_name(spec)}'
             hd = row['d_in'] // spec.num_heads
             for nm in ('query', 'key', 'value'):
                 ent.append((f'{uf}/multi_head_attention/{nm}', 'w', (row['d_in'], spec.num_heads * hd), 'ferminet_w'))
@@ -105,6 +122,14 @@ def param_entries(spec: AnsatzSpec, n_up: int, n_down: int, n_nuc: int):
         ent += mlp_entries(f'{ln}/~/g', spec.g, row['cat'], D)
         if spec.deep_features and not row['last']:
             ent += mlp_entries(f'{ln}/~/u', spec.u, row['e_in'], E)
+    if spec.envelope == 'simplified':   # NuclearGNNHead (omni.py:181-211): one GLU readout per spin + bias (init 2)
+        n_z = K * spec.n_envelope_per_nucleus
+        for glu in ('zetas_readout_glu', 'zetas_readout_glu_1'):
+            for lin in ('W', 'V'):
+                ent.append((f'{NUC_HEAD}/{glu}/{lin}', 'w', (D, n_z), 'hk_linear_w'))
+                ent.append((f'{NUC_HEAD}/{glu}/{lin}', 'b', (n_z,), 'default_b'))
+        for spin in ('up', 'down'):
+            ent.append((NUC_HEAD, f'zetas_bias_{spin}', (n_nuc, K, spec.n_envelope_per_nucleus), 'twos'))
     if spec.jastrow is not None:
         ent += mlp_entries(f'{OMNI}/~/Jastrow/~/mlp', spec.jastrow, D, 1)
     n_orb_up, n_orb_down = (N, N) if spec.full_determinant else (n_up, n_down)
@@ -116,6 +141,8 @@ def param_entries(spec: AnsatzSpec, n_up: int, n_down: int, n_nuc: int):
 def _draw(rng: np.random.Generator, shape, init: str, spec: AnsatzSpec):
     if init == 'ones':
         return np.ones(shape)
+    if init == 'twos':
+        return 2.0 * np.ones(shape)
     if init == 'alpha':
         return np.asarray(spec.cusp_alpha, np.float64)
     if init in ('default_b',):
@@ -148,7 +175,7 @@ def init_params(spec: AnsatzSpec, n_up: int, n_down: int, n_nuc: int, seed: int 
     tree: Dict[str, Dict[str, np.ndarray]] = OrderedDict()
     for mod, leaf, shape, init in param_entries(spec, n_up, n_down, n_nuc):
         val = _draw(rng, shape, init, spec)
-        if perturb_envelopes and init == 'ones' and 'envelopes' in mod:
+        if perturb_envelopes and ((init == 'ones' and 'envelopes' in mod) or init == 'twos'):
             val = val + perturb_envelopes * rng.standard_normal(shape)
         tree.setdefault(mod, OrderedDict())[leaf] = np.asarray(val, np.float64)
     return tree

@@ -14,7 +14,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
-from .params import GNN, OMNI, WF, layer_dims, layer_name
+from .params import attention_feature_name, GNN, OMNI, WF, layer_dims, layer_name
 from .spec import AnsatzSpec, MLPSpec
 
 OP_FEAT_EN, OP_FEAT_EE, OP_LINEAR, OP_SPIN_MEAN, OP_CONV, OP_EDGE_SUM, OP_ROW_SUM = 1, 2, 3, 4, 5, 6, 7
@@ -226,8 +226,16 @@ class _Builder:
                     c[k]()
 
 
-def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int) -> Program:
+def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int, R=None, eps=None) -> Program:
+    """`R` [n_nuc,3] and the safe-norm `eps` are needed only by ansatzes with nuclear tokens, whose
+    electron-independent nuclear stream is folded into constants here (nuclear_stream.py)."""
     b = _Builder(spec, params, n_up, n_down, n_nuc)
+    nuc_kv, nuc_zetas = None, None
+    if spec.nuclei_tokens:
+        if R is None or eps is None:
+            raise ValueError(f'{spec.name}: the nuclear geometry R and eps are needed to compile nuclear tokens')
+        from .nuclear_stream import fold
+        nuc_kv, nuc_zetas = fold(params, spec, R, eps)
     N, K, D, E = n_up + n_down, spec.n_determinants, spec.embedding_dim, spec.two_particle_dim
     S2 = 1.0 / np.sqrt(2.0)
 
@@ -271,16 +279,21 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
     for l, row in enumerate(rows):
         ln = layer_name(l)
         if spec.layer_kind == 'attention':
-            uf = f'{ln}/~/node_attention_electron_update_feature'
+            uf = f'{ln}/~/{attention_feature_name(spec)}'
             H = spec.num_heads
             hd = x_dim // H
             q, k_, v = (b.buf(f'l{l}/{nm}', N, H * hd) for nm in ('q', 'k', 'v'))
             for nm, dst in (('query', q), ('key', k_), ('value', v)):
                 b.linear(f'{uf}/multi_head_attention/{nm}', [(x, 0, x_dim, 0)], dst, 0, 0, N, None)
             att = b.buf(f'l{l}/att', N, H * hd)
-            b.ops.append(Op(OP_ATTENTION, [q, k_, v, att, H, hd], note=f'layer {l} attention'))
-            # attention FLOPs (QK^T and PV), algorithmic: 2 * 2 * N*N*D per walker
-            b.flops += 4.0 * N * N * H * hd
+            n_const, kc_off, vc_off = 0, 0, 0
+            if nuc_kv is not None:       # nuclear tokens: constant extra key / value rows (no derivative lanes)
+                n_const = n_nuc
+                kc_off = b.push_w(nuc_kv[l][0], ('', '', 'const', ()))
+                vc_off = b.push_w(nuc_kv[l][1], ('', '', 'const', ()))
+            b.ops.append(Op(OP_ATTENTION, [q, k_, v, att, H, hd, n_const, kc_off, vc_off], note=f'layer {l} attention'))
+            # attention FLOPs (QK^T and PV), algorithmic: 2 * 2 * N*(N + n_const)*D per walker
+            b.flops += 4.0 * N * (N + n_const) * H * hd
             a2 = b.buf(f'l{l}/attended', N, x_dim)
             b.linear(f'{uf}/multi_head_attention/linear', [(att, 0, H * hd, 0)], a2, 0, 0, N, None, res=x, res_scale=1.0)
             xn = b.buf(f'x{l + 1}', N, x_dim)
@@ -354,11 +367,21 @@ def compile_program(spec: AnsatzSpec, params, n_up: int, n_down: int, n_nuc: int
     bf = b.buf('backflow', N, K * N)
     b.mlp(f'{OMNI}/~/Backflow/~/mlp', spec.backflow, [(x, 0, x_dim, 0)], x_dim, K * N, bf, 0, 0, n_up, N)
     b.mlp(f'{OMNI}/~/Backflow_1/~/mlp', spec.backflow, [(x, n_up, x_dim, 0)], x_dim, K * N, bf, n_up, 0, n_down, N)
-    env = params[f'{WF}/~/exponential_envelopes']
-    offs = [b.push_w(env[nm], (f'{WF}/~/exponential_envelopes', nm, 'raw', ())) for nm in
-            ('pi_up', 'pi_down', 'zetas_up', 'zetas_down')]
+    n_env = 1
+    if spec.envelope == 'simplified':
+        # wf/env.py:110-226 with pi = 1 and orbital-independent exponents, expanded to the general
+        # [K*N orbitals][n_nuc * n_env] table the ORBITALS kernel reads: zeta[(k,mu)][(nuc,e)] = zetas[nuc,k,e]
+        n_env = spec.n_envelope_per_nucleus
+        offs = [b.push_w(np.ones((K * N, n_nuc * n_env)), ('', '', 'const', ())) for _ in range(2)]
+        for spin in ('up', 'down'):
+            z = np.transpose(nuc_zetas[spin], (1, 0, 2)).reshape(K, 1, n_nuc * n_env)
+            offs.append(b.push_w(np.broadcast_to(z, (K, N, n_nuc * n_env)), ('', '', 'const', ())))
+    else:
+        env = params[f'{WF}/~/exponential_envelopes']
+        offs = [b.push_w(env[nm], (f'{WF}/~/exponential_envelopes', nm, 'raw', ())) for nm in
+                ('pi_up', 'pi_down', 'zetas_up', 'zetas_down')]
     orb = b.buf('orbitals', K, N * N)
-    b.ops.append(Op(OP_ORBITALS, [bf, orb] + offs, note='Slater matrices = envelope * backflow'))
+    b.ops.append(Op(OP_ORBITALS, [bf, orb] + offs + [n_env], note='Slater matrices = envelope * backflow'))
     b.ops.append(Op(OP_SLOGDET, [orb], note='slogdet + derivative traces'))
     cc_off = -1
     if spec.conf_coeff == 'linear':

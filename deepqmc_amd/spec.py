@@ -83,6 +83,12 @@ class AnsatzSpec:
     num_heads: int = 4
     attn_mlp: Optional[MLPSpec] = None
     init: str = 'default'
+    # ---- nuclear tokens (TransPsiformer: gnn/electron_gnn.py:435-537, update_features.py:385-451,
+    # wf/omni.py:181-211, wf/env.py:110-226) ----
+    nuclei_tokens: bool = False            # CombinedNodeAttention over [nuclei; electrons], elec_to_nuc = False
+    nuc_types: Tuple[int, ...] = ()        # index of each nucleus' charge among the sorted unique charges
+    envelope: str = 'exponential'          # 'exponential' (env.py:57-108) | 'simplified' (env.py:110-226)
+    n_envelope_per_nucleus: int = 1
 
     @property
     def deep_features(self) -> bool:
@@ -133,4 +139,19 @@ def psiformer() -> AnsatzSpec:
     )
 
 
-ANSATZES = {'paulinet': paulinet, 'default': paulinet, 'ferminet': ferminet, 'psiformer': psiformer}
+def transpsiformer(charges=None) -> AnsatzSpec:
+    """conf/ansatz/transpsiformer.yaml: Psiformer whose attention also runs over nuclear tokens (which do not
+    see the electrons: `elec_to_nuc: false`) and whose envelope exponents are read out from the final nuclear
+    embeddings.  `charges` fixes the atom types of the nuclei embedding (one-hot over the sorted unique charges,
+    electron_gnn.py:497-503); NeuralNetworkWaveFunction fills it in from the Hamiltonian."""
+    import dataclasses
+    types = ()
+    if charges is not None:
+        uniq = sorted(set(float(c) for c in charges))
+        types = tuple(uniq.index(float(c)) for c in charges)
+    return dataclasses.replace(psiformer(), name='transpsiformer', nuclei_tokens=True, nuc_types=types,
+                               envelope='simplified', n_envelope_per_nucleus=3)
+
+
+ANSATZES = {'paulinet': paulinet, 'default': paulinet, 'ferminet': ferminet, 'psiformer': psiformer,
+            'transpsiformer': transpsiformer}

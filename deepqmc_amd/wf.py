@@ -24,7 +24,10 @@ class NeuralNetworkWaveFunction:
     def __init__(self, hamil: MolecularHamiltonian, spec='paulinet', *, dtype=torch.float32, device='cuda',
                  norm_eps=None, lib=None):
         self.hamil = hamil
-        self.spec: AnsatzSpec = ANSATZES[spec]() if isinstance(spec, str) else spec
+        if spec == 'transpsiformer':
+            self.spec: AnsatzSpec = ANSATZES[spec](hamil.mol.charges)      # atom types of the nuclei embedding
+        else:
+            self.spec = ANSATZES[spec]() if isinstance(spec, str) else spec
         self.dtype, self.device, self.norm_eps, self._lib = dtype, device, norm_eps, lib
         self._engines = {}       # id(params) -> Engine, most recently used last (one per electronic state)
         self.max_engines = 8

@@ -210,8 +210,9 @@ class Interp:
 
     def op_8(self, op):  # ORBITALS
         bf, dst, o_pu, o_pd, o_zu, o_zd = op.i[:6]
+        n_env = max(op.i[6], 1)                       # envelopes per nucleus (table column = nuc * n_env + e)
         N, K, n_up = self.N, self.p.spec.n_determinants, self.p.n_up
-        n_nuc = self.R.shape[0]
+        n_nuc = self.R.shape[0] * n_env
         out = self.bufs[dst]
         for i in range(N):
             o_pi, o_z = (o_pu, o_zu) if i < n_up else (o_pd, o_zd)
@@ -219,7 +220,7 @@ class Interp:
             ze = self.w[o_z:o_z + K * N * n_nuc].reshape(K * N, n_nuc)
             env = np.zeros((self.B, K * N, self.TP))
             for a in range(n_nuc):
-                f_rho, _ = self._dist_lanes(self.r[:, i] - self.R[a], i, -1)        # [B,TP]
+                f_rho, _ = self._dist_lanes(self.r[:, i] - self.R[a // n_env], i, -1)   # [B,TP]
                 z = np.abs(ze[:, a])                                                 # [KN]
                 ex = np.exp(-z[None] * f_rho[:, :1])                                 # [B,KN]
                 f = np.broadcast_to(f_rho[:, None, :], (self.B, K * N, self.TP))
@@ -303,11 +304,19 @@ class Interp:
 
     def op_11(self, op):  # ATTENTION (forward-Laplacian softmax attention, appendix C)
         qb, kb, vb, dst, H, hd = op.i[:6]
+        n_const, kc_off, vc_off = op.i[6:9]          # constant (nuclear-token) key / value rows, value lane only
         T = self.T
         sc = 1 / math.sqrt(hd)
         for h in range(H):
             sl = slice(h * hd, (h + 1) * hd)
             q, k, v = (self.bufs[b_][..., sl] for b_ in (qb, kb, vb))              # [B,N,TP,hd]
+            if n_const:
+                ext = []
+                for off, arr in ((kc_off, k), (vc_off, v)):
+                    c = np.zeros((self.B, n_const, self.TP, hd))
+                    c[:, :, 0] = self.w[off:off + n_const * H * hd].reshape(n_const, H * hd)[None, :, sl]
+                    ext.append(np.concatenate([c, arr], axis=1))
+                k, v = ext
             S = np.einsum('bitd,bjd->bijt', q, k[:, :, 0]) * sc                     # lanes of q
             S[..., 1:] += np.einsum('bid,bjtd->bijt', q[:, :, 0], k[:, :, 1:]) * sc
             if self.lap:

@@ -13,7 +13,8 @@ from typing import Dict
 
 import torch
 
-from deepqmc_amd.params import GNN, OMNI, WF, layer_dims, layer_name
+from deepqmc_amd.params import (GNN, NUC_EDGE_MLP, NUC_EMB, NUC_HEAD, OMNI, WF, attention_feature_name, layer_dims,
+                                layer_name, nuc_embed_mlp)
 from deepqmc_amd.spec import AnsatzSpec, MLPSpec
 
 from . import geom
@@ -104,25 +105,68 @@ def convolve(typ: str, comps: dict, hx: torch.Tensor, n_up: int, normalize: bool
     return sum_senders(prod, normalize)
 
 
-def attention(params, prefix: str, h: torch.Tensor, num_heads: int) -> torch.Tensor:
+def attention(params, prefix: str, h: torch.Tensor, num_heads: int, mask=None) -> torch.Tensor:
     """hk.MultiHeadAttention(num_heads, key_size=D/H, with_bias=False) -- dm-haiku,
-    called at gnn/update_features.py:273-278: Q/K/V Linear -> [T,H,hd], logits/sqrt(hd),
-    softmax over keys, concat heads, output Linear."""
+    called at gnn/update_features.py:273-278 / :436-444: Q/K/V Linear -> [T,H,hd], logits/sqrt(hd),
+    masked logits -> -1e30, softmax over keys, concat heads, output Linear."""
     T, D = h.shape
     hd = D // num_heads
     q = (h @ params[f'{prefix}/query']['w']).reshape(T, num_heads, hd)
     k = (h @ params[f'{prefix}/key']['w']).reshape(T, num_heads, hd)
     v = (h @ params[f'{prefix}/value']['w']).reshape(T, num_heads, hd)
     logits = torch.einsum('thd,Thd->htT', q, k) / math.sqrt(hd)
+    if mask is not None:
+        logits = torch.where(mask[None], logits, torch.full_like(logits, -1e30))
     w = torch.softmax(logits, dim=-1)
     a = torch.einsum('htT,Thd->thd', w, v).reshape(T, num_heads * hd)
     return a @ params[f'{prefix}/linear']['w']
 
 
+def nuclei_embedding(params, spec: AnsatzSpec, R, eps: float):
+    """NucleiEmbedding.__call__ with edge features (gnn/electron_gnn.py:528-537): nn edges with self
+    interaction, [log1p|d|, d log1p|d|/|d|] features, one-hot atom type OF THE SENDER appended
+    (:497-503), edge_mlp, sum over senders, embed_mlp."""
+    n_nuc = R.shape[0]
+    f = edge_features(geom.compute_edges(R, R, False), True, eps)        # [s, r, 4]
+    onehot = torch.zeros(n_nuc, n_nuc, dtype=R.dtype)
+    onehot[torch.arange(n_nuc), torch.as_tensor(spec.nuc_types)] = 1.0
+    f = torch.cat([f, onehot[:, None, :].expand(n_nuc, n_nuc, n_nuc)], dim=-1)
+    e = mlp(params, f'{NUC_EMB}/edge_mlp', NUC_EDGE_MLP, f, 32)
+    return mlp(params, f'{NUC_EMB}/embed_mlp', nuc_embed_mlp(spec.embedding_dim), e.sum(0), spec.embedding_dim)
+
+
+def nuclear_head(params, spec: AnsatzSpec, h_nuc):
+    """NuclearGNNHead (wf/omni.py:181-211): per spin GLU(LayerNorm(h), LayerNorm(h)) + bias ->
+    zetas [n_nuc, K, n_env].  hkext.GLU (:165-202): sigmoid(W x) * (V y), LayerNorm without scale/offset."""
+    K, ne = spec.n_determinants, spec.n_envelope_per_nucleus
+    ln = torch.nn.functional.layer_norm(h_nuc, (h_nuc.shape[-1],), eps=1e-5)
+    out = {}
+    for spin, glu in (('up', 'zetas_readout_glu'), ('down', 'zetas_readout_glu_1')):
+        W, V = params[f'{NUC_HEAD}/{glu}/W'], params[f'{NUC_HEAD}/{glu}/V']
+        g = torch.sigmoid(ln @ W['w'] + W['b']) * (ln @ V['w'] + V['b'])
+        out[spin] = g.reshape(-1, K, ne) + params[NUC_HEAD][f'zetas_bias_{spin}']
+    return out
+
+
 def gnn(params, spec: AnsatzSpec, r, R, n_up: int, eps: float, trace=None):
-    """gnn/electron_gnn.py:403-432 + layer update order of gnn/graph.py:182-192."""
+    """gnn/electron_gnn.py:403-432 + layer update order of gnn/graph.py:182-192.  With nuclear tokens
+    returns (electron embeddings, nuclear embeddings)."""
     N, n_nuc = r.shape[0], R.shape[0]
     x = electron_embedding(params, spec, r, R, n_up, eps)
+    if spec.nuclei_tokens:
+        xn = nuclei_embedding(params, spec, R, eps)
+        mask = torch.ones(n_nuc + N, n_nuc + N, dtype=torch.bool)
+        mask[:n_nuc, n_nuc:] = False                                         # update_features.py:428-434
+        _, rows = layer_dims(spec, n_nuc)
+        for l, row in enumerate(rows):
+            uf = f'{layer_name(l)}/~/{attention_feature_name(spec)}'
+            h = torch.cat([xn, x], dim=0)
+            att = h + attention(params, f'{uf}/multi_head_attention', h, spec.num_heads, mask)
+            h = att + mlp(params, f'{uf}/mlp', spec.attn_mlp, att, h.shape[-1])
+            xn, x = h[:n_nuc], h[n_nuc:]
+            if trace is not None:
+                trace[f'x{l + 1}'], trace[f'xn{l + 1}'] = x, xn
+        return x, xn
     comps = geom.molecular_edges(r, R, n_up, spec.edge_types, spec.self_interaction)
     edges = {t: geom.from_single_array(c, edge_features(geom.single_array(c), spec.edge_log_rescale, eps))
              for t, c in comps.items()}
@@ -185,6 +229,17 @@ def gnn(params, spec: AnsatzSpec, r, R, n_up: int, eps: float, trace=None):
     return x
 
 
+def simplified_envelopes(zetas, r, R, n_up: int, eps: float):
+    """SimplifiedNucleusDependentEnvelopes (wf/env.py:110-226; per_orbital_exponent false, pi fixed to 1):
+    env[k, i] = sum_{nuc, e} exp(-|zeta_spin(i)[nuc, k, e] * |r_i - R_nuc||), the same for every orbital."""
+    d = geom.norm(geom.pairwise_diffs(r, R)[..., :-1], safe=True, eps=eps)     # [N, n_nuc]
+    outs = []
+    for zeta, dd in ((zetas['up'], d[:n_up]), (zetas['down'], d[n_up:])):
+        expo = torch.abs(dd[:, :, None, None] * zeta[None])                      # [n_el, n_nuc, K, n_env]
+        outs.append(torch.exp(-expo).sum(dim=(1, 3)).swapaxes(0, 1))             # [K, n_el]
+    return torch.cat(outs, dim=1)[:, :, None]                                    # [K, N, 1] broadcast over orbitals
+
+
 def envelopes(params, r, R, n_up: int, K: int, eps: float):
     """ExponentialEnvelopes(isotropic, per_orbital_exponent, spin-unrestricted, one shell
     per nucleus) -- wf/env.py:57-75,94-108.  Returns [K, N, n_orb]."""
@@ -229,7 +284,15 @@ def orbitals(params, spec: AnsatzSpec, r, R, n_up: int, eps: float, trace=None):
     """Slater matrices [K, N, N] (full_determinant) -- nn_wave_function.py:127-147."""
     N, K, D = r.shape[0], spec.n_determinants, spec.embedding_dim
     x = gnn(params, spec, r, R, n_up, eps, trace)
-    orb = envelopes(params, r, R, n_up, K, eps)                          # [K, N, N]
+    if spec.nuclei_tokens:
+        x, xn = x
+    if spec.envelope == 'simplified':
+        zetas = nuclear_head(params, spec, xn)
+        if trace is not None:
+            trace['zetas'] = zetas
+        orb = simplified_envelopes(zetas, r, R, n_up, eps).expand(K, N, N)
+    else:
+        orb = envelopes(params, r, R, n_up, K, eps)                      # [K, N, N]
     assert spec.full_determinant
     bf_up = mlp(params, f'{OMNI}/~/Backflow/~/mlp', spec.backflow, x[:n_up], N * K)
     bf_dn = mlp(params, f'{OMNI}/~/Backflow_1/~/mlp', spec.backflow, x[n_up:], N * K)

@@ -19,7 +19,7 @@ from deepqmc_amd.hamil import MolecularHamiltonian
 from deepqmc_amd.molecule import Molecule
 from deepqmc_amd.params import init_params
 from deepqmc_amd.sampling import synthetic_walkers
-from deepqmc_amd.spec import ferminet, paulinet, psiformer
+from deepqmc_amd.spec import ferminet, paulinet, psiformer, transpsiformer
 from oracle import geom, sampling as osamp
 from oracle import wf as owf
 from oracle.program_interp import Interp
@@ -30,8 +30,8 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def setup(spec_fn, molname, dtype, seed=5):
-    spec = spec_fn()
     mol = Molecule.from_name(molname)
+    spec = spec_fn(mol.charges) if spec_fn is transpsiformer else spec_fn()
     h = MolecularHamiltonian(mol=mol)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=seed, perturb_envelopes=0.1)
     eng = Engine(spec, h, tree, dtype=dtype, device=DEV, norm_eps=geom.F32_EPS)
@@ -48,7 +48,8 @@ def report(name, payload):
 
 
 @pytest.mark.parametrize('spec_fn,molname,B', [(paulinet, 'LiH', 8), (ferminet, 'LiH', 5), (paulinet, 'Be', 4), (ferminet, 'N2', 3),
-                                               (psiformer, 'LiH', 4), (psiformer, 'N2', 2)])
+                                               (psiformer, 'LiH', 4), (psiformer, 'N2', 2), (transpsiformer, 'LiH', 4),
+                                               (transpsiformer, 'cyclobutadiene_square', 1)])
 def test_f64_every_buffer(spec_fn, molname, B):
     spec, mol, h, tree, eng, it = setup(spec_fn, molname, torch.float64)
     r = synthetic_walkers(h, B, seed=3)
@@ -72,7 +73,8 @@ def test_f64_every_buffer(spec_fn, molname, B):
     report(f'f64_buffers_{spec.name}_{molname}', {'max_abs_err': max(worst.values())})
 
 
-@pytest.mark.parametrize('spec_fn,molname,B', [(paulinet, 'LiH', 256), (ferminet, 'N2', 16), (psiformer, 'LiH', 32)])
+@pytest.mark.parametrize('spec_fn,molname,B', [(paulinet, 'LiH', 256), (ferminet, 'N2', 16), (psiformer, 'LiH', 32),
+                                               (transpsiformer, 'LiH', 32)])
 def test_f32_local_energy(spec_fn, molname, B, lih_walker):
     spec, mol, h, tree, eng, it = setup(spec_fn, molname, torch.float32)
     r = synthetic_walkers(h, B, seed=11).astype(np.float32)

@@ -8,7 +8,7 @@ from deepqmc_amd.hamil import MolecularHamiltonian
 from deepqmc_amd.molecule import Molecule
 from deepqmc_amd.params import init_params
 from deepqmc_amd.program import compile_program
-from deepqmc_amd.spec import ferminet, paulinet, psiformer
+from deepqmc_amd.spec import ferminet, paulinet, psiformer, transpsiformer
 from oracle import geom, physics
 from oracle import wf as owf
 from oracle.program_interp import Interp
@@ -23,13 +23,16 @@ def make_walkers(mol, n_elec, B, seed=1):
     return mol.coords[centers][None] + rng.standard_normal((B, n_elec, 3))
 
 
-@pytest.mark.parametrize('spec_fn,molname', [(paulinet, 'LiH'), (ferminet, 'LiH'), (psiformer, 'LiH'), (paulinet, 'Be')])
+@pytest.mark.parametrize('spec_fn,molname', [(paulinet, 'LiH'), (ferminet, 'LiH'), (psiformer, 'LiH'), (paulinet, 'Be'),
+                                             (transpsiformer, 'LiH')])
 def test_interp_matches_autograd(spec_fn, molname, lih_walker):
-    spec = spec_fn()
     mol = Molecule.from_name(molname)
+    spec = spec_fn(mol.charges) if spec_fn is transpsiformer else spec_fn()
     h = MolecularHamiltonian(mol=mol)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
-    prog = compile_program(spec, tree, h.n_up, h.n_down, h.n_nuc)
+    # transpsiformer: the nuclear stream is folded at compile time (deepqmc_amd/nuclear_stream.py); the oracle
+    # evaluates the full masked attention over [nuclei; electrons] instead
+    prog = compile_program(spec, tree, h.n_up, h.n_down, h.n_nuc, R=mol.coords, eps=geom.F32_EPS)
     r = make_walkers(mol, h.n_elec, 3)
     if molname == 'LiH':
         r[0] = lih_walker
@@ -41,8 +44,9 @@ def test_interp_matches_autograd(spec_fn, molname, lih_walker):
     e_ref, st_ref, qf_ref = physics.batch_local_energy(params, spec, T(r), T(mol.coords), T(mol.charges), h.n_up, eps)
     s_ref, l_ref = physics.batch_wave_function(params, spec, T(r), T(mol.coords), h.n_up, eps)
     np.testing.assert_array_equal(val['sign'], s_ref.numpy().astype(np.int32))
-    np.testing.assert_allclose(val['log'], l_ref.numpy(), rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(lap['log'], l_ref.numpy(), rtol=1e-12, atol=1e-12)
+    tol = 1e-10 if spec.nuclei_tokens else 1e-12      # folded nuclear stream: different summation order
+    np.testing.assert_allclose(val['log'], l_ref.numpy(), rtol=tol, atol=tol)
+    np.testing.assert_allclose(lap['log'], l_ref.numpy(), rtol=tol, atol=tol)
     np.testing.assert_allclose(lap['grad'], qf_ref.numpy(), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(lap['e_loc'], e_ref.numpy(), rtol=1e-9, atol=1e-9)
     order = ['hamil/V_el', 'hamil/E_kin', 'hamil/V_loc', 'hamil/V_nl', 'hamil/lap', 'hamil/quantum_force']

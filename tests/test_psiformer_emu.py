@@ -7,7 +7,7 @@ from deepqmc_amd.engine import Engine
 from deepqmc_amd.hamil import MolecularHamiltonian
 from deepqmc_amd.molecule import Molecule
 from deepqmc_amd.params import init_params
-from deepqmc_amd.spec import AnsatzSpec, MLPSpec, psiformer
+from deepqmc_amd.spec import AnsatzSpec, MLPSpec, psiformer, transpsiformer
 from oracle import geom
 from oracle.program_interp import Interp
 from simt_util import emu_lib
@@ -39,3 +39,38 @@ def test_psiformer_emu_f64():
     sign, logpsi = eng.wf_eval(torch.as_tensor(r))
     np.testing.assert_array_equal(sign.numpy(), val['sign'])
     np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-11, atol=1e-11)
+
+
+def test_transpsiformer_emu_f64():
+    """TransPsiformer (conf/ansatz/transpsiformer.yaml): attention of the electron queries over
+    [nuclear tokens; electrons] with the nuclear stream folded on the host, envelope exponents read out of
+    the nuclear embeddings (3 per nucleus, pi = 1).  HIP kernels (emulated) vs the NumPy interpreter on every
+    buffer, and vs the un-folded torch oracle (full masked attention over all tokens) on psi and E_loc."""
+    from oracle import physics
+    from oracle import wf as owf
+    mol = Molecule.from_name('LiH')
+    spec = dataclasses.replace(transpsiformer(mol.charges), embedding_dim=32, n_interactions=2, n_determinants=4)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    for name, idx in eng.program.buf_names.items():
+        np.testing.assert_allclose(eng.debug_read(name, B), it.bufs[idx], rtol=1e-9, atol=1e-9, err_msg=name)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    e_ref, _, _ = physics.batch_local_energy(owf.to_torch(tree), spec, T(r), T(mol.coords), T(mol.charges), h.n_up, geom.F32_EPS)
+    np.testing.assert_allclose(e.numpy(), e_ref.numpy(), rtol=1e-8, atol=1e-8)
+    sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+    s_ref, l_ref = physics.batch_wave_function(owf.to_torch(tree), spec, T(r), T(mol.coords), h.n_up, geom.F32_EPS)
+    np.testing.assert_array_equal(sign.numpy(), s_ref.numpy().astype(np.int32))
+    np.testing.assert_allclose(logpsi.numpy(), l_ref.numpy(), rtol=1e-10, atol=1e-10)
+    # a different geometry needs a new engine (the nuclear stream is folded at the Hamiltonian's R)
+    import pytest
+    from deepqmc_amd.engine import DqmcError
+    with pytest.raises(DqmcError):
+        eng.wf_eval(torch.as_tensor(r), R=torch.as_tensor(mol.coords + 0.1))
