@@ -111,6 +111,8 @@ def main():
     ap.add_argument('--ansatz', default='paulinet')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--ecp', action='store_true', help='Gaussian-type ECP on every atom heavier than He with SYNTHETIC '
+                    'coefficients (pyscf tables are not available offline): exercises the 12 N n_ecp psi-ratio quadrature')
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
@@ -131,7 +133,15 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
-    hamil = MolecularHamiltonian(mol=Molecule.from_name(args.molecule))
+    mol = Molecule.from_name(args.molecule)
+    if args.ecp:
+        from deepqmc_amd.ecp import ELEMENTS
+        tab = lambda z: [2 if z > 2 else 0, [[-1, [[], [[5.4, float(z - 2)]], [[4.6, -4.6]], [[2.7, 5.4]]]],
+                                              [0, [[], [], [[1.33, 6.75]]]], [1, [[], [], [[1.25, 0.45]]]]]]
+        hamil = MolecularHamiltonian(mol=mol, ecp_type='synthetic',
+                                     ecp_tables={ELEMENTS[int(z)]: tab(int(z)) for z in set(mol.charges) if z > 2})
+    else:
+        hamil = MolecularHamiltonian(mol=mol)
     wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
@@ -163,7 +173,7 @@ def main():
             r = state['r']
         else:
             r = state['r']
-        e, _ = loc_ene(None, params, r)
+        e, _ = loc_ene(step, params, r)
         stats = parallel.energy_stats(eng, e)
         return state, stats
 
@@ -235,6 +245,9 @@ def main():
             'flops_per_eloc': (3 * hamil.n_elec + 2) * eng.program.flops_per_walker,
             'roofline': roofline,
         }
+        if args.ecp:
+            out['data'] += ', synthetic ECP coefficients'
+            out['config']['workload'] += ' + Gaussian-type ECP (12-point quadrature)'
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub)
         print(json.dumps(out))

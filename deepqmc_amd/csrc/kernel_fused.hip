@@ -442,15 +442,27 @@ __device__ __forceinline__ void fused_body(const FusedArgs<real>& a) {
           const int n_env = i[6] > 0 ? i[6] : 1;          // envelopes per nucleus (kernels_head.hip: k_orbitals)
           const real* pi = a.w + (el < n_up ? i[2] : i[3]) + kmu * n_nuc * n_env;
           const real* ze = a.w + (el < n_up ? i[4] : i[5]) + kmu * n_nuc * n_env;
-          double e0 = 0;
-          for (int n = 0; n < n_nuc; ++n) {
-            double d2 = a.eps;
-            for (int c = 0; c < 3; ++c) { const double d = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += d * d; }
-            const double rho = sqrt(d2);
-            for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
+          real res;
+          if (sizeof(real) == 4) {        // float32 build: exponentials on the f32 unit (as k_orbitals, T = 1)
+            float acc = 0.f;
+            for (int n = 0; n < n_nuc; ++n) {
+              float d2 = (float)a.eps;
+              for (int c = 0; c < 3; ++c) { const float d = (float)r[(wl * N + el) * 3 + c] - (float)a.R[n * 3 + c]; d2 += d * d; }
+              const float rho = sqrtf(d2);
+              for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[n * n_env + ev] * expf(-fabsf((float)ze[n * n_env + ev]) * rho);
+            }
+            res = (real)(acc * (float)smem[bf.lds + (wl * N + el) * bf.stride + kmu]);
+          } else {
+            double e0 = 0;
+            for (int n = 0; n < n_nuc; ++n) {
+              double d2 = a.eps;
+              for (int c = 0; c < 3; ++c) { const double d = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += d * d; }
+              const double rho = sqrt(d2);
+              for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
+            }
+            res = (real)(e0 * (double)smem[bf.lds + (wl * N + el) * bf.stride + kmu]);
           }
-          const double b0 = (double)smem[bf.lds + (wl * N + el) * bf.stride + kmu];
-          orb_g[(wl * K + kd) * orb.width + el * N + mu] = (real)(e0 * b0);
+          orb_g[(wl * K + kd) * orb.width + el * N + mu] = res;
         }
         break;
       }

@@ -20,56 +20,68 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
                                                   const real* __restrict__ pi_dn, const real* __restrict__ ze_up,
                                                   const real* __restrict__ ze_dn, int B, int n_up, int n_nuc, int n_env,
                                                   int K, LaneInfo li, double eps) {
+  // One thread per (walker, electron, orbital k*N+mu): the envelope value / gradient / Laplacian are
+  // computed once (n_nuc*n_env exponentials) and then applied to all TP lanes of the backflow row;
+  // neighbouring threads walk neighbouring orbitals, so the backflow reads and the Slater-matrix
+  // writes of every lane are contiguous runs of N elements.
   const int N = li.N, KN = K * N;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * N * li.TP * KN;
+  const long total = (long)B * N * KN;
   if (idx >= total) return;
   const int kmu = (int)(idx % KN);
-  long q = idx / KN;
-  const int t = (int)(q % li.TP); q /= li.TP;
+  const long q = idx / KN;
   const int i = (int)(q % N);
   const int b = (int)(q / N);
   const int k = kmu / N, mu = kmu - k * N;
-  real out = 0;
-  if (t < li.T) {
-    const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc * n_env;
-    const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc * n_env;
-    double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
-    const bool need_d = li.T > 1;
+  const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc * n_env;
+  const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc * n_env;
+  double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
+  const bool need_d = li.T > 1;
+  if (!need_d && sizeof(real) == 4) {
+    // value-only evaluation of the float32 build (Metropolis sub-steps, ECP quadrature walkers): the
+    // n_nuc*n_env exponentials per orbital dominate this kernel, so they run on the f32 exp unit
+    float acc = 0.f;
     for (int a = 0; a < n_nuc; ++a) {
-      double d[3];
-      for (int c = 0; c < 3; ++c) d[c] = (double)r[((long)b * N + i) * 3 + c] - (double)R[a * 3 + c];
-      const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-      const double rho = sqrt(eps + d2);
-      for (int ev = 0; ev < n_env; ++ev) {
-        const double z = fabs((double)ze[a * n_env + ev]);
-        const double w = (double)pi[a * n_env + ev] * exp(-z * rho);
-        e0 += w;
-        if (need_d) {
-          for (int c = 0; c < 3; ++c) eJ[c] += -z * w * d[c] / rho;
-          eL += w * (z * z * d2 / (rho * rho) - z * (3.0 / rho - d2 / (rho * rho * rho)));
-        }
-      }
+      float d2 = (float)eps;
+      for (int c = 0; c < 3; ++c) { const float d = (float)r[((long)b * N + i) * 3 + c] - (float)R[a * 3 + c]; d2 += d * d; }
+      const float rho = sqrtf(d2);
+      for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[a * n_env + ev] * expf(-fabsf((float)ze[a * n_env + ev]) * rho);
     }
-    const real* brow = bf + (((long)b * N + i) * li.TP) * bf_width + kmu;
-    const double b0 = (double)brow[0];
-    double o;
-    if (t == 0) {
-      o = e0 * b0;
-    } else {
-      const double bt = (double)brow[(long)t * bf_width];
-      o = e0 * bt;
-      if (t < li.T - 1) {
-        const int c = t - 1;
-        if (c / 3 == i) o += eJ[c - 3 * i] * b0;
-      } else {  // Laplacian lane
-        o += eL * b0;
-        for (int c = 0; c < 3; ++c) o += 2.0 * eJ[c] * (double)brow[(long)(1 + 3 * i + c) * bf_width];
-      }
-    }
-    out = (real)o;
+    orb[(((long)b * K + k) * li.TP) * orb_width + i * N + mu] =
+        (real)(acc * (float)bf[(((long)b * N + i) * li.TP) * bf_width + kmu]);
+    return;
   }
-  orb[(((long)b * K + k) * li.TP + t) * orb_width + i * N + mu] = out;
+  for (int a = 0; a < n_nuc; ++a) {
+    double d[3];
+    for (int c = 0; c < 3; ++c) d[c] = (double)r[((long)b * N + i) * 3 + c] - (double)R[a * 3 + c];
+    const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const double rho = sqrt(eps + d2);
+    for (int ev = 0; ev < n_env; ++ev) {
+      const double z = fabs((double)ze[a * n_env + ev]);
+      const double w = (double)pi[a * n_env + ev] * exp(-z * rho);
+      e0 += w;
+      if (need_d) {
+        for (int c = 0; c < 3; ++c) eJ[c] += -z * w * d[c] / rho;
+        eL += w * (z * z * d2 / (rho * rho) - z * (3.0 / rho - d2 / (rho * rho * rho)));
+      }
+    }
+  }
+  const real* brow = bf + (((long)b * N + i) * li.TP) * bf_width + kmu;
+  real* orow = orb + (((long)b * K + k) * li.TP) * orb_width + i * N + mu;
+  const double b0 = (double)brow[0];
+  orow[0] = (real)(e0 * b0);
+  if (!need_d) return;
+  double lap_cross = 0;
+  for (int t = 1; t < li.T - 1; ++t) {
+    const double bt = (double)brow[(long)t * bf_width];
+    double o = e0 * bt;
+    const int c = t - 1;
+    if (c / 3 == i) { o += eJ[c - 3 * i] * b0; lap_cross += 2.0 * eJ[c - 3 * i] * bt; }
+    orow[(long)t * orb_width] = (real)o;
+  }
+  const int tl = li.T - 1;
+  orow[(long)tl * orb_width] = (real)(e0 * (double)brow[(long)tl * bf_width] + eL * b0 + lap_cross);
+  for (int t = li.T; t < li.TP; ++t) orow[(long)t * orb_width] = (real)0;
 }
 
 // slogdet of one N x N matrix per wave plus its forward-Laplacian lanes:
@@ -170,6 +182,65 @@ __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, in
     __syncthreads();
   }
   for (int t = li.T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
+}
+
+// Value-only variant (Metropolis sub-steps, ECP quadrature walkers; T = 1): sign and log|det| need only
+// the LU factorisation, not the inverse.  One wave per matrix, the matrix in LDS (double, odd row stride);
+// per pivot: wave-wide arg-max over the column (first maximum, as LAPACK idamax), row swap, and the rank-1
+// update of the trailing block dealt over an 8 x 8 lane grid.  Two barriers per pivot instead of five, no
+// serial pivot search, a third of the flops of the Gauss-Jordan kernel above.
+template <typename real>
+__global__ void __launch_bounds__(64) k_slogdet_lu(const real* __restrict__ orb, int orb_width,
+                                                   double* __restrict__ logdet, int32_t* __restrict__ sign_k,
+                                                   LaneInfo li) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  double* A = reinterpret_cast<double*>(smem_raw);
+  const int N = li.N, NS = N | 1;
+  const int lane = threadIdx.x;
+  const long bk = blockIdx.x;  // b*K + k
+  const real* base = orb + bk * li.TP * orb_width;
+  for (int e = lane; e < N * N; e += 64) {
+    const int i = e / N, j = e - i * N;
+    A[i * NS + j] = (double)base[e];
+  }
+  __syncthreads();
+  double logabs = 0.0;
+  int sgn = 1;
+  const int li8 = lane >> 3, lj8 = lane & 7;
+  for (int p = 0; p < N; ++p) {
+    double bv = -1.0;
+    int q = p;
+    for (int i = p + lane; i < N; i += 64) {
+      const double x = fabs(A[i * NS + p]);
+      if (x > bv) { bv = x; q = i; }
+    }
+    for (int m = 1; m < 64; m <<= 1) {
+      const double ov = __shfl_xor(bv, m, 64);
+      const int oq = __shfl_xor(q, m, 64);
+      if (ov > bv || (ov == bv && oq < q)) { bv = ov; q = oq; }
+    }
+    if (q != p) {
+      for (int j = lane; j < N; j += 64) {
+        const double t0 = A[p * NS + j]; A[p * NS + j] = A[q * NS + j]; A[q * NS + j] = t0;
+      }
+      sgn = -sgn;
+    }
+    __syncthreads();
+    const double piv = A[p * NS + p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) { sgn = 0; break; }      // singular: log|det| = -inf, sign 0 (wave-uniform exit)
+    const double ip = 1.0 / piv;
+    for (int i = p + 1 + li8; i < N; i += 8) {
+      const double f = A[i * NS + p] * ip;
+      for (int j = p + 1 + lj8; j < N; j += 8) A[i * NS + j] -= f * A[p * NS + j];
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
 }
 
 // Small-matrix variant (N <= 4: H2, LiH, Be ...): one thread per (walker, determinant), the
@@ -394,7 +465,7 @@ template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
                      int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
                      int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps) {
-  const long total = (long)B * li.N * li.TP * K * li.N;
+  const long total = (long)B * li.N * K * li.N;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_orbitals<real>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r, R,
                      bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps);
 }
@@ -414,6 +485,9 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
   else if (li.N == 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 4>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
                        sign_k, n_mat, li);
+  else if (li.T == 1)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu<real>), dim3(grid), dim3(64), sizeof(double) * li.N * (li.N | 1), st,
+                       orb, orb_width, logdet, sign_k, li);
   else if (li.N <= 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
                        sign_k, K, li);

@@ -116,3 +116,24 @@ def test_emu_rng_moments():
     moved = (st['r'].numpy() - r0)[acc.numpy()[0].astype(bool)].reshape(-1)
     assert moved.size > 300
     assert abs(moved.mean()) < 0.15 and 0.5 < moved.std() < 1.3
+
+
+def test_emu_value_slogdet_lu_n2():
+    """Value-only psi of N2 (14 electrons): the wave-per-matrix LU kernel (k_slogdet_lu: wave arg-max pivot
+    search, 8x8 trailing update) against numpy slogdet -- log|det| and the bit-exact sign of every determinant."""
+    import dataclasses
+    spec = dataclasses.replace(ferminet(), embedding_dim=16, n_interactions=1, n_determinants=3)
+    mol = Molecule.from_name('N2')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=2, perturb_envelopes=0.3)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    eng.set_option('fused', 0)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    val = it.run(r, mol.coords, laplacian=False)
+    sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+    np.testing.assert_array_equal(eng.debug_read('sign_k', B), it.sign_k)
+    np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-10, atol=1e-10)
+    np.testing.assert_array_equal(sign.numpy(), val['sign'])
+    np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)
