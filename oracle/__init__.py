@@ -17,7 +17,10 @@ Parity status: PINNED.  The oracle reproduces
   * its sampler goldens test_sampling/test_sampler_{init,sample}_{Metropolis,DecorrMetropolis}_.npz:
     psi of the 10 initial walkers, then 4 x sample(PRNGKey(step)) through oracle/sampling.py driven by
     the emulated jax.random.split/normal/uniform streams -- ages and tau exactly, positions to 1e-12.
-Not pinned: the Langevin sampler golden (sampler not restated), the electron initialiser
-(jax.random.categorical/orthogonal), hk.MultiHeadAttention / LayerNorm semantics (no reference test
-instantiates the Psiformer configs), ECP values (pyscf tables absent).
+  * the Langevin golden test_sampler_sample_Langevin_.npz the same way (oracle/sampling.py: langevin_step,
+    clean_force).
+Not pinned: the electron initialiser (jax.random.categorical/orthogonal), hk.MultiHeadAttention / LayerNorm /
+GLU semantics and the TransPsiformer's nuclei embedding / nuclear head (no reference test instantiates the
+Psiformer or TransPsiformer configs), ECP values (oracle/ecp.py restates the formulas; pyscf's coefficient
+tables are absent, so the reference's ECP goldens cannot be reproduced -- checked by properties instead).
 """
