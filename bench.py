@@ -114,6 +114,7 @@ def main():
     ap.add_argument('--ecp', action='store_true', help='Gaussian-type ECP on every atom heavier than He with SYNTHETIC '
                     'coefficients (pyscf tables are not available offline): exercises the 12 N n_ecp psi-ratio quadrature')
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
+    ap.add_argument('--fused-version', type=int, default=0, help='1: first fused kernel (in-kernel op interpreter); 2 (library default): descriptor driven')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
     ap.add_argument('--fused-occ', type=int, default=0, help='register budget of the fused kernel: workgroups per CU (2..4)')
@@ -145,6 +146,8 @@ def main():
     wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
+    if args.fused_version:
+        eng.set_option('fused_version', args.fused_version)
     if args.fused_sched >= 0:
         eng.set_option('fused_sched', args.fused_sched)
     if args.fused_occ:

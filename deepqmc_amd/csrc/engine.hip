@@ -132,6 +132,13 @@ struct Engine : dqmc_ctx {
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
+  // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
+  int fused_version = 2, fused2_WT = 0, fused2_shift = 0;
+  size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
+  std::vector<dqmc::FusedBuf> fbufs2_h;
+  dqmc::FDesc* d_descs = nullptr;
+  int32_t* d_wave_begin = nullptr;
+  dqmc::FusedBuf* d_fbufs2 = nullptr;
   // effective core potential (dqmc_set_ecp): local terms for k_final, non-local channels per nucleus
   double* d_ecp_loc = nullptr;
   double* d_ecp_nl = nullptr;
@@ -144,6 +151,9 @@ struct Engine : dqmc_ctx {
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
 
   ~Engine() override {
+    if (d_descs) (void)hipFree(d_descs);
+    if (d_wave_begin) (void)hipFree(d_wave_begin);
+    if (d_fbufs2) (void)hipFree(d_fbufs2);
     if (d_ecp_loc) (void)hipFree(d_ecp_loc);
     if (d_ecp_nl) (void)hipFree(d_ecp_nl);
     if (d_ecp_nuc) (void)hipFree(d_ecp_nuc);
@@ -265,14 +275,15 @@ struct Engine : dqmc_ctx {
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ = value; return DQMC_OK; }
+    if (s == "fused_version") { fused_version = value; return DQMC_OK; }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
       fused_dbg = value;
-      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80)));
+      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80 + 1024)));
       return DQMC_OK;
     }
-    if (s == "fused_lds_kb") { fused_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
+    if (s == "fused_lds_kb") { fused_lds_budget = fused2_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
     return fail(DQMC_E_ARG, "unknown option " + s);
   }
 
@@ -352,7 +363,7 @@ struct Engine : dqmc_ctx {
   size_t fused_meta_bytes() const {
     return (size_t)dqmc::fused_meta_bytes(fused_n_ops, (int)bufs.size());
   }
-  size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb) const {
+  size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb, bool with_meta = true) const {
     const int nb = (int)bufs.size(), no = fused_n_ops;
     const int BIG = 1 << 30;
     std::vector<int> first(nb, BIG), last(nb, -1);
@@ -369,7 +380,7 @@ struct Engine : dqmc_ctx {
     fb.assign(nb, dqmc::FusedBuf{});
     struct Seg { size_t off, len; int until; };
     std::vector<Seg> live;
-    const size_t base = fused_meta_bytes() / sizeof(real);
+    const size_t base = with_meta ? fused_meta_bytes() / sizeof(real) : 0;
     size_t peak = base;
     const int n_levels = no ? f_level[no - 1] + 1 : 0;
     for (int l = 0; l < n_levels; ++l) {
@@ -427,7 +438,135 @@ struct Engine : dqmc_ctx {
     for (int j = 0; j < fused_n_ops; ++j) sched[j] = ops[f_order[j]];
     HIP_TRY(hipMemcpy(d_ops, sched.data(), sizeof(dqmc_op) * fused_n_ops, hipMemcpyHostToDevice));
     if (dqmc::fused_set_lds_limit<real>(fused_lds) != 0) { fused_n_ops = 0; return DQMC_OK; }
-    return pack_fused_weights();
+    const int rc = pack_fused_weights();
+    if (rc) return rc;
+    return build_fused2_plan();
+  }
+
+  // Work lists of the descriptor-driven fused kernel (kernel_fused2.hip): the units of every linear layer,
+  // dealt to the 4 waves level by level (longest first onto the least loaded wave), structured ops for all
+  // waves, one barrier per dependency level.  Tile layout [row][WT] needs a power-of-two tile.
+  int build_fused2_plan() {
+    fused2_WT = 0;
+    if (fused_n_ops == 0) return DQMC_OK;
+    const int cand[] = {16, 8, 4, 2, 1};
+    std::vector<dqmc::FusedBuf> fb;
+    for (int WT : cand) {
+      if (fused_wt_req > 0 && WT != fused_wt_req) continue;
+      const size_t bytes = fused_layout(WT, fb, false);
+      if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused2_lds_budget)) { fused2_WT = WT; fused2_lds = bytes; break; }
+    }
+    if (fused2_WT == 0) return DQMC_OK;
+    const int WT = fused2_WT, n_waves = 4;
+    fused2_shift = 0;
+    while ((1 << fused2_shift) < WT) ++fused2_shift;
+    std::vector<int32_t> words(2 * (size_t)fused_n_ops);
+    HIP_TRY(hipMemcpy(words.data(), d_wpk_off, sizeof(int32_t) * words.size(), hipMemcpyDeviceToHost));
+    std::vector<std::vector<dqmc::FDesc>> lists(n_waves);
+    struct Unit { dqmc::FDesc d; long cost; };
+    std::vector<Unit> level_units;
+    std::vector<int> level_generic;
+    auto flush_level = [&]() {
+      std::stable_sort(level_units.begin(), level_units.end(), [](const Unit& x, const Unit& y) { return x.cost > y.cost; });
+      long load[4] = {0, 0, 0, 0};
+      for (const Unit& u : level_units) {
+        int best = 0;
+        for (int w = 1; w < n_waves; ++w) if (load[w] < load[best]) best = w;
+        lists[best].push_back(u.d);
+        load[best] += u.cost;
+      }
+      for (int j : level_generic)
+        for (int w = 0; w < n_waves; ++w) { dqmc::FDesc g{}; g.kind = 3; g.op = j; lists[w].push_back(g); }
+      for (int w = 0; w < n_waves; ++w) { dqmc::FDesc b{}; b.kind = 2; lists[w].push_back(b); }
+      level_units.clear(); level_generic.clear();
+    };
+    for (int j = 0; j < fused_n_ops; ++j) {
+      const dqmc_op& op = ops[f_order[j]];
+      const int32_t* i = op.i;
+      if (op.kind != DQMC_OP_LINEAR) {
+        level_generic.push_back(j);
+      } else {
+        const int ldw = pad4(i[21]), Rtot = WT * i[20];
+        const int NRB = (Rtot + 15) / 16, NCB = (ldw + 15) / 16, n_cg = (NCB + 1) / 2;
+        int rpu = NRB * n_cg / n_waves;
+        rpu = rpu < 1 ? 1 : (rpu > 4 ? 4 : rpu);
+        dqmc::FDesc t{};
+        t.kind = 1; t.op = j; t.n_pieces = i[0]; t.rtot = Rtot; t.ldw = ldw;
+        long kq = 0;
+        for (int p = 0; p < i[0]; ++p) {
+          const dqmc::FusedBuf& sb = fb[i[1 + 4 * p]];
+          if (sb.is_global) { fused2_WT = 0; return DQMC_OK; }
+          t.a_base[p] = sb.off + i[2 + 4 * p] * WT * sb.stride;
+          t.a_stride[p] = sb.stride;
+          t.a_ks[p] = pad4(i[3 + 4 * p]) / 4;
+          t.a_nq[p] = (t.a_ks[p] + 3) / 4;
+          if (i[4 + 4 * p]) t.bcast |= 1 << p;
+          kq += t.a_nq[p];
+        }
+        t.qstride = NCB * 64;
+        t.bias_off = i[23];
+        const dqmc::FusedBuf& db = fb[i[17]];
+        t.flags = (i[24] & 3) | (i[27] ? 4 : 0);
+        if (db.is_global) { t.flags |= 8; t.dst_base = i[17]; t.g_r0 = i[18]; t.g_col0 = i[19]; }
+        else { t.dst_base = db.off + i[18] * WT * db.stride + i[19]; t.dst_stride = db.stride; }
+        t.res_base = -1;
+        if (i[25] >= 0) {
+          const dqmc::FusedBuf& rb = fb[i[25]];
+          if (rb.is_global) { fused2_WT = 0; return DQMC_OK; }
+          t.res_base = rb.off + i[26] * WT * rb.stride + i[19];
+          t.res_stride = rb.stride;
+        }
+        for (int rb0 = 0; rb0 < NRB; rb0 += rpu)
+          for (int cg = 0; cg < n_cg; ++cg) {
+            Unit u{t, 0};
+            u.d.ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
+            u.d.row0 = rb0 * 16;
+            u.d.col0 = cg * 32;
+            u.d.w_off = words[2 * j] / 4 + (cg * 2) * 64;
+            u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
+            u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
+            level_units.push_back(u);
+          }
+      }
+      if (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) flush_level();
+    }
+    std::vector<dqmc::FDesc> flat;
+    int32_t begin[4];
+    for (int w = 0; w < n_waves; ++w) {
+      begin[w] = (int32_t)flat.size();
+      flat.insert(flat.end(), lists[w].begin(), lists[w].end());
+      dqmc::FDesc e{}; e.kind = 0; flat.push_back(e);
+    }
+    if (d_descs) { HIP_TRY(hipFree(d_descs)); d_descs = nullptr; }
+    HIP_TRY(hipMalloc((void**)&d_descs, sizeof(dqmc::FDesc) * flat.size()));
+    if (!d_wave_begin) HIP_TRY(hipMalloc((void**)&d_wave_begin, sizeof(int32_t) * 4));
+    if (!d_fbufs2) HIP_TRY(hipMalloc((void**)&d_fbufs2, sizeof(dqmc::FusedBuf) * bufs.size()));
+    HIP_TRY(hipMemcpy(d_descs, flat.data(), sizeof(dqmc::FDesc) * flat.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_wave_begin, begin, sizeof(begin), hipMemcpyHostToDevice));
+    fbufs2_h = fb;
+    if (dqmc::fused2_set_lds_limit<real>(fused2_lds) != 0) { fused2_WT = 0; return DQMC_OK; }
+    return DQMC_OK;
+  }
+
+  int run_fused2(const real* r, const real* R, int B, dqmc::LaneInfo li) {
+    for (size_t b = 0; b < bufs.size(); ++b) fbufs2_h[b].goff = (long)buf_off[b];
+    HIP_TRY(hipMemcpyAsync(d_fbufs2, fbufs2_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
+    dqmc::Fused2Args<real> a{};
+    a.descs = d_descs; a.wave_begin = d_wave_begin; a.ops = d_ops; a.fbufs = d_fbufs2;
+    a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
+    a.B = B; a.WT = fused2_WT; a.wt_shift = fused2_shift; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det;
+    a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
+    double flops = 0;
+    for (int k = 0; k < fused_n_ops; ++k)
+      if (ops[k].kind == DQMC_OP_LINEAR) {
+        int ktot = 0;
+        for (int p = 0; p < ops[k].i[0]; ++p) ktot += ops[k].i[3 + 4 * p];
+        flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
+      }
+    t_begin("fused_psi", flops);
+    dqmc::launch_fused2_value<real>(st, a, (B + fused2_WT - 1) / fused2_WT, fused2_lds, fused_occ);
+    t_end();
+    return DQMC_OK;
   }
 
   // Fragment-major copy of the Linear weights: [k/4][column block][lane] so that one wave load
@@ -526,7 +665,7 @@ struct Engine : dqmc_ctx {
     if (rc) return rc;
     size_t first_op = 0;
     if (!laplacian && fused_enabled && fused_n_ops > 0) {
-      rc = run_fused(r, R, B, li);
+      rc = (fused_version >= 2 && fused2_WT > 0) ? run_fused2(r, R, B, li) : run_fused(r, R, B, li);
       if (rc) return rc;
       first_op = (size_t)fused_n_ops;
     }
@@ -803,7 +942,7 @@ struct Engine : dqmc_ctx {
       return DQMC_OK;
     }
     if (buf == -3) {   // per-op shader-clock stamps of the fused kernel (workgroup 0)
-      if (!d_prof || n > 9 * ops.size() + 80) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
+      if (!d_prof || n > 9 * ops.size() + 80 + 1024) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
       std::vector<long long> tmp(n);
       HIP_TRY(hipMemcpy(tmp.data(), d_prof, sizeof(long long) * n, hipMemcpyDeviceToHost));
       for (size_t k = 0; k < n; ++k) out[k] = (double)tmp[k];

@@ -1,0 +1,414 @@
+// kernel_fused2.hip -- value-only psi evaluation (the Metropolis hot loop) as ONE kernel, descriptor driven.
+//
+// Same job as kernel_fused.hip (a workgroup owns a tile of WT walkers and runs the whole layer program
+// on it with every activation resident in LDS; reference sampling/electron_samplers.py:76-81 vmap(wf)),
+// but everything that is identical for all workgroups is decided on the HOST once per program
+// (engine.hip: build_fused2_plan) instead of being recomputed by every wave of every workgroup:
+//
+//   * the linear layers are cut into units (row blocks x 2 column blocks) and the units of a dependency
+//     level are dealt to the 4 waves by cost; each wave walks its own list of 160-byte unit descriptors
+//     (LDS offsets and strides of every concat piece, packed-weight offset, destination, flags).  The
+//     descriptors sit in the constant address space, so they arrive through scalar loads into SGPRs --
+//     no per-lane metadata traffic, no integer division, no LDS copy of the program;
+//   * waves skip the ops they have no unit of; only level boundaries carry a workgroup barrier;
+//   * tile layout: element (walker wl, row, col) of a buffer at off + (row*WT + wl)*stride + col with WT a
+//     power of two, so the MFMA row index m = row*WT + wl addresses every piece, residual and destination
+//     as an affine function (broadcast pieces: m & (WT-1)), and stride = width + 2 keeps the 16 rows x 2 k
+//     of a half-wave fragment read on 32 distinct banks.
+//
+// The SQ counters and clock stamps of the first fused kernel (profiles/r01_pmc_sq_counters_fused_wt4.json,
+// DESIGN.md section 4) showed ~3.4 k cycles of such setup per unit against ~1.2 k cycles of MFMA work.
+#include "common.h"
+#include "kernels.h"
+
+#if defined(__HIPCC__)
+#define DQMC_UNIFORM __attribute__((address_space(4)))   // constant address space: uniform loads are scalar
+#else
+#define DQMC_UNIFORM
+#endif
+
+namespace dqmc {
+
+typedef const DQMC_UNIFORM FDesc* DescPtr;
+typedef const DQMC_UNIFORM FusedBuf* BufPtr;
+typedef const DQMC_UNIFORM ::dqmc_op* OpPtr;
+
+template <typename real> __device__ __forceinline__ real act2_value(int act, real v) {
+  if (act == 1) return r_tanh<real>(v);
+  if (act == 2) return v / (1 + r_exp<real>(-v));
+  return v;
+}
+
+// One unit: MA row blocks x 2 column blocks of y = act(concat(pieces) W + b) (+ residual) on the tile.
+template <typename real, int MA>
+__device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  typedef typename Mfma<real>::acc_t acc_t;
+  constexpr int NRW = 2;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
+  const int wtm1 = a.WT - 1;
+  int mrow[MA];
+#pragma unroll
+  for (int x = 0; x < MA; ++x) {
+    const int m = row0 + x * 16 + l15;
+    mrow[x] = m < rtot ? m : row0;                          // dummy rows read a valid row, dropped at the store
+  }
+  acc_t acc[MA][NRW];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
+  const int bias_off = d->bias_off;
+  real bias_v[NRW];
+#pragma unroll
+  for (int y = 0; y < NRW; ++y) {
+    const int col = col_u + y * 16 + l15;
+    bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : (real)0;
+  }
+  const Vec4<real>* wbase = reinterpret_cast<const Vec4<real>*>(a.wpk) + d->w_off + lane;
+  const int cb1 = d->w_cb1, qstride = d->qstride, bcast = d->bcast, n_pieces = d->n_pieces;
+  int q0 = 0;
+  for (int p = 0; p < n_pieces; ++p) {
+    const int base = d->a_base[p], stride = d->a_stride[p], KS = d->a_ks[p], NQ = d->a_nq[p];
+    const bool bc = (bcast >> p) & 1;
+    int ao[MA];
+#pragma unroll
+    for (int x = 0; x < MA; ++x) ao[x] = base + (bc ? (mrow[x] & wtm1) : mrow[x]) * stride + l4;
+    // B fragments: one 16-byte load per lane = 4 consecutive k-steps of one 16-column block (fragment-major,
+    // quad-interleaved packing, engine.hip: pack_fused_weights); a ring of D quads stays in flight to cover
+    // the L2 round trip, A fragments (LDS) run one quad ahead.
+    constexpr int D = 4;
+    const Vec4<real>* wq0 = wbase + (long)q0 * qstride;
+    const Vec4<real>* wq1 = wq0 + cb1;
+    Vec4<real> ring[D][NRW];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) {
+      if (dd < NQ) {                               // wave-uniform; short layers load only what they use
+        ring[dd][0] = wq0[(long)dd * qstride];
+        ring[dd][1] = wq1[(long)dd * qstride];
+      }
+    }
+    real fan[4][MA];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ks = kk < KS ? kk : KS - 1;
+#pragma unroll
+      for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+    }
+    for (int q = 0; q < NQ; q += D) {
+#pragma unroll
+      for (int dd = 0; dd < D; ++dd) {
+        if (q + dd < NQ) {                         // wave-uniform
+          Vec4<real> cur[NRW];
+          cur[0] = ring[dd][0]; cur[1] = ring[dd][1];
+          if (q + dd + D < NQ) {
+            ring[dd][0] = wq0[(long)(q + dd + D) * qstride];
+            ring[dd][1] = wq1[(long)(q + dd + D) * qstride];
+          }
+          real fa[4][MA];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {         // A fragments of the next quad (clamped past the end)
+            int ks = (q + dd + 1) * 4 + kk;
+            ks = ks < KS ? ks : KS - 1;
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) {
+              acc[x][0] = Mfma<real>::run(fa[kk][x], cur[0].v[kk], acc[x][0]);
+              acc[x][1] = Mfma<real>::run(fa[kk][x], cur[1].v[kk], acc[x][1]);
+            }
+        }
+      }
+    }
+    q0 += NQ;
+  }
+  // ---- epilogue: bias + activation + residual, store to LDS (or HBM for buffers later kernels read) ----
+  const int flags = d->flags, act = flags & 3;
+  const bool dst_global = (flags & 8) != 0;
+  const real res_scale = (flags & 4) ? (real)0.70710678118654752440 : (real)1;
+  const int res_base = d->res_base;
+  int colv[NRW];
+  bool c_ok[NRW];
+#pragma unroll
+  for (int y = 0; y < NRW; ++y) {
+    colv[y] = col_u + y * 16 + l15;
+    c_ok[y] = colv[y] < ldw;
+    if (!c_ok[y]) colv[y] = col_u;
+  }
+  int m_e[MA][4];
+  bool r_ok[MA][4];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) {
+      const int m = row0 + x * 16 + Mfma<real>::row_of(lane, rgi);
+      r_ok[x][rgi] = m < rtot;
+      m_e[x][rgi] = r_ok[x][rgi] ? m : row0;
+    }
+  real ov[MA][4][NRW];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+      for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = acc[x][y][rgi] + bias_v[y];
+  if (act == 1) {                                  // wave-uniform: one branch around the whole batch
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = r_tanh<real>(ov[x][rgi][y]);
+  } else if (act == 2) {
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = act2_value<real>(2, ov[x][rgi][y]);
+  }
+  if (res_base >= 0) {
+    const int rs = d->res_stride;
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y)
+          ov[x][rgi][y] = (smem[res_base + m_e[x][rgi] * rs + colv[y]] + ov[x][rgi][y]) * res_scale;
+  }
+  if (!dst_global) {
+    const int db = d->dst_base, ds = d->dst_stride;
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+        for (int y = 0; y < NRW; ++y)
+          if (r_ok[x][rgi] && c_ok[y]) smem[db + m_e[x][rgi] * ds + colv[y]] = ov[x][rgi][y];
+  } else {
+    // walker-major HBM layout [B][rows][width]; m = rr*WT + wl
+    const BufPtr fb = (BufPtr)a.fbufs + d->dst_base;
+    const int rows = fb->rows, width = fb->width, g_r0 = d->g_r0, g_col0 = d->g_col0, sh = a.wt_shift;
+    real* dst_g = reinterpret_cast<real*>(a.ws + fb->goff) + (long)blockIdx.x * a.WT * rows * width;
+#pragma unroll
+    for (int x = 0; x < MA; ++x)
+#pragma unroll
+      for (int rgi = 0; rgi < 4; ++rgi) {
+        const int m = m_e[x][rgi], wl = m & wtm1, rr = m >> sh;
+#pragma unroll
+        for (int y = 0; y < NRW; ++y)
+          if (r_ok[x][rgi] && c_ok[y] && blockIdx.x * a.WT + wl < a.B)
+            dst_g[((long)wl * rows + g_r0 + rr) * width + g_col0 + colv[y]] = ov[x][rgi][y];
+      }
+  }
+}
+
+// Structured ops (pair features, spin means, convolutions, sums, envelopes): all threads of the
+// workgroup, element-parallel.  Tile element (wl, row, col) of buffer b: off + (row*WT + wl)*stride + col.
+template <typename real>
+__device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr op, int nw) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int WT = a.WT, sh = a.wt_shift, wtm1 = WT - 1;
+  const int N = a.li.N, n_up = a.n_up, n_nuc = a.n_nuc, K = a.K;
+  const real* r = a.r + (long)blockIdx.x * WT * N * 3;
+  const BufPtr fbs = (BufPtr)a.fbufs;
+  const int kind = op->kind;
+  LaneInfo li = a.li;   // T = TP = 1
+  // Elements are enumerated walker-fastest (e = rest*WT + wl) so neighbouring threads touch neighbouring
+  // LDS rows of the same column; walkers beyond the batch (wl >= nw) are skipped.
+  switch (kind) {
+    case DQMC_OP_FEAT_EN: {
+      const BufPtr x = fbs + op->i[0];
+      const int xo = x->off, xs = x->stride, xw = x->width, lr = op->i[1], sp = op->i[2];
+      for (int e = tid; e < N * n_nuc * WT; e += nthr) {
+        const int wl = e & wtm1, q = e >> sh;
+        const int el = q / n_nuc, n = q - el * n_nuc;
+        if (wl >= nw) continue;
+        double dd[3], f[4];
+        for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c];
+        pair_feature_lane(dd, a.eps, el, -1, 0, li, lr != 0, f);
+        const int row = xo + (el * WT + wl) * xs;
+        for (int c = 0; c < 4; ++c) smem[row + 4 * n + c] = (real)f[c];
+        if (n == 0) {
+          int c = 4 * n_nuc;
+          if (sp) smem[row + c++] = (real)(el < n_up ? 1.0 : -1.0);
+          for (; c < xw; ++c) smem[row + c] = (real)0;
+        }
+      }
+      break;
+    }
+    case DQMC_OP_FEAT_EE: {
+      const BufPtr eb = fbs + op->i[0];
+      const int eo = eb->off, es = eb->stride, n_rows = op->i[2], lr = op->i[3];
+      const int32_t* pairs = a.itable + op->i[1];
+      for (int e = tid; e < n_rows * WT; e += nthr) {
+        const int wl = e & wtm1, kr = e >> sh;
+        if (wl >= nw) continue;
+        const int rc = pairs[2 * kr], sd = pairs[2 * kr + 1];
+        double dd[3], f[4];
+        for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + rc) * 3 + c] - (double)r[(wl * N + sd) * 3 + c];
+        pair_feature_lane(dd, a.eps, rc, sd, 0, li, lr != 0, f);
+        const int row = eo + (kr * WT + wl) * es;
+        for (int c = 0; c < 4; ++c) smem[row + c] = (real)f[c];
+      }
+      break;
+    }
+    case DQMC_OP_SPIN_MEAN: {
+      const BufPtr x = fbs + op->i[0];
+      const BufPtr m = fbs + op->i[1];
+      const int xo = x->off, xs = x->stride, W = x->width, mo = m->off, ms = m->stride;
+      for (int e = tid; e < W * 2 * WT; e += nthr) {
+        const int wl = e & wtm1, q = e >> sh;
+        const int which = q & 1, c = q >> 1;
+        const int i0 = which ? n_up : 0, i1 = which ? N : n_up;
+        real acc = 0;
+        for (int el = i0; el < i1; ++el) acc += smem[xo + (el * WT + wl) * xs + c];
+        smem[mo + (which * WT + wl) * ms + c] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
+      }
+      break;
+    }
+    case DQMC_OP_CONV:
+    case DQMC_OP_EDGE_SUM: {
+      const bool conv = kind == DQMC_OP_CONV;
+      const BufPtr we = fbs + op->i[0];
+      const BufPtr out = fbs + op->i[2];
+      const BufPtr hx = conv ? fbs + op->i[1] : we;
+      const int wo = we->off, ws_ = we->stride, ho = hx->off, hs = hx->stride, oo = out->off, os = out->stride;
+      const real scale = conv ? (real)1 : (real)(1.0 / (double)(op->i[1] > 0 ? op->i[1] : 1));
+      const int32_t* tab = a.itable + op->i[4];
+      const int S = op->i[5], W = op->i[6], col0 = op->i[3];
+      for (int e = tid; e < N * W * WT; e += nthr) {
+        const int wl = e & wtm1, q = e >> sh;
+        const int el = q / W, c = q - el * W;
+        real acc = 0;
+        for (int s = 0; s < S; ++s) {
+          const int row = tab[2 * (el * S + s)], snd = tab[2 * (el * S + s) + 1];
+          if (row < 0) continue;
+          const real ev = smem[wo + (row * WT + wl) * ws_ + c];
+          acc += conv ? ev * smem[ho + (snd * WT + wl) * hs + c] : ev;
+        }
+        smem[oo + (el * WT + wl) * os + col0 + c] = acc * scale;
+      }
+      break;
+    }
+    case DQMC_OP_ROW_SUM: {
+      const BufPtr x = fbs + op->i[0];
+      const BufPtr s = fbs + op->i[1];
+      const int xo = x->off, xs = x->stride, W = x->width, rows = x->rows, so = s->off, ss = s->stride;
+      for (int e = tid; e < W * WT; e += nthr) {
+        const int wl = e & wtm1, c = e >> sh;
+        real acc = 0;
+        for (int el = 0; el < rows; ++el) acc += smem[xo + (el * WT + wl) * xs + c];
+        smem[so + wl * ss + c] = acc;
+      }
+      break;
+    }
+    case DQMC_OP_ORBITALS: {
+      const BufPtr bf = fbs + op->i[0];
+      const BufPtr orb = fbs + op->i[1];
+      const int bo = bf->off, bs = bf->stride, ow = orb->width;
+      real* orb_g = reinterpret_cast<real*>(a.ws + orb->goff) + (long)blockIdx.x * WT * orb->rows * ow;
+      const int KN = K * N;
+      const int n_env = op->i[6] > 0 ? op->i[6] : 1;          // envelopes per nucleus (kernels_head.hip: k_orbitals)
+      const int o_pu = op->i[2], o_pd = op->i[3], o_zu = op->i[4], o_zd = op->i[5];
+      for (int e = tid; e < N * KN * WT; e += nthr) {
+        const int wl = e & wtm1, q = e >> sh;
+        const int el = q / KN, kmu = q - el * KN;
+        if (wl >= nw) continue;
+        const int kd = kmu / N, mu = kmu - kd * N;
+        const real* pi = a.w + (el < n_up ? o_pu : o_pd) + kmu * n_nuc * n_env;
+        const real* ze = a.w + (el < n_up ? o_zu : o_zd) + kmu * n_nuc * n_env;
+        const real b0 = smem[bo + (el * WT + wl) * bs + kmu];
+        real res;
+        if (sizeof(real) == 4) {        // float32 build: exponentials on the f32 unit (as k_orbitals, T = 1)
+          float acc = 0.f;
+          for (int n = 0; n < n_nuc; ++n) {
+            float d2 = (float)a.eps;
+            for (int c = 0; c < 3; ++c) { const float dx = (float)r[(wl * N + el) * 3 + c] - (float)a.R[n * 3 + c]; d2 += dx * dx; }
+            const float rho = sqrtf(d2);
+            for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[n * n_env + ev] * expf(-fabsf((float)ze[n * n_env + ev]) * rho);
+          }
+          res = (real)(acc * (float)b0);
+        } else {
+          double e0 = 0;
+          for (int n = 0; n < n_nuc; ++n) {
+            double d2 = a.eps;
+            for (int c = 0; c < 3; ++c) { const double dx = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += dx * dx; }
+            const double rho = sqrt(d2);
+            for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
+          }
+          res = (real)(e0 * (double)b0);
+        }
+        orb_g[(wl * K + kd) * ow + el * N + mu] = res;
+      }
+      break;
+    }
+    default:
+      break;
+  }
+}
+
+template <typename real>
+__device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
+#if defined(__HIPCC__)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#else
+  const int wave = (int)(threadIdx.x >> 6);
+#endif
+  const int w0 = blockIdx.x * a.WT;
+  const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
+  DescPtr d = (DescPtr)a.descs + ((const DQMC_UNIFORM int32_t*)a.wave_begin)[wave];
+  const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
+  int n_d = 0;
+  if (stamp) a.prof[wave * 256] = clock64();
+  for (;; ++d) {
+    const int kind = d->kind;
+    if (kind == 0) break;
+    if (kind == 2) {
+      __syncthreads();
+    } else if (kind == 1) {
+      const int ma = d->ma;
+      if (ma == 1) fused2_unit<real, 1>(a, d);
+      else if (ma == 2) fused2_unit<real, 2>(a, d);
+      else if (ma == 3) fused2_unit<real, 3>(a, d);
+      else fused2_unit<real, 4>(a, d);
+    } else {
+      fused2_generic<real>(a, (OpPtr)a.ops + d->op, nw);
+    }
+    if (stamp && n_d < 254) a.prof[wave * 256 + (++n_d)] = clock64();
+  }
+}
+
+// OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.
+template <typename real, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_fused2_value(const Fused2Args<real> a) { fused2_body<real>(a); }
+
+template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ) {
+  const dim3 g((unsigned)n_blocks), b(256);
+  if (occ >= 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 3>), g, b, lds_bytes, st, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 2>), g, b, lds_bytes, st, a);
+}
+template <typename real> int fused2_set_lds_limit(size_t lds_bytes) {
+  int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  return rc;
+}
+
+template void launch_fused2_value<float>(hipStream_t, const Fused2Args<float>&, int, size_t, int);
+template void launch_fused2_value<double>(hipStream_t, const Fused2Args<double>&, int, size_t, int);
+template int fused2_set_lds_limit<float>(size_t);
+template int fused2_set_lds_limit<double>(size_t);
+
+}  // namespace dqmc

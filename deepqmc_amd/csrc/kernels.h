@@ -90,6 +90,54 @@ __host__ __device__ inline int fused_meta_bytes(int n_ops, int n_bufs) {
 template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes, int occ);
 template <typename real> int fused_set_lds_limit(size_t lds_bytes);
 
+// ---- kernel_fused2.hip: descriptor-driven variant (the default) ----
+// One entry of a wave's work list; built on the host (engine.hip: build_fused2_plan), read through scalar loads.
+struct FDesc {
+  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves)
+  int32_t op;           // scheduled op index (FusedArgs::ops)
+  int32_t ma;           // row blocks of the unit (1..4); column blocks are always 2
+  int32_t n_pieces;
+  int32_t row0;         // first tile row m = row*WT + wl of the unit
+  int32_t rtot;         // rows of the segment in the tile (WT * nrows)
+  int32_t col0;         // first output column of the unit
+  int32_t ldw;          // padded output width of the layer
+  int32_t a_base[4];    // LDS offset of segment row m = 0 of concat piece p
+  int32_t a_stride[4];
+  int32_t a_ks[4];      // k-steps (pad4(K)/4)
+  int32_t a_nq[4];      // quads of 4 k-steps
+  int32_t bcast;        // bit p: piece p is one row per walker (row index m & (WT-1))
+  int32_t w_off;        // Vec4 index of (quad 0, first column block of the unit, lane 0) in the packed weights
+  int32_t w_cb1;        // Vec4 distance to the second column block (0: none, re-read the first)
+  int32_t qstride;      // Vec4 per quad of k-steps
+  int32_t bias_off;     // into the plain weight buffer, or -1
+  int32_t dst_base;     // LDS offset of (segment row 0, col0_dst); HBM destination: buffer index
+  int32_t dst_stride;
+  int32_t res_base;     // LDS offset of (residual segment row 0, col0_dst), or -1
+  int32_t res_stride;
+  int32_t flags;        // bits 0-1 activation, bit 2 scale by 1/sqrt(2), bit 3 destination in HBM
+  int32_t g_r0, g_col0; // HBM destination: first row / column
+  int32_t pad[4];
+};
+static_assert(sizeof(FDesc) == 160, "FDesc is 40 dwords");
+template <typename real> struct Fused2Args {
+  const FDesc* descs;       // device: the four wave lists, concatenated
+  const int32_t* wave_begin; // device int[4]: first descriptor of each wave
+  const ::dqmc_op* ops;     // device: the scheduled ops (structured ops read their fields from here)
+  const FusedBuf* fbufs;    // device: LDS offset / stride (tile layout [row][WT]) or HBM offset per buffer
+  const real* w;
+  const real* wpk;
+  const int32_t* itable;
+  char* ws;
+  const real* r;
+  const real* R;
+  int B, WT, wt_shift, n_up, n_nuc, K;
+  long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
+  LaneInfo li;
+  double eps;
+};
+template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ);
+template <typename real> int fused2_set_lds_limit(size_t lds_bytes);
+
 // ---- kernel_attention.hip ----
 // returns 0, or -1 if the (N, head_dim) tile set does not fit the 160 KiB LDS, -2 on a HIP error
 template <typename real>
