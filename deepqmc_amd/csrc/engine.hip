@@ -123,7 +123,7 @@ struct Engine : dqmc_ctx {
   bool fused_enabled = true;
   // measured on MI355X (LiH/PauliNet, 4096 walkers): full dependency levels + 4-walker tiles
   // (2 workgroups per CU) is the fastest configuration of the latency-bound fused kernel
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 1, fused_occ = 2;
+  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 3, fused_occ = 2, fused_occ_req = 0;
   size_t fused_lds = 0, fused_lds_budget = 80 * 1024, wpk_cap = 0;
   std::vector<dqmc::FusedBuf> fbufs_h;
   std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
@@ -133,7 +133,9 @@ struct Engine : dqmc_ctx {
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
-  int fused_version = 2, fused2_WT = 0, fused2_shift = 0;
+  int fused_version = 2, fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4;
+  size_t fused_sched_budget = 36 * 1024;   // bytes live per level the list scheduler (mode 3) aims for
+  const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   dqmc::FDesc* d_descs = nullptr;
@@ -274,8 +276,14 @@ struct Engine : dqmc_ctx {
     const std::string s(name);
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
-    if (s == "fused_occ") { fused_occ = value; return DQMC_OK; }
+    if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
+    if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
+    if (s == "fused_print") {   // plan summary on stderr (tuning aid)
+      fprintf(stderr, "[dqmc] fused plan: v1 WT=%d lds=%zu B; v2 WT=%d lds=%zu B; %d fused ops, %d levels\n", fused_WT, fused_lds,
+              fused2_WT, fused2_lds, fused_n_ops, fused_n_ops ? f_level[fused_n_ops - 1] + 1 : 0);
+      return DQMC_OK;
+    }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
@@ -351,6 +359,80 @@ struct Engine : dqmc_ctx {
         for (int b : rd) if (wlevel[b] >= 0 && lvl[k] <= wlevel[b]) { lvl[k] = wlevel[b] + 1; changed = true; }
       }
     }
+    if (fused_sched_mode == 3) {
+      // List scheduling under an LDS budget: level by level, ops on the critical path (no slack against the
+      // as-late-as-possible levels) are placed unconditionally, the others -- in program order -- only while
+      // the bytes live in the level stay under the budget.  Gives (nearly) the short critical path of the full
+      // levels with (nearly) the footprint of program order, i.e. one more co-resident workgroup per CU.
+      int L = 0;
+      for (int k = 0; k < no; ++k) L = lvl[k] + 1 > L ? lvl[k] + 1 : L;
+      std::vector<int> alap(no, L - 1), rlevel(nb, L);
+      for (int k = no - 1; k >= 0; --k) {
+        op_io(ops[k], rd, wr);
+        int l = L - 1;
+        for (int b : wr) if (rlevel[b] - 1 < l) l = rlevel[b] - 1;
+        if (l < lvl[k]) l = lvl[k];
+        alap[k] = l;
+        for (int b : rd) if (l < rlevel[b]) rlevel[b] = l;
+      }
+      // per buffer: writers, readers; global buffers (read after the fused range) cost no LDS
+      std::vector<std::vector<int>> writers(nb), readers(nb);
+      for (int k = 0; k < no; ++k) { op_io(ops[k], rd, wr); for (int b : wr) writers[b].push_back(k); for (int b : rd) readers[b].push_back(k); }
+      std::vector<char> is_glob(nb, 0);
+      for (int k = no; k < (int)ops.size(); ++k) { op_io(ops[k], rd, wr); for (int b : rd) is_glob[b] = 1; }
+      const int WTl = fused_sched_wt > 0 ? fused_sched_wt : 4;
+      auto blen = [&](int b) { return is_glob[b] ? (size_t)0 : sizeof(real) * (((size_t)WTl * bufs[b].rows * (bufs[b].width + 2) + 3) / 4 * 4); };
+      std::vector<int> sched(no, -1);
+      int n_done = 0, delay = 0;
+      for (int l = 0; n_done < no; ++l) {
+        auto ready = [&](int k) {
+          op_io(ops[k], rd, wr);
+          for (int b : rd) for (int w : writers[b]) if (sched[w] < 0 || sched[w] >= l) return false;
+          return true;
+        };
+        auto live_bytes = [&]() {       // buffers with a scheduled writer and a reader not scheduled before level l
+          size_t tot = 0;
+          for (int b = 0; b < nb; ++b) {
+            bool written = false, needed = false;
+            for (int w : writers[b]) written = written || sched[w] >= 0;
+            if (!written) continue;
+            for (int rr : readers[b]) needed = needed || sched[rr] < 0 || sched[rr] >= l;
+            for (int w : writers[b]) needed = needed || sched[w] == l || sched[w] < 0;
+            if (needed) tot += blen(b);
+          }
+          return tot;
+        };
+        std::vector<int> cand;
+        for (int k = 0; k < no; ++k) if (sched[k] < 0 && ready(k)) cand.push_back(k);
+        int placed_now = 0;
+        std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return alap[x] < alap[y]; });   // least slack first
+        for (int k : cand) {
+          sched[k] = l;
+          if (live_bytes() <= fused_sched_budget) { ++n_done; ++placed_now; }
+          else sched[k] = -1;
+        }
+        if (placed_now == 0 && !cand.empty()) { sched[cand[0]] = l; ++n_done; }   // budget too small: make progress
+        (void)delay;
+      }
+      lvl = sched;
+    }
+    if (fused_sched_mode == 2) {
+      // As late as possible within the same number of levels: ops with slack (the edge-stream MLPs, which do
+      // not depend on the node stream) move next to their consumers, which shortens buffer live ranges and
+      // so the LDS footprint of a tile (what decides how many workgroups share a CU).
+      int L = 0;
+      for (int k = 0; k < no; ++k) L = lvl[k] + 1 > L ? lvl[k] + 1 : L;
+      std::vector<int> alap(no, L - 1), rlevel(nb, L);     // rlevel[b]: earliest level of a reader of b
+      for (int k = no - 1; k >= 0; --k) {
+        op_io(ops[k], rd, wr);
+        int l = L - 1;
+        for (int b : wr) if (rlevel[b] - 1 < l) l = rlevel[b] - 1;
+        if (l < lvl[k]) l = lvl[k];
+        alap[k] = l;
+        for (int b : rd) if (l < rlevel[b]) rlevel[b] = l;
+      }
+      lvl = alap;
+    }
     f_order.resize(no);
     for (int k = 0; k < no; ++k) f_order[k] = k;
     std::stable_sort(f_order.begin(), f_order.end(), [&](int x, int y) { return lvl[x] < lvl[y]; });
@@ -378,32 +460,45 @@ struct Engine : dqmc_ctx {
       for (int b : rd) last[b] = BIG;
     }
     fb.assign(nb, dqmc::FusedBuf{});
-    struct Seg { size_t off, len; int until; };
-    std::vector<Seg> live;
+    // Placement = interval colouring: buffers in decreasing size, each at the lowest offset that does not
+    // overlap an already placed buffer whose live range [first, last] intersects its own (largest-first beats
+    // first-fit-in-time by ~10 % here, which decides how many workgroups share a CU).
+    struct Seg { size_t off, len; int a, b; };
+    std::vector<Seg> placed;
     const size_t base = with_meta ? fused_meta_bytes() / sizeof(real) : 0;
     size_t peak = base;
-    const int n_levels = no ? f_level[no - 1] + 1 : 0;
-    for (int l = 0; l < n_levels; ++l) {
-      for (size_t q = 0; q < live.size();)
-        if (live[q].until < l) live.erase(live.begin() + q); else ++q;
-      for (int b = 0; b < nb; ++b) {
-        if (first[b] != l) continue;
-        dqmc::FusedBuf& f = fb[b];
-        f.rows = bufs[b].rows; f.width = bufs[b].width;
-        if (last[b] == BIG) { f.is_global = 1; continue; }
-        f.is_global = 0;
-        f.stride = bufs[b].width + 2;
-        const size_t len = ((size_t)WT * f.rows * f.stride + 3) / 4 * 4;
-        size_t off = base;
-        for (bool moved = true; moved;) {
-          moved = false;
-          for (const Seg& s : live)
-            if (off < s.off + s.len && s.off < off + len) { off = s.off + s.len; moved = true; }
-        }
-        f.off = (int)off;
-        live.push_back(Seg{off, len, last[b]});
-        if (off + len > peak) peak = off + len;
+    std::vector<int> order;
+    for (int b = 0; b < nb; ++b) {
+      if (first[b] == BIG) continue;            // not touched by the fused range
+      dqmc::FusedBuf& f = fb[b];
+      f.rows = bufs[b].rows; f.width = bufs[b].width;
+      if (last[b] == BIG) { f.is_global = 1; continue; }
+      f.is_global = 0;
+      f.stride = bufs[b].width + 2;
+      order.push_back(b);
+    }
+    auto len_of = [&](int b) { return ((size_t)WT * fb[b].rows * fb[b].stride + 3) / 4 * 4; };
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return len_of(x) > len_of(y); });
+    if (getenv("DQMC_FUSED_VERBOSE")) {
+      const int n_levels = no ? f_level[no - 1] + 1 : 0;
+      for (int l = 0; l < n_levels; ++l) {
+        size_t live = 0;
+        std::string who;
+        for (int b : order) if (first[b] <= l && l <= last[b]) { live += len_of(b); who += " " + std::to_string(b) + ":" + std::to_string(len_of(b) * sizeof(real)); }
+        fprintf(stderr, "[dqmc] WT=%d level %d live %zu B:%s\n", WT, l, live * sizeof(real), who.c_str());
       }
+    }
+    for (int b : order) {
+      const size_t len = len_of(b);
+      size_t off = base;
+      for (bool moved = true; moved;) {
+        moved = false;
+        for (const Seg& s : placed)
+          if (s.a <= last[b] && first[b] <= s.b && off < s.off + s.len && s.off < off + len) { off = s.off + s.len; moved = true; }
+      }
+      fb[b].off = (int)off;
+      placed.push_back(Seg{off, len, first[b], last[b]});
+      if (off + len > peak) peak = off + len;
     }
     return peak * sizeof(real);
   }
@@ -417,7 +512,19 @@ struct Engine : dqmc_ctx {
     }
     if (n_f < 0) return DQMC_OK;
     fused_n_ops = n_f;
-    fused_schedule();
+    if (fused_sched_mode == 3) {
+      // largest per-level budget (= fewest levels) whose packed 4-walker tile leaves room for 4 workgroups per CU
+      bool fit = false;
+      for (int kb = 44; kb >= 24 && !fit; --kb) {
+        fused_sched_budget = (size_t)kb * 1024;
+        fused_schedule();
+        std::vector<dqmc::FusedBuf> fbt;
+        fit = fused_layout(4, fbt, false) <= fused2_lds_quarter;
+      }
+      if (!fit) { fused_sched_mode = 1; fused_schedule(); fused_sched_mode = 3; }   // too big for that: full levels
+    } else {
+      fused_schedule();
+    }
     fused_WT = 0;
     const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
     for (int WT : cand) {
@@ -451,10 +558,16 @@ struct Engine : dqmc_ctx {
     if (fused_n_ops == 0) return DQMC_OK;
     const int cand[] = {16, 8, 4, 2, 1};
     std::vector<dqmc::FusedBuf> fb;
-    for (int WT : cand) {
-      if (fused_wt_req > 0 && WT != fused_wt_req) continue;
-      const size_t bytes = fused_layout(WT, fb, false);
-      if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused2_lds_budget)) { fused2_WT = WT; fused2_lds = bytes; break; }
+    if (fused_wt_req <= 0 && fused_layout(4, fb, false) <= fused2_lds_quarter) {
+      // 4 walkers per tile and 4 tiles per CU: for the batch sizes of the north star (4096 walkers = 1024 tiles =
+      // 256 CUs x 4) the whole batch is ONE round of co-resident workgroups (measured fastest)
+      fused2_WT = 4; fused2_lds = fused_layout(4, fb, false);
+    } else {
+      for (int WT : cand) {
+        if (fused_wt_req > 0 && WT != fused_wt_req) continue;
+        const size_t bytes = fused_layout(WT, fb, false);
+        if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused2_lds_budget)) { fused2_WT = WT; fused2_lds = bytes; break; }
+      }
     }
     if (fused2_WT == 0) return DQMC_OK;
     const int WT = fused2_WT, n_waves = 4;
@@ -564,7 +677,9 @@ struct Engine : dqmc_ctx {
         flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
       }
     t_begin("fused_psi", flops);
-    dqmc::launch_fused2_value<real>(st, a, (B + fused2_WT - 1) / fused2_WT, fused2_lds, fused_occ);
+    int occ = fused_occ_req;
+    if (occ <= 0) { const size_t per_cu = (size_t)160 * 1024 / (fused2_lds ? fused2_lds : 1); occ = per_cu >= 4 ? 4 : (per_cu >= 3 ? 3 : 2); }
+    dqmc::launch_fused2_value<real>(st, a, (B + fused2_WT - 1) / fused2_WT, fused2_lds, occ);
     t_end();
     return DQMC_OK;
   }

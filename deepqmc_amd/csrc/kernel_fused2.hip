@@ -397,12 +397,15 @@ __global__ void __launch_bounds__(256, OCC) k_fused2_value(const Fused2Args<real
 
 template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ) {
   const dim3 g((unsigned)n_blocks), b(256);
-  if (occ >= 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 3>), g, b, lds_bytes, st, a);
+  if (sizeof(real) == 8) occ = 2;     // the float64 (parity) build needs the full register file
+  if (occ >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 4>), g, b, lds_bytes, st, a);
+  else if (occ == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 3>), g, b, lds_bytes, st, a);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 2>), g, b, lds_bytes, st, a);
 }
 template <typename real> int fused2_set_lds_limit(size_t lds_bytes) {
   int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   return rc;
 }
 

@@ -1,5 +1,5 @@
-"""Per-op shader-clock breakdown of the fused psi kernel (workgroup 0) on the GPU.
-Usage: python tools/fused_profile.py [--wt 4]"""
+"""Shader-clock profile of the descriptor-driven fused psi kernel (workgroup 0): per wave, cycles spent in each
+descriptor of its work list.  Usage: python tools/fused_profile.py [--wt 4]  (prints the plan on stderr)."""
 import argparse, ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,35 +7,28 @@ from deepqmc_amd import MolecularHamiltonian, Molecule
 from deepqmc_amd.sampling import synthetic_walkers
 from deepqmc_amd.wf import NeuralNetworkWaveFunction
 
-ap = argparse.ArgumentParser(); ap.add_argument('--wt', type=int, default=4); ap.add_argument('--walkers', type=int, default=4096)
+ap = argparse.ArgumentParser(); ap.add_argument('--wt', type=int, default=0); ap.add_argument('--walkers', type=int, default=4096)
+ap.add_argument('--sched', type=int, default=-1)
 args = ap.parse_args()
 h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
 wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cuda:0')
 params = wf.init(0, perturb_envelopes=0.05)
 eng = wf.engine(params)
-eng.set_option('fused_wt', args.wt)
+if args.sched >= 0:
+    eng.set_option('fused_sched', args.sched)
+if args.wt:
+    eng.set_option('fused_wt', args.wt)
 eng.set_option('fused_dbg', 1)
+eng.set_option('fused_print', 2)
 r = torch.as_tensor(synthetic_walkers(h, args.walkers).astype(np.float32), device='cuda:0')
 for _ in range(3):
     eng.wf_eval(r)
 torch.cuda.synchronize()
-n_f = next(k for k, op in enumerate(eng.program.ops) if op.kind == 8) + 1
-out = np.zeros(64 + 8 * n_f + 8)
+out = np.zeros(1024)
 eng._check(eng.lib.dqmc_debug_read(eng._ctx, -3, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
-d = np.diff(out[:n_f + 1])
-print('total cycles (wg 0):', out[n_f] - out[0], ' = %.1f us at 2.4 GHz' % ((out[n_f] - out[0]) / 2400))
-for k in range(n_f):
-    u = out[64 + 8 * k: 64 + 8 * k + 6]
-    if u[0] > 0:
-        print('unit', k, [int(x) for x in np.diff(u)])
-kinds = {1: 'FEAT_EN', 2: 'FEAT_EE', 3: 'LINEAR', 4: 'SPIN_MEAN', 5: 'CONV', 6: 'EDGE_SUM', 7: 'ROW_SUM', 8: 'ORBITALS'}
-# the kernel executes ops in level order; we do not know the order here, so print raw slots
-for k, c in enumerate(d):
-    print(k, int(c))
-t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-eng.set_option('fused_dbg', 0)
-t0.record()
-for _ in range(20):
-    eng.wf_eval(r)
-t1.record(); torch.cuda.synchronize()
-print('wf_eval ms:', t0.elapsed_time(t1) / 20)
+st = out.reshape(4, 256)
+t0 = st[:, 0].min()
+for w in range(4):
+    row = st[w]
+    n = int((row > 0).sum())
+    print('wave', w, 'start', int(row[0] - t0), 'end', int(row[n - 1] - t0), 'deltas', [int(x) for x in np.diff(row[:n])])
