@@ -216,13 +216,15 @@ def main():
     rep = eng.timing_report()
     eng.timing(False)
     names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
-             'fused_psi': 'k_fused_value (LDS-resident psi evaluation of the Metropolis loop, v_mfma_f32_16x16x4_f32)'}
+             'fused_psi': 'k_fused2_value (LDS-resident psi evaluation, v_mfma_f32_16x16x4_f32)',
+             'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + '
+                              'determinants + accept, v_mfma_f32_16x16x4_f32)'}
     cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
     dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
     lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
     total_ms = sum(v['ms'] for v in rep.values()) or 1.0
     achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
-    traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused_value'}[dom],
+    traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused2_value', 'fused_substep': 'k_fused2_value'}[dom],
                                              f'{args.molecule}/{args.ansatz}/{B}/{args.dtype}')
     roofline = {
         'bound': 'mfma', 'kernel': names[dom],

@@ -133,7 +133,7 @@ struct Engine : dqmc_ctx {
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
-  int fused_version = 2, fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4;
+  int fused_version = 2, fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
   size_t fused_sched_budget = 36 * 1024;   // bytes live per level the list scheduler (mode 3) aims for
   const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
@@ -188,9 +188,9 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipMalloc((void**)&d_w, sizeof(real) * (nw ? nw : 1)));
     HIP_TRY(hipMalloc((void**)&d_it, sizeof(int32_t) * (nit ? nit : 1)));
     HIP_TRY(hipMalloc((void**)&d_charges, sizeof(double) * sys.n_nuc));
-    HIP_TRY(hipMalloc((void**)&d_nacc, sizeof(int32_t)));
+    HIP_TRY(hipMalloc((void**)&d_nacc, sizeof(int32_t) * 2));
     HIP_TRY(hipMalloc((void**)&d_acc, sizeof(double) * 16));
-    HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t) * 2, st));
     HIP_TRY(hipMemcpyAsync(d_charges, charges, sizeof(double) * sys.n_nuc, hipMemcpyHostToDevice, st));
     if (nit) HIP_TRY(hipMemcpyAsync(d_it, it, sizeof(int32_t) * nit, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -278,6 +278,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
+    if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
       fprintf(stderr, "[dqmc] fused plan: v1 WT=%d lds=%zu B; v2 WT=%d lds=%zu B; %d fused ops, %d levels\n", fused_WT, fused_lds,
@@ -519,7 +520,7 @@ struct Engine : dqmc_ctx {
         fused_sched_budget = (size_t)kb * 1024;
         fused_schedule();
         std::vector<dqmc::FusedBuf> fbt;
-        fit = fused_layout(4, fbt, false) <= fused2_lds_quarter;
+        fit = fused_layout(4, fbt, false) + 16 + dqmc::fused2_scratch_bytes(4, N, sys.n_det, (int)sizeof(real)) <= fused2_lds_quarter;
       }
       if (!fit) { fused_sched_mode = 1; fused_schedule(); fused_sched_mode = 3; }   // too big for that: full levels
     } else {
@@ -558,14 +559,15 @@ struct Engine : dqmc_ctx {
     if (fused_n_ops == 0) return DQMC_OK;
     const int cand[] = {16, 8, 4, 2, 1};
     std::vector<dqmc::FusedBuf> fb;
-    if (fused_wt_req <= 0 && fused_layout(4, fb, false) <= fused2_lds_quarter) {
+    auto with_scratch = [&](size_t act, int WT) { return (act + 15) / 16 * 16 + (size_t)dqmc::fused2_scratch_bytes(WT, N, sys.n_det, (int)sizeof(real)); };
+    if (fused_wt_req <= 0 && with_scratch(fused_layout(4, fb, false), 4) <= fused2_lds_quarter) {
       // 4 walkers per tile and 4 tiles per CU: for the batch sizes of the north star (4096 walkers = 1024 tiles =
       // 256 CUs x 4) the whole batch is ONE round of co-resident workgroups (measured fastest)
-      fused2_WT = 4; fused2_lds = fused_layout(4, fb, false);
+      fused2_WT = 4; fused2_lds = with_scratch(fused_layout(4, fb, false), 4);
     } else {
       for (int WT : cand) {
         if (fused_wt_req > 0 && WT != fused_wt_req) continue;
-        const size_t bytes = fused_layout(WT, fb, false);
+        const size_t bytes = with_scratch(fused_layout(WT, fb, false), WT);
         if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused2_lds_budget)) { fused2_WT = WT; fused2_lds = bytes; break; }
       }
     }
@@ -661,7 +663,23 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
-  int run_fused2(const real* r, const real* R, int B, dqmc::LaneInfo li) {
+  // LDS offset for the Slater matrices of the sub-step tail: dead activation space clear of the backflow
+  // buffer, which the tail still reads; -1 if there is none (then the staged path runs).
+  int substep_mat_off() const {
+    int orb = -1;
+    for (int j = 0; j < fused_n_ops; ++j) if (ops[f_order[j]].kind == DQMC_OP_ORBITALS) orb = f_order[j];
+    if (orb < 0 || fused2_WT == 0) return -1;
+    const dqmc::FusedBuf& bfb = fbufs2_h[ops[orb].i[0]];
+    const size_t need = (size_t)fused2_WT * sys.n_det * N * N;
+    const size_t bf_len = (size_t)fused2_WT * bfb.rows * bfb.stride;
+    const size_t act_end = (fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real))) / sizeof(real);
+    if (bfb.is_global) return -1;
+    if ((size_t)bfb.off >= need) return 0;
+    if ((size_t)bfb.off + bf_len + need <= act_end) return (int)((size_t)bfb.off + bf_len);
+    return -1;
+  }
+
+  int run_fused2(const real* r, const real* R, int B, dqmc::LaneInfo li, const dqmc::FusedMc* mc = nullptr) {
     for (size_t b = 0; b < bufs.size(); ++b) fbufs2_h[b].goff = (long)buf_off[b];
     HIP_TRY(hipMemcpyAsync(d_fbufs2, fbufs2_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
     dqmc::Fused2Args<real> a{};
@@ -669,6 +687,8 @@ struct Engine : dqmc_ctx {
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
     a.B = B; a.WT = fused2_WT; a.wt_shift = fused2_shift; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det;
     a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
+    a.scratch_off = (int)((fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real))) / sizeof(real));
+    if (mc) a.mc = *mc;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)
       if (ops[k].kind == DQMC_OP_LINEAR) {
@@ -676,7 +696,7 @@ struct Engine : dqmc_ctx {
         for (int p = 0; p < ops[k].i[0]; ++p) ktot += ops[k].i[3 + 4 * p];
         flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
       }
-    t_begin("fused_psi", flops);
+    t_begin(mc ? "fused_substep" : "fused_psi", flops);
     int occ = fused_occ_req;
     if (occ <= 0) { const size_t per_cu = (size_t)160 * 1024 / (fused2_lds ? fused2_lds : 1); occ = per_cu >= 4 ? 4 : (per_cu >= 3 ? 3 : 2); }
     dqmc::launch_fused2_value<real>(st, a, (B + fused2_WT - 1) / fused2_WT, fused2_lds, occ);
@@ -1008,8 +1028,45 @@ struct Engine : dqmc_ctx {
     real* r_prop = (real*)(d_mc + o_rp); real* lp_prop = (real*)(d_mc + o_lp);
     int32_t* s_prop = (int32_t*)(d_mc + o_sp);
     real* nz = (real*)(d_mc + o_nz); real* un = (real*)(d_mc + o_un);
+    // whole sub-step in one launch (kernel_fused2.hip: propose in the prologue, determinants / CI sum / accept /
+    // tau adaptation in the tail) when the ansatz tail is the plain SLOGDET + FINAL pair and N <= 4
+    const bool one_launch = fused_enabled && fused_version >= 2 && fused2_WT > 0 && fused_substep && N >= 2 && N <= 4 &&
+                            sys.n_nuc <= 8 && fused2_WT <= 16 && (int)ops.size() == fused_n_ops + 2 &&
+                            ops[fused_n_ops].kind == DQMC_OP_SLOGDET && ops[fused_n_ops + 1].kind == DQMC_OP_FINAL &&
+                            substep_mat_off() >= 0;
     for (int s = 0; s < n_sub; ++s) {
       const real* noise_s; const real* unif_s;
+      if (one_launch) {
+        if (noise_) {
+          noise_s = (const real*)noise_ + (size_t)s * n_r;
+          unif_s = (const real*)unif_ + (size_t)s * B;
+        } else {
+          t_begin("mcmc", 0);
+          dqmc::launch_rng<real>(st, nz, (long)n_r, un, (long)B, seed, (uint64_t)s);
+          t_end();
+          noise_s = nz; unif_s = un;
+        }
+        dqmc::LaneInfo li; li.N = N; li.T = 1; li.TP = 1;
+        int rc = plan(B, 1);
+        if (rc) return rc;
+        const dqmc_op& fin = ops[fused_n_ops + 1];
+        dqmc::FusedMc mc{};
+        mc.enabled = 1; mc.noise = noise_s; mc.unif = unif_s; mc.r = r; mc.logpsi = logpsi; mc.sign = sign; mc.age = age;
+        mc.tau = tau; mc.counters = d_nacc; mc.accept_out = accept_out ? accept_out + (size_t)s * B : nullptr;
+        mc.max_age = max_age;
+        mc.orb_op = -1;
+        for (int j = 0; j < fused_n_ops; ++j) if (ops[f_order[j]].kind == DQMC_OP_ORBITALS) mc.orb_op = j;
+        mc.mat_off = substep_mat_off();
+        mc.jas_width = fin.i[0] >= 0 ? bufs[fin.i[0]].width : 0;
+        mc.cc_off = fin.i[1]; mc.cusp_kind = fin.i[2]; mc.al_off = fin.i[3];
+        mc.same_scale = fin.f[0]; mc.anti_scale = fin.f[1];
+        rc = run_fused2(nullptr, R, B, li, &mc);
+        if (rc) return rc;
+        t_begin("mcmc", 0);
+        dqmc::launch_tau_update<real>(st, tau, d_nacc, B, target, d_acc);
+        t_end();
+        continue;
+      }
       if (noise_) {
         noise_s = (const real*)noise_ + (size_t)s * n_r;
         unif_s = (const real*)unif_ + (size_t)s * B;

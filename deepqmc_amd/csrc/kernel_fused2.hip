@@ -200,6 +200,17 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
     const BufPtr fb = (BufPtr)a.fbufs + d->dst_base;
     const int rows = fb->rows, width = fb->width, g_r0 = d->g_r0, g_col0 = d->g_col0, sh = a.wt_shift;
     real* dst_g = reinterpret_cast<real*>(a.ws + fb->goff) + (long)blockIdx.x * a.WT * rows * width;
+    if (a.mc.enabled) {        // sub-step mode: the only such buffer is the Jastrow value, consumed by the tail of this kernel
+      real* jas = smem + a.scratch_off + a.WT * a.li.N * 3;
+#pragma unroll
+      for (int x = 0; x < MA; ++x)
+#pragma unroll
+        for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+          for (int y = 0; y < NRW; ++y)
+            if (r_ok[x][rgi] && c_ok[y] && g_col0 + colv[y] < 4) jas[(m_e[x][rgi] & wtm1) * 4 + g_col0 + colv[y]] = ov[x][rgi][y];
+      return;
+    }
 #pragma unroll
     for (int x = 0; x < MA; ++x)
 #pragma unroll
@@ -222,7 +233,7 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int WT = a.WT, sh = a.wt_shift, wtm1 = WT - 1;
   const int N = a.li.N, n_up = a.n_up, n_nuc = a.n_nuc, K = a.K;
-  const real* r = a.r + (long)blockIdx.x * WT * N * 3;
+  const real* r = smem + a.scratch_off;          // positions of the tile (proposed positions in sub-step mode)
   const BufPtr fbs = (BufPtr)a.fbufs;
   const int kind = op->kind;
   LaneInfo li = a.li;   // T = TP = 1
@@ -316,6 +327,7 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
       break;
     }
     case DQMC_OP_ORBITALS: {
+      if (a.mc.enabled) break;                     // sub-step mode: the tail builds the Slater matrices itself
       const BufPtr bf = fbs + op->i[0];
       const BufPtr orb = fbs + op->i[1];
       const int bo = bf->off, bs = bf->stride, ow = orb->width;
@@ -360,8 +372,201 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
   }
 }
 
+// LU with partial pivoting of one N x N Slater matrix (LDS, `real` entries as the ORBITALS op would have stored
+// them) in double registers: sign and log|det| -- the arithmetic of k_slogdet_small, value lane only.
+template <typename real, int N>
+__device__ __forceinline__ void fused2_det(const real* m, double& logabs, int& sgn) {
+  double A[N][N];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+#pragma unroll
+    for (int j = 0; j < N; ++j) A[i][j] = (double)m[i * N + j];
+  logabs = 0.0;
+  sgn = 1;
+#pragma unroll
+  for (int p = 0; p < N; ++p) {
+    int best = p;
+    double bv = fabs(A[p][p]);
+#pragma unroll
+    for (int i = p + 1; i < N; ++i) {
+      const double v = fabs(A[i][p]);
+      if (v > bv) { bv = v; best = i; }
+    }
+#pragma unroll
+    for (int i = p + 1; i < N; ++i) {
+      const bool sw = (best == i);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        const double a0 = A[p][j], a1 = A[i][j];
+        A[p][j] = sw ? a1 : a0; A[i][j] = sw ? a0 : a1;
+      }
+    }
+    if (best != p) sgn = -sgn;
+    const double piv = A[p][p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) sgn = 0;
+    const double ip = 1.0 / piv;
+#pragma unroll
+    for (int j = 0; j < N; ++j) A[p][j] *= ip;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i == p) continue;
+      const double f = A[i][p];
+#pragma unroll
+      for (int j = 0; j < N; ++j) A[i][j] -= f * A[p][j];
+    }
+  }
+}
+
+// Tail of a Metropolis sub-step: Slater matrices (all threads) -> determinants (one thread each) -> CI terms
+// -> psi of the proposal -> accept / reject -> sampler state, acceptance count; the last workgroup to finish
+// adapts tau (electron_samplers.py:106-138).  The matrices reuse LDS of activations that are dead by now.
+template <typename real>
+__device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  const int tid = threadIdx.x, nthr = blockDim.x, WT = a.WT, N = a.li.N, K = a.K, wtm1 = WT - 1, sh = a.wt_shift;
+  const int n_up = a.n_up, n_nuc = a.n_nuc, NN = N * N, KN = K * N;
+  real* rs = smem + a.scratch_off;
+  real* jas = rs + WT * N * 3;
+  char* after = smem_raw + (size_t)a.scratch_off * sizeof(real) + ((WT * (N * 3 + 4) * (int)sizeof(real) + 15) / 16 * 16);
+  double* ld = reinterpret_cast<double*>(after);
+  int32_t* sg = reinterpret_cast<int32_t*>(after + (size_t)WT * K * 8);
+  double* shv = reinterpret_cast<double*>(after + (size_t)WT * K * 12);      // CI shift per walker
+  real* mats = smem + a.mc.mat_off;                           // [WT*K][N*N]
+  // sampler state of this thread's walker: requested now, used after the determinants
+  real lp_old = 0, u_b = 1;
+  int age_b = 0;
+  if (tid < nw) {
+    const long b = (long)blockIdx.x * WT + tid;
+    lp_old = reinterpret_cast<const real*>(a.mc.logpsi)[b];
+    u_b = reinterpret_cast<const real*>(a.mc.unif)[b];
+    age_b = a.mc.age[b];
+  }
+  const OpPtr op = (OpPtr)a.ops + a.mc.orb_op;
+  const BufPtr bf = (BufPtr)a.fbufs + op->i[0];
+  const int bo = bf->off, bs = bf->stride;
+  const int n_env = op->i[6] > 0 ? op->i[6] : 1;
+  const int o_pu = op->i[2], o_pd = op->i[3], o_zu = op->i[4], o_zd = op->i[5];
+  // Slater matrix entries = envelope * backflow, exactly as the ORBITALS op computes them
+  for (int e = tid; e < N * KN * WT; e += nthr) {
+    const int wl = e & wtm1, q = e >> sh;
+    const int el = q / KN, kmu = q - el * KN;
+    if (wl >= nw) continue;
+    const int kd = kmu / N, mu = kmu - kd * N;
+    const real* pi = a.w + (el < n_up ? o_pu : o_pd) + kmu * n_nuc * n_env;
+    const real* ze = a.w + (el < n_up ? o_zu : o_zd) + kmu * n_nuc * n_env;
+    const real b0 = smem[bo + (el * WT + wl) * bs + kmu];
+    real res;
+    if (sizeof(real) == 4) {
+      float acc = 0.f;
+      for (int n = 0; n < n_nuc; ++n) {
+        float d2 = (float)a.eps;
+        for (int c = 0; c < 3; ++c) { const float dx = (float)rs[(wl * N + el) * 3 + c] - (float)a.R[n * 3 + c]; d2 += dx * dx; }
+        const float rho = sqrtf(d2);
+        for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[n * n_env + ev] * expf(-fabsf((float)ze[n * n_env + ev]) * rho);
+      }
+      res = (real)(acc * (float)b0);
+    } else {
+      double e0 = 0;
+      for (int n = 0; n < n_nuc; ++n) {
+        double d2 = a.eps;
+        for (int c = 0; c < 3; ++c) { const double dx = (double)rs[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += dx * dx; }
+        const double rho = sqrt(d2);
+        for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
+      }
+      res = (real)(e0 * (double)b0);
+    }
+    mats[(wl * K + kd) * NN + el * N + mu] = res;
+  }
+  __syncthreads();
+  for (int e = tid; e < K * WT; e += nthr) {
+    const int wl = e & wtm1, kd = e >> sh;
+    double la = 0.0;
+    int sn = 0;
+    if (wl < nw) {
+      const real* m = mats + (wl * K + kd) * NN;
+      if (N == 2) fused2_det<real, 2>(m, la, sn);
+      else if (N == 3) fused2_det<real, 3>(m, la, sn);
+      else fused2_det<real, 4>(m, la, sn);
+    }
+    ld[wl * K + kd] = la;
+    sg[wl * K + kd] = sn;
+  }
+  __syncthreads();
+  // exp-normalised CI terms (wf/nn_wave_function.py:152-160), one thread per (walker, determinant)
+  const real* cc = a.mc.cc_off >= 0 ? a.w + a.mc.cc_off : nullptr;
+  double term = 0.0, shift = 0.0;
+  int e_own = -1;
+  for (int e = tid; e < K * WT; e += nthr) {      // K*WT <= 256: at most one element per thread
+    const int wl = e & wtm1, kd = e >> sh;
+    const double* x = ld + wl * K;
+    shift = -INFINITY;
+    for (int k = 0; k < K; ++k) shift = fmax(shift, x[k]);
+    if (isinf(shift)) shift = 0.0;
+    term = (cc ? (double)cc[kd] : 1.0) * sg[wl * K + kd] * exp(x[kd] - shift);
+    if (kd == 0) shv[wl] = shift;
+    e_own = e;
+  }
+  __syncthreads();
+  if (e_own >= 0) ld[(e_own & wtm1) * K + (e_own >> sh)] = term;     // log|det| -> CI term, in place
+  __syncthreads();
+  int n_acc = 0;
+  if (tid < nw) {
+    const int wl = tid;
+    const long b = (long)blockIdx.x * WT + wl;
+    double psi = 0.0;
+    for (int k = 0; k < K; ++k) psi += ld[wl * K + k];
+    double logpsi = log(fabs(psi)) + shv[wl];
+    const int sign_p = (psi > 0) - (psi < 0);
+    const real* r = rs + wl * N * 3;
+    const real* al = a.w + a.mc.al_off;
+    double cusp = 0.0;
+    if (a.mc.cusp_kind) {     // wf/cusp.py:5-26,68-78 (value)
+      for (int i = 0; i < N; ++i)
+        for (int j = i + 1; j < N; ++j) {
+          double d2 = a.eps;
+          for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
+          const double rho = sqrt(d2);
+          const bool same = (i < n_up) == (j < n_up);
+          const double sc = same ? a.mc.same_scale : a.mc.anti_scale, alp = (double)al[same ? 0 : 1];
+          cusp += a.mc.cusp_kind == 1 ? -sc / (alp * (1 + alp * rho)) : -sc * alp * alp / (alp + rho);
+        }
+    }
+    logpsi += cusp + (a.mc.jas_width > 0 ? (double)jas[wl * 4] : 0.0);
+    const real lp_prop = (real)logpsi;
+    // accept = 2 (log|psi'| - log|psi|) > log u  [| age >= max_age]   (k_accept)
+    real* lp_state = reinterpret_cast<real*>(a.mc.logpsi);
+    const real log_prob = 2 * (lp_prop - lp_old);
+    const real lu = sizeof(real) == 4 ? (real)logf((float)u_b) : (real)log((double)u_b);
+    bool acc = log_prob > lu;
+    const int age = age_b;
+    if (a.mc.max_age >= 0) acc = acc || (age >= a.mc.max_age);
+    if (acc) {
+      real* rg = reinterpret_cast<real*>(a.mc.r) + b * 3 * N;
+      for (int k = 0; k < 3 * N; ++k) rg[k] = r[k];
+      lp_state[b] = lp_prop;
+      a.mc.sign[b] = sign_p;
+      a.mc.age[b] = 0;
+      n_acc = 1;
+    } else {
+      a.mc.age[b] = age + 1;
+    }
+    if (a.mc.accept_out) a.mc.accept_out[b] = acc ? 1 : 0;
+  }
+  if (tid < 64) {                                   // WT <= 16 < 64: the walkers of the tile sit in wave 0
+    for (int m = 1; m < 64; m <<= 1) n_acc += __shfl_xor(n_acc, m, 64);
+    // acceptance count: a fire-and-forget atomic (no return value, no fence); k_tau_update, launched right
+    // after this kernel on the same stream, turns it into the new step size (electron_samplers.py:121-126)
+    if (tid == 0 && n_acc) atomicAdd(a.mc.counters, n_acc);
+  }
+}
+
 template <typename real>
 __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
 #if defined(__HIPCC__)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 #else
@@ -369,6 +574,21 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
 #endif
   const int w0 = blockIdx.x * a.WT;
   const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
+  {
+    // positions of the tile -> LDS; in sub-step mode the proposal r' = r + tau * xi (electron_samplers.py:102-104)
+    real* rs = smem + a.scratch_off;
+    const int n = nw * a.li.N * 3;
+    const long g0 = (long)w0 * a.li.N * 3;
+    if (a.mc.enabled) {
+      const real tau = reinterpret_cast<const real*>(a.mc.tau)[0];
+      const real* rg = reinterpret_cast<const real*>(a.mc.r) + g0;
+      const real* nz = reinterpret_cast<const real*>(a.mc.noise) + g0;
+      for (int e = threadIdx.x; e < n; e += blockDim.x) rs[e] = rg[e] + tau * nz[e];
+    } else {
+      for (int e = threadIdx.x; e < n; e += blockDim.x) rs[e] = a.r[g0 + e];
+    }
+    __syncthreads();
+  }
   DescPtr d = (DescPtr)a.descs + ((const DQMC_UNIFORM int32_t*)a.wave_begin)[wave];
   const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
   int n_d = 0;
@@ -389,6 +609,7 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     }
     if (stamp && n_d < 254) a.prof[wave * 256 + (++n_d)] = clock64();
   }
+  if (a.mc.enabled) fused2_mc_tail<real>(a, nw);     // every wave list ends with a barrier
 }
 
 // OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.

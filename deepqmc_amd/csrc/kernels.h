@@ -119,6 +119,27 @@ struct FDesc {
   int32_t pad[4];
 };
 static_assert(sizeof(FDesc) == 160, "FDesc is 40 dwords");
+// Metropolis sub-step folded into the fused kernel (N <= 4): propose r' = r + tau xi in the prologue, the K
+// Slater determinants, the CI sum / cusp / Jastrow and the accept step in the tail -- one launch per sub-step
+// instead of seven (electron_samplers.py:102-138).  enabled = 0: plain psi evaluation.
+struct FusedMc {
+  int enabled;
+  const void* noise;      // real[B][N][3]
+  const void* unif;       // real[B]
+  void* r;                // real[B][N][3] sampler state, updated in place
+  void* logpsi;           // real[B]
+  int32_t* sign;          // [B]
+  int32_t* age;           // [B]
+  const void* tau;        // real[1]
+  int32_t* counters;      // [0] accepted walkers (k_tau_update consumes and clears it)
+  uint8_t* accept_out;    // [B] or nullptr
+  int max_age;
+  int orb_op;             // scheduled index of the ORBITALS op (backflow buffer, envelope tables)
+  int mat_off;            // LDS offset (reals) of WT*K*N*N free elements for the Slater matrices (dead activations)
+  int jas_width;          // > 0: a Jastrow value per walker arrives through the scratch area
+  int cc_off, al_off, cusp_kind;
+  double same_scale, anti_scale;
+};
 template <typename real> struct Fused2Args {
   const FDesc* descs;       // device: the four wave lists, concatenated
   const int32_t* wave_begin; // device int[4]: first descriptor of each wave
@@ -131,10 +152,16 @@ template <typename real> struct Fused2Args {
   const real* r;
   const real* R;
   int B, WT, wt_shift, n_up, n_nuc, K;
+  int scratch_off;          // LDS offset (in reals) of the per-tile scratch: positions, Jastrow, log|det|, det signs
+  FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
   LaneInfo li;
   double eps;
 };
+// bytes of that scratch area: r tile [WT][N][3], Jastrow [WT][4], log|det| double[WT][K], sign int[WT][K], CI shift double[WT]
+__host__ __device__ inline int fused2_scratch_bytes(int WT, int N, int K, int real_size) {
+  return ((WT * (N * 3 + 4) * real_size + 15) / 16 * 16) + WT * K * 12 + WT * 8;
+}
 template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ);
 template <typename real> int fused2_set_lds_limit(size_t lds_bytes);
 

@@ -90,6 +90,7 @@ template <typename T> inline T __shfl_xor(T v, int mask, int = 64) {
 }
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
+inline void __threadfence() {}
 inline long long clock64() { static long long t = 0; return ++t; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }

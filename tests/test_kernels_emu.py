@@ -65,12 +65,16 @@ def test_emu_f32_energy():
     np.testing.assert_allclose(logpsi.numpy(), ref['log'], rtol=1e-5, atol=1e-5)
 
 
-def test_emu_metropolis_bit_exact_and_stats():
-    """MCMC kernels (propose / accept / tau / stats / energy record) through the emulator."""
+@pytest.mark.parametrize('substep', [1, 0])
+def test_emu_metropolis_bit_exact_and_stats(substep):
+    """MCMC through the emulator, both ways: the whole sub-step in ONE launch of the fused kernel (propose in
+    its prologue; determinants, CI sum, accept and the tau adaptation in its tail) and the kernel-per-stage
+    path (k_propose / psi / k_slogdet / k_final / k_accept / k_tau_update); stats and the energy record."""
     from oracle import sampling as osamp
     from oracle import wf as owf
     B, n_sub = 6, 3
     spec, mol, h, eng, r0, it = _setup(paulinet, 'LiH', torch.float64, B)
+    eng.set_option('fused_substep', substep)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
     rng = np.random.default_rng(0)
     noise = rng.standard_normal((n_sub, B, h.n_elec, 3))
@@ -78,7 +82,10 @@ def test_emu_metropolis_bit_exact_and_stats():
     sign0, log0 = eng.wf_eval(torch.as_tensor(r0))
     st = {'r': torch.as_tensor(r0).clone(), 'log': log0.clone(), 'sign': sign0.clone(),
           'age': torch.zeros(B, dtype=torch.int32), 'tau': torch.full((1,), 0.3, dtype=torch.float64)}
+    eng.timing(True); eng.timing_reset()
     stats, acc = eng.mcmc_steps(st, n_sub, max_age=1, target_acceptance=0.57, noise=noise, unif=unif, return_accept=True)
+    rep = eng.timing_report(); eng.timing(False)
+    assert ('fused_substep' in rep) == bool(substep), rep.keys()        # the path under test is the one that ran
     T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
     ost = {'r': T(r0), 'sign': T(sign0.numpy()), 'log': T(log0.numpy()), 'age': torch.zeros(B, dtype=torch.int64), 'tau': 0.3}
     ost, ostats, oacc = osamp.decorr_sample(owf.to_torch(tree), spec, ost, T(mol.coords), h.n_up, geom.F32_EPS,
