@@ -1019,7 +1019,8 @@ struct Engine : dqmc_ctx {
     // scratch: r_prop, logpsi_prop, sign_prop, noise, unif
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t o_rp = 0, o_lp = o_rp + al(sizeof(real) * n_r), o_sp = o_lp + al(sizeof(real) * B),
-                 o_nz = o_sp + al(sizeof(int32_t) * B), o_un = o_nz + al(sizeof(real) * n_r), tot = o_un + al(sizeof(real) * B);
+                 o_nz = o_sp + al(sizeof(int32_t) * B), o_un = o_nz + al(sizeof(real) * n_r * (size_t)(n_sub > 0 ? n_sub : 1)),
+                 tot = o_un + al(sizeof(real) * B * (size_t)(n_sub > 0 ? n_sub : 1));
     if (tot > mc_bytes) {
       if (d_mc) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_mc)); d_mc = nullptr; }
       HIP_TRY(hipMalloc((void**)&d_mc, tot));
@@ -1028,6 +1029,11 @@ struct Engine : dqmc_ctx {
     real* r_prop = (real*)(d_mc + o_rp); real* lp_prop = (real*)(d_mc + o_lp);
     int32_t* s_prop = (int32_t*)(d_mc + o_sp);
     real* nz = (real*)(d_mc + o_nz); real* un = (real*)(d_mc + o_un);
+    if (!noise_ && n_sub > 0) {      // all sub-steps' normals and uniforms in ONE launch (Philox is counter based)
+      t_begin("mcmc", 0);
+      dqmc::launch_rng<real>(st, nz, (long)(n_r * n_sub), un, (long)B * n_sub, seed, (uint64_t)0);
+      t_end();
+    }
     // whole sub-step in one launch (kernel_fused2.hip: propose in the prologue, determinants / CI sum / accept /
     // tau adaptation in the tail) when the ansatz tail is the plain SLOGDET + FINAL pair and N <= 4
     const bool one_launch = fused_enabled && fused_version >= 2 && fused2_WT > 0 && fused_substep && N >= 2 && N <= 4 &&
@@ -1041,10 +1047,7 @@ struct Engine : dqmc_ctx {
           noise_s = (const real*)noise_ + (size_t)s * n_r;
           unif_s = (const real*)unif_ + (size_t)s * B;
         } else {
-          t_begin("mcmc", 0);
-          dqmc::launch_rng<real>(st, nz, (long)n_r, un, (long)B, seed, (uint64_t)s);
-          t_end();
-          noise_s = nz; unif_s = un;
+          noise_s = nz + (size_t)s * n_r; unif_s = un + (size_t)s * B;
         }
         dqmc::LaneInfo li; li.N = N; li.T = 1; li.TP = 1;
         int rc = plan(B, 1);
@@ -1071,10 +1074,7 @@ struct Engine : dqmc_ctx {
         noise_s = (const real*)noise_ + (size_t)s * n_r;
         unif_s = (const real*)unif_ + (size_t)s * B;
       } else {
-        t_begin("mcmc", 0);
-        dqmc::launch_rng<real>(st, nz, (long)n_r, un, (long)B, seed, (uint64_t)s);
-        t_end();
-        noise_s = nz; unif_s = un;
+        noise_s = nz + (size_t)s * n_r; unif_s = un + (size_t)s * B;
       }
       t_begin("mcmc", 0);
       dqmc::launch_propose<real>(st, r, noise_s, tau, r_prop, (long)n_r);

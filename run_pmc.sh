@@ -1,11 +1,24 @@
 #!/bin/bash
+# SQ counters of one VMC step per kernel (three passes of <= 8 SQ counters) -> gpurun_out/pmc_sq.json
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOT=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L > "$ROOT/gpurun_out/counters.txt" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d "$ROOT/gpurun_out/pmc1" -o p1 -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --fused-wt 4 > "$ROOT/gpurun_out/pmc1.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d "$ROOT/gpurun_out/pmc2" -o p2 -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --fused-wt 4 > "$ROOT/gpurun_out/pmc2.log" 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$ROOT/gpurun_out/pmc3" -o p3 -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --fused-wt 4 > "$ROOT/gpurun_out/pmc3.log" 2>&1
-ls -la "$ROOT"/gpurun_out/pmc*/ | head -30
-tail -3 "$ROOT"/gpurun_out/pmc1.log "$ROOT"/gpurun_out/pmc3.log
+P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU"
+P2="SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
+P3="SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"
+k=1
+for P in "$P1" "$P2" "$P3"; do
+  rm -rf "$ROOT/gpurun_out/pmc$k"
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$ROOT/gpurun_out/pmc$k" -o p$k -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$ROOT/gpurun_out/pmc$k.log" 2>&1
+  k=$((k+1))
+done
+cd "$ROOT"
+python tools/pmc_sq.py gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 > gpurun_out/pmc_sq.json
+rm -f gpurun_out/pmc[123]/*kernel_trace.csv
+python - <<'PY'
+import json
+d = json.load(open('gpurun_out/pmc_sq.json'))
+for k in ('k_fused2_value', 'k_linear'):
+    if k in d: print(k, json.dumps(d[k]))
+PY
