@@ -41,3 +41,26 @@ def test_fused_matches_layered_and_oracle(spec_fn, dtype, wt, version):
     np.testing.assert_array_equal(s1.numpy(), ref['sign'])
     tol = 1e-11 if dtype == torch.float64 else 2e-5
     np.testing.assert_allclose(l1.numpy(), ref['log'], rtol=tol, atol=tol)
+
+
+def test_set_params_repacks_fused_weights():
+    """Engine.set_params (new parameters after an optimiser step, fit.py:75-92 -> dqmc_set_weights) must refresh
+    the plain weights AND the fragment-major copy the fused kernel reads: same result as a fresh engine."""
+    spec = paulinet()
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    t0 = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=1, perturb_envelopes=0.1)
+    t1 = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=2, perturb_envelopes=0.1)
+    rt = torch.as_tensor(make_walkers(mol, h.n_elec, 5))
+    eng = Engine(spec, h, t0, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    s_a, l_a = eng.wf_eval(rt)
+    eng.set_params(t1)
+    s_b, l_b = eng.wf_eval(rt)
+    fresh = Engine(spec, h, t1, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    s_c, l_c = fresh.wf_eval(rt)
+    assert not np.allclose(l_a.numpy(), l_b.numpy())
+    np.testing.assert_array_equal(s_b.numpy(), s_c.numpy())
+    np.testing.assert_array_equal(l_b.numpy(), l_c.numpy())
+    e_b, _ = eng.local_energy(rt)
+    e_c, _ = fresh.local_energy(rt)
+    np.testing.assert_array_equal(e_b.numpy(), e_c.numpy())
