@@ -52,3 +52,25 @@ def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
     log_ratio = shifted - diag[None]
     sdiag = torch.diagonal(sign, dim1=0, dim2=1).permute(1, 0)
     return (sign * sdiag[None] * torch.exp(log_ratio))[None]
+
+
+def symmetrize_overlap_with_clipped_geometric_mean(x: torch.Tensor) -> torch.Tensor:
+    """loss/overlap.py:102-121: y_ij = sign(x_ij) sqrt(max(0, x_ij x_ji))."""
+    return torch.sign(x) * torch.sqrt(torch.clamp(x * x.transpose(-1, -2), min=0.0))
+
+
+def compute_mean_overlap(psi_ratio: torch.Tensor, weight: torch.Tensor):
+    """loss/overlap.py:124-149: weighted mean of the psi ratios over the walkers of ALL ranks (the reference's
+    all_device_mean; here one all-reduce of an [M,S,S] tensor), symmetrised; returns (sum_{i<j} S_ij^2 averaged
+    over molecules, {'overlap/pairwise/mean': S[M,S,S]}).  psi_ratio [M,S,S,B], weight [M,S,B]."""
+    import torch.distributed as dist
+    s = (weight[:, None, :, :] * psi_ratio).sum(-1)
+    n = torch.tensor(float(psi_ratio.shape[-1]), dtype=s.dtype, device=s.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(s)
+        dist.all_reduce(n)
+    symm = symmetrize_overlap_with_clipped_geometric_mean(s / n)
+    S = symm.shape[-1]
+    iu = torch.triu_indices(S, S, offset=1, device=symm.device)
+    loss = (symm[:, iu[0], iu[1]] ** 2).sum(-1).mean()
+    return loss, {'overlap/pairwise/mean': symm}

@@ -159,3 +159,59 @@ class LangevinSampler(MetropolisSampler):
             r = state['r']
             stats = {'sampling/acceptance': float(acceptance), 'sampling/tau': float(tau)}
         return state, self.phys_conf(eng.R if R is None else R, state['r']), stats
+
+
+class OppositeSpinExchangeSampler:
+    """sampling/electron_samplers.py:235-330 chained in front of a Metropolis-type sampler: with probability
+    `exchange_step_probability` a step proposes swapping the positions of one random spin-up and one random
+    spin-down electron per walker (uniform choice = the reference's default zero logits) and accepts with
+    |psi'|^2 / |psi|^2 -- no age override and no step-size adaptation on such steps (:312-321) -- otherwise it
+    is an ordinary step of the wrapped sampler.  The swap bookkeeping is torch glue on the device; psi comes from
+    the HIP engine.  `choices` = (is_exchange: bool, up_idx[B], down_idx[B], unif[B]) overrides the draws
+    (parity tests)."""
+
+    def __init__(self, sampler: MetropolisSampler, *, exchange_step_probability: float):
+        self.sampler = sampler
+        self.exchange_step_probability = exchange_step_probability
+        self.hamil, self.wf = sampler.hamil, sampler.wf
+
+    def init(self, rng, params, n, R=None):
+        return self.sampler.init(rng, params, n, R)
+
+    def update(self, state, params, R=None):
+        return self.sampler.update(state, params, R)
+
+    def sample(self, rng, state, params, R=None, choices=None, **kw):
+        eng = self.wf.engine(params)
+        B, n_up, n_down = state['r'].shape[0], self.hamil.n_up, self.hamil.n_down
+        gen = torch.Generator(device='cpu')
+        gen.manual_seed(int(rng) * 7919 + 13)
+        if choices is None:
+            is_ex = bool(torch.rand((), generator=gen) < self.exchange_step_probability)
+            up_idx = torch.randint(0, n_up, (B,), generator=gen)
+            down_idx = torch.randint(0, n_down, (B,), generator=gen)
+            unif = torch.rand(B, generator=gen, dtype=torch.float64)
+        else:
+            is_ex, up_idx, down_idx, unif = choices
+        if not is_ex:
+            return self.sampler.sample(rng, state, params, R, **kw)
+        dev = eng.device
+        up_idx, down_idx = torch.as_tensor(up_idx, device=dev).long(), torch.as_tensor(down_idx, device=dev).long() + n_up
+        r = state['r']
+        bi = torch.arange(B, device=dev)
+        r_prop = r.clone()
+        r_prop[bi, up_idx] = r[bi, down_idx]
+        r_prop[bi, down_idx] = r[bi, up_idx]
+        sign_p, log_p = eng.wf_eval(r_prop, R)
+        log_prob = 2 * (log_p - state['psi'].log)                                          # :290-293
+        acc = log_prob > torch.log(torch.as_tensor(unif, dtype=eng.dtype, device=dev))      # _accept without max_age/target
+        new = {**state,
+               'r': torch.where(acc[:, None, None], r_prop, r).contiguous(),
+               'psi': Psi(torch.where(acc, sign_p, state['psi'].sign), torch.where(acc, log_p, state['psi'].log)),
+               'age': torch.where(acc, torch.zeros_like(state['age']), state['age'] + 1)}
+        acceptance = float(acc.to(torch.float64).mean())
+        stats = {'sampling/acceptance': acceptance, 'sampling/tau': float(state['tau'][0]),
+                 'sampling/age/mean': float(new['age'].to(torch.float64).mean()), 'sampling/age/max': float(new['age'].max()),
+                 'sampling/log_psi/mean': float(new['psi'].log.mean()),
+                 'sampling/log_psi/std': float(new['psi'].log.std(unbiased=False))}
+        return new, self.sampler.phys_conf(eng.R if R is None else R, new['r']), stats

@@ -124,3 +124,22 @@ def langevin_step(psi_force_fn, state, R, charges, noise, unif, max_age=None, ta
            'force': sel(force_p, state['force']),
            'age': torch.where(accepted, torch.zeros_like(state['age']), state['age'] + 1), 'tau': new_tau}
     return new, accepted, float(acceptance)
+
+
+# ---- opposite-spin exchange step, reference sampling/electron_samplers.py:235-330 ----
+
+def spin_exchange_step(psi_fn, state, n_up: int, up_idx, down_idx, unif):
+    """One exchange step: swap r[b, up_idx[b]] <-> r[b, n_up + down_idx[b]] (:277-288), accept with
+    2 (log|psi'| - log|psi|) > log u (:290-293), `_accept` WITHOUT max_age / target_acceptance (:312-313)."""
+    r = state['r']
+    B = r.shape[0]
+    bi = torch.arange(B)
+    r_prop = r.clone()
+    r_prop[bi, up_idx] = r[bi, n_up + down_idx]
+    r_prop[bi, n_up + down_idx] = r[bi, up_idx]
+    sign_p, log_p = psi_fn(r_prop)
+    accepted = 2 * (log_p - state['log']) > torch.log(unif)
+    new = {'r': torch.where(accepted[:, None, None], r_prop, r), 'sign': torch.where(accepted, sign_p, state['sign']),
+           'log': torch.where(accepted, log_p, state['log']),
+           'age': torch.where(accepted, torch.zeros_like(state['age']), state['age'] + 1), 'tau': state['tau']}
+    return new, accepted

@@ -89,3 +89,55 @@ def test_langevin_sampler_matches_oracle():
     np.testing.assert_allclose(state['r'].numpy(), ost['r'].numpy(), rtol=0, atol=1e-9)
     np.testing.assert_allclose(float(state['tau']), ost['tau'], rtol=1e-10)
     np.testing.assert_allclose(state['psi'].log.numpy(), ost['log'].numpy(), rtol=0, atol=1e-9)
+
+
+def test_spin_exchange_sampler_matches_oracle():
+    """OppositeSpinExchangeSampler (electron_samplers.py:235-330): the exchange step through the emulated HIP
+    psi against the oracle restatement on the same choices; a non-exchange step is the wrapped sampler's."""
+    from deepqmc_amd.sampling import MetropolisSampler, OppositeSpinExchangeSampler
+    from oracle import sampling as osamp
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(3, perturb_envelopes=0.1)
+    B = 6
+    smp = OppositeSpinExchangeSampler(MetropolisSampler(h, wf, tau=0.3), exchange_step_probability=0.5)
+    state = smp.init(0, params, B)
+    rng = np.random.default_rng(4)
+    up, dn, u = rng.integers(0, h.n_up, B), rng.integers(0, h.n_down, B), rng.random(B)
+    new, pc, stats = smp.sample(1, state, params, choices=(True, up, dn, u))
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    p = owf.to_torch(params)
+    psi = lambda rr: physics.batch_wave_function(p, wf.spec, rr, T(h.mol.coords), h.n_up, geom.F32_EPS)
+    ost = {'r': state['r'].clone(), 'sign': state['psi'].sign.to(torch.float64), 'log': state['psi'].log.clone(),
+           'age': state['age'].to(torch.int64), 'tau': 0.3}
+    onew, oacc = osamp.spin_exchange_step(psi, ost, h.n_up, torch.as_tensor(up), torch.as_tensor(dn), T(u))
+    assert oacc.any() and not oacc.all()                     # the case exercises both branches
+    np.testing.assert_array_equal(new['age'].numpy(), onew['age'].numpy())
+    np.testing.assert_array_equal(new['r'].numpy(), onew['r'].numpy())
+    np.testing.assert_allclose(new['psi'].log.numpy(), onew['log'].numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_array_equal(new['psi'].sign.numpy(), onew['sign'].numpy().astype(np.int32))
+    assert float(new['tau'][0]) == 0.3                       # no step-size adaptation on exchange steps
+    # swapped electrons really are one up and one down electron of the same walker
+    moved = (new['r'] != state['r']).any(-1)
+    assert ((moved[:, :h.n_up].sum(1) == moved[:, h.n_up:].sum(1))).all()
+    new2, _, stats2 = smp.sample(2, new, params, choices=(False, None, None, None))
+    assert new2['tau'].item() != 0.3 or stats2['sampling/acceptance'] >= 0
+
+
+def test_overlap_symmetrisation_known_answers():
+    """The known answers of the reference's tests/test_overlap.py (TestSymmetrizeOverlap,
+    TestComputeMeanOverlap) for loss.symmetrize_overlap_with_clipped_geometric_mean / compute_mean_overlap."""
+    sym = loss.symmetrize_overlap_with_clipped_geometric_mean
+    T = lambda a: torch.tensor(a, dtype=torch.float64)
+    s06 = 0.06 ** 0.5
+    np.testing.assert_allclose(sym(T([[1.0, 0.3], [0.2, 1.0]])).numpy(), [[1.0, s06], [s06, 1.0]], rtol=1e-14)
+    y = sym(T([[1.0, -0.4], [0.3, 1.0]]))
+    np.testing.assert_allclose(y.numpy(), [[1.0, 0.0], [0.0, 1.0]], atol=0)
+    np.testing.assert_allclose(sym(T([[1.0, 2.0], [3.0, 1.0]])).numpy(), [[1.0, 6 ** 0.5], [6 ** 0.5, 1.0]], rtol=1e-14)
+    y = sym(T([[1.0, 0.3, -0.5], [0.2, 1.0, 0.4], [0.6, 0.5, 1.0]]))
+    np.testing.assert_allclose(y.numpy(), [[1.0, s06, 0.0], [s06, 1.0, 0.2 ** 0.5], [0.0, 0.2 ** 0.5, 1.0]], rtol=1e-14)
+    ratio = T([[[[1.0, 1.0], [0.2, 0.4]], [[0.3, 0.5], [1.0, 1.0]]]])
+    weight = T([[[1.0, 1.0], [0.8, 1.2]]])
+    ov, stats = loss.compute_mean_overlap(ratio, weight)
+    np.testing.assert_allclose(float(ov), 0.128, rtol=1e-14)
+    np.testing.assert_allclose(stats['overlap/pairwise/mean'][0].numpy(), [[1.0, 0.128 ** 0.5], [0.128 ** 0.5, 1.0]], rtol=1e-14)
