@@ -114,6 +114,8 @@ def main():
     ap.add_argument('--ecp', action='store_true', help='Gaussian-type ECP on every atom heavier than He with SYNTHETIC '
                     'coefficients (pyscf tables are not available offline): exercises the 12 N n_ecp psi-ratio quadrature')
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
+    ap.add_argument('--overlap', type=int, default=0, help='1: E_loc of step k on a second HIP stream, overlapped with the '
+                    'Metropolis sub-steps of step k+1 (software pipelining; same work per step)')
     ap.add_argument('--fused-version', type=int, default=0, help='1: first fused kernel (in-kernel op interpreter); 2 (library default): descriptor driven')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
@@ -180,12 +182,45 @@ def main():
         stats = parallel.energy_stats(eng, e)
         return state, stats
 
+    # ---- software-pipelined variant: E_loc(k) runs on a second stream while the sub-steps of step k+1 run ----
+    pipe = {'e': None, 'stats': None}
+    if args.overlap:
+        from deepqmc_amd.engine import Engine
+        s_e = torch.cuda.Stream(device)
+        with torch.cuda.stream(s_e):
+            eng_e = Engine(wf.spec, hamil, params, dtype=dtype, device=device)      # its work goes to s_e
+        s_main = torch.cuda.current_stream(device)
+
+        def vmc_step_pipelined(step, state):
+            state, pc, _ = sampler.sample(step * world + rank, state, params)        # enqueued on the main stream
+            if pipe['e'] is not None:                                                # E_loc of the previous step
+                with torch.cuda.stream(s_e):
+                    pipe['stats'] = parallel.energy_stats(eng_e, pipe['e'])          # syncs s_e only
+            r_snap = state['r'].clone()
+            r_snap.record_stream(s_e)
+            ev = s_main.record_event()
+            with torch.cuda.stream(s_e):
+                s_e.wait_event(ev)
+                pipe['e'], _ = eng_e.local_energy(r_snap)
+            return state, pipe['stats']
+
+        def drain():
+            with torch.cuda.stream(s_e):
+                pipe['stats'] = parallel.energy_stats(eng_e, pipe['e'])
+            pipe['e'] = None
+            return pipe['stats']
+
+    step_fn = vmc_step_pipelined if args.overlap else vmc_step
     for s in range(args.warmup):
-        state, stats = vmc_step(s, state)
+        state, stats = step_fn(s, state)
+    if args.overlap:
+        stats = drain()
     barrier()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        state, stats = vmc_step(args.warmup + s, state)
+        state, stats = step_fn(args.warmup + s, state)
+    if args.overlap:
+        stats = drain()          # the last step's E_loc and reduction are inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:

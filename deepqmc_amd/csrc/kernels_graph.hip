@@ -97,35 +97,40 @@ __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int w
                                               const real* __restrict__ hx, int hx_width, real* __restrict__ out,
                                               int out_width, int col0, const int32_t* __restrict__ tab, int S, int W,
                                               int B, LaneInfo li) {
+  // One thread per (walker, receiver, column) walks the lanes once: out_t = sum_s (a_t h_0 + a_0 h_t), and the
+  // Laplacian lane adds 2 sum_s sum_c a_c h_c from a running dot product -- every input element is read once
+  // and no thread carries the whole Laplacian sum alone.
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * li.N * li.TP * W;
+  const long total = (long)B * li.N * W;
   if (idx >= total) return;
   const int c = (int)(idx % W);
-  long q = idx / W;
-  const int t = (int)(q % li.TP); q /= li.TP;
+  const long q = idx / W;
   const int i = (int)(q % li.N);
   const int b = (int)(q / li.N);
-  real acc = 0;
-  if (t < li.T) {
+  const int T = li.T;
+  real* o = out + (((long)b * li.N + i) * li.TP) * out_width + col0 + c;
+  real acc0 = 0, dot = 0;
+  for (int s = 0; s < S; ++s) {
+    const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
+    if (row < 0) continue;
+    acc0 += we[(((long)b * we_rows + row) * li.TP) * we_width + c] * hx[(((long)b * li.N + snd) * li.TP) * hx_width + c];
+  }
+  o[0] = acc0;
+  for (int t = 1; t < T; ++t) {
+    real acc = 0;
     for (int s = 0; s < S; ++s) {
       const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
       if (row < 0) continue;
       const real* a = we + (((long)b * we_rows + row) * li.TP) * we_width + c;
       const real* h = hx + (((long)b * li.N + snd) * li.TP) * hx_width + c;
-      const real a0 = a[0], h0 = h[0];
-      if (t == 0) {
-        acc += a0 * h0;
-      } else {
-        acc += a[(long)t * we_width] * h0 + a0 * h[(long)t * hx_width];
-        if (t == li.T - 1) {
-          real dot = 0;
-          for (int u = 1; u < li.T - 1; ++u) dot += a[(long)u * we_width] * h[(long)u * hx_width];
-          acc += 2 * dot;
-        }
-      }
+      const real at = a[(long)t * we_width], ht = h[(long)t * hx_width];
+      acc += at * h[0] + a[0] * ht;
+      if (t < T - 1) dot += at * ht;
     }
+    if (t == T - 1) acc += 2 * dot;
+    o[(long)t * out_width] = acc;
   }
-  out[(((long)b * li.N + i) * li.TP + t) * out_width + col0 + c] = acc;
+  for (int t = T; t < li.TP; ++t) o[(long)t * out_width] = 0;
 }
 
 // Edge sum/mean feature, reference gnn/update_features.py:109-159 (linear in the lanes).
@@ -182,7 +187,7 @@ void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int
 template <typename real>
 void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
                  int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li) {
-  const long total = (long)B * li.N * li.TP * W;
+  const long total = (long)B * li.N * W;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx,
                      hx_width, out, out_width, col0, tab, S, W, B, li);
 }
