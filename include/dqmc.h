@@ -86,8 +86,9 @@ enum dqmc_op_kind {
   DQMC_OP_ROW_SUM = 7,
   /* i: [0]=backflow buf ([N][pad4(K*N)], column k*N+mu) [1]=dst buf (rows=K,
    * width=pad4(N*N), column i*N+mu) [2..5]=weight offsets of pi_up, pi_down, zetas_up,
-   * zetas_down ([K*N][n_nuc]).  Slater matrix entries A = envelope * backflow
-   * (wf/env.py:57-75, wf/nn_wave_function.py:135-147). */
+   * zetas_down ([K*N][n_nuc*n_env]) [6]=n_env envelopes per nucleus (0 = 1).  Slater matrix
+   * entries A = envelope * backflow (wf/env.py:57-75, wf/nn_wave_function.py:135-147;
+   * n_env = 3 with pi = 1: the SimplifiedNucleusDependentEnvelopes of env.py:110-226). */
   DQMC_OP_ORBITALS = 8,
   /* i: [0]=orbital buf.  sign/log|det| of the K matrices and their forward-Laplacian
    * lanes, kept in double inside the context (wf/nn_wave_function.py:36-39). */
@@ -100,7 +101,10 @@ enum dqmc_op_kind {
   DQMC_OP_FINAL = 10,
   /* Multi-head self attention over the electrons of a walker, forward-Laplacian form
    * (hk.MultiHeadAttention called at gnn/update_features.py:273-278).
-   * i: [0]=q buf [1]=k buf [2]=v buf [3]=dst buf [4]=heads [5]=head_dim. */
+   * i: [0]=q buf [1]=k buf [2]=v buf [3]=dst buf [4]=heads [5]=head_dim
+   * [6]=n_const extra key/value rows that do not depend on the electrons (the nuclear tokens of
+   * CombinedNodeAttention with elec_to_nuc = false, update_features.py:385-451; they come first
+   * in the key order) [7],[8]=weight offsets of their keys / values ([n_const][heads*head_dim]). */
   DQMC_OP_ATTENTION = 11
 };
 
@@ -192,8 +196,14 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out_host, size_t n);
 int dqmc_debug_lanes(dqmc_ctx* ctx);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op (0 keeps every
- * activation buffer readable by dqmc_debug_read); "fused_wt": walkers per workgroup tile
- * (0 = automatic); "fused_lds_kb": LDS budget per workgroup for the automatic choice. */
+ * activation buffer readable by dqmc_debug_read); "fused_substep" (1): fold propose / determinants /
+ * accept of a Metropolis sub-step into that kernel when N <= 4; "fused_version" (2: descriptor-driven
+ * kernel, 1: the first interpreter-style kernel); "fused_wt": walkers per workgroup tile (0 = automatic);
+ * "fused_sched" (3: list scheduling under an LDS budget, 2: as late as possible, 1: full dependency
+ * levels, 0: program order); "fused_occ": register budget as workgroups per CU (0 = from the LDS size);
+ * "fused_lds_kb", "fused_sched_kb": LDS budgets; "fused_dbg": clock stamps readable through
+ * dqmc_debug_read(buf = -3); "fused_print": plan summary on stderr; "ecp_max_cfg": quadrature walkers
+ * per value-mode batch of the non-local ECP term.  Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 
 /* Per-kernel timing (HIP events on the context's stream).  enable != 0 starts recording
