@@ -93,6 +93,31 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // [0,1) with
   return (double)((((uint64_t)hi << 32) | lo) >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// Pair-compact lanes.  An edge row (receiver i, sender j) of the two-particle stream depends on the coordinates
+// of electrons i and j only (reference gnn/graph.py:23-31: d = r_recv - r_send; the edge MLPs act row-wise), so
+// of its 3N derivative lanes at most 6 are non-zero.  Edge buffers therefore carry 8 lanes instead of
+// round_up(3N+2, 16):   0 value | 1..3 d/dr_recv | 4..6 d/dr_send | 7 Laplacian
+// (a nuclear sender or a self edge leaves lanes 4..6 zero).  pair_lane() maps a full lane t to the compact
+// lane of edge (recv, send), or -1 if that lane is identically zero.  This is the block sparsity that folx
+// exploits for the reference (last paragraph).
+constexpr int PAIR_LANES = 8;
+__device__ __forceinline__ int pair_lane(int t, int T, int recv, int send) {
+  if (t == 0) return 0;
+  if (t == T - 1) return PAIR_LANES - 1;
+  const int e = (t - 1) / 3, x = (t - 1) - 3 * e;
+  if (e == recv) return 1 + x;
+  if (e == send) return 4 + x;
+  return -1;
+}
+// inverse: full lane of compact lane ct (or -1: a lane that is zero for this edge)
+__device__ __forceinline__ int pair_lane_full(int ct, int T, int recv, int send) {
+  if (ct == 0) return 0;
+  if (ct == PAIR_LANES - 1) return T - 1;
+  if (ct < 4) return 1 + 3 * recv + (ct - 1);
+  if (send < 0 || send == recv) return -1;
+  return 1 + 3 * send + (ct - 4);
+}
+
 // Lane-t value of the pair features [rho, d_x, d_y, d_z] (optionally * log1p(rho)/rho) of the
 // difference d = r_recv - r_send (send < 0: a nucleus, no dependence), rho = sqrt(eps + d.d).
 // Reference: gnn/edge_features.py:21-123 + utils.py:79-85; derivative lanes per SURVEY.md

@@ -104,6 +104,7 @@ struct Engine : dqmc_ctx {
   std::vector<dqmc_op> ops;
   std::vector<double> charges_h;
   size_t n_weights = 0, n_itable = 0;
+  std::vector<int32_t> h_itable;
   real* d_w = nullptr;
   int32_t* d_it = nullptr;
   double* d_charges = nullptr;
@@ -132,6 +133,11 @@ struct Engine : dqmc_ctx {
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
+  // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
+  // (receiver, sender) of each of their rows (for the lane maps of debug_read)
+  bool lane_compact = true;
+  std::vector<char> compact;
+  std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused_version = 2, fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
   size_t fused_sched_budget = 36 * 1024;   // bytes live per level the list scheduler (mode 3) aims for
@@ -193,9 +199,11 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t) * 2, st));
     HIP_TRY(hipMemcpyAsync(d_charges, charges, sizeof(double) * sys.n_nuc, hipMemcpyHostToDevice, st));
     if (nit) HIP_TRY(hipMemcpyAsync(d_it, it, sizeof(int32_t) * nit, hipMemcpyHostToDevice, st));
+    h_itable.assign(it, it + nit);
     HIP_TRY(hipStreamSynchronize(st));
     int rc = validate();
     if (rc) return rc;
+    analyse_lanes();
     rc = set_weights(w, nw);
     if (rc) return rc;
     return build_fused_plan();
@@ -259,6 +267,96 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
+  // Which buffers can carry pair-compact lanes: outputs of FEAT_EE and of row-wise LINEAR ops on them (all
+  // pieces compact, none broadcast; residual compact with the same row pairs).  Consumers that understand the
+  // compact layout: LINEAR, CONV (edge operand), EDGE_SUM.  Anything else turns the optimisation off.
+  void analyse_lanes() {
+    const int nb = (int)bufs.size();
+    compact.assign(nb, 0);
+    pair_rs.assign(nb, std::vector<int>());
+    if (!lane_compact) return;
+    std::vector<char> full_written(nb, 0);
+    bool ok = true;
+    auto set_pairs = [&](int b, int row, int rc, int sd) {
+      if (pair_rs[b].empty()) pair_rs[b].assign(2 * (size_t)bufs[b].rows, -2);
+      int& pr = pair_rs[b][2 * row];
+      int& ps = pair_rs[b][2 * row + 1];
+      if (pr != -2 && (pr != rc || ps != sd)) ok = false;
+      pr = rc; ps = sd;
+    };
+    for (size_t k = 0; k < ops.size() && ok; ++k) {
+      const int32_t* i = ops[k].i;
+      switch (ops[k].kind) {
+        case DQMC_OP_FEAT_EE:
+          if (full_written[i[0]]) { ok = false; break; }
+          compact[i[0]] = 1;
+          for (int r = 0; r < i[2]; ++r) set_pairs(i[0], r, h_itable[i[1] + 2 * r], h_itable[i[1] + 2 * r + 1]);
+          break;
+        case DQMC_OP_LINEAR: {
+          int n_c = 0;
+          for (int p = 0; p < i[0]; ++p) n_c += compact[i[1 + 4 * p]] ? 1 : 0;
+          if (n_c == 0) {
+            if (compact[i[17]] || (i[25] >= 0 && compact[i[25]])) ok = false;
+            full_written[i[17]] = 1;
+            break;
+          }
+          if (n_c != i[0] || full_written[i[17]]) { ok = false; break; }
+          compact[i[17]] = 1;
+          for (int rr = 0; rr < i[20] && ok; ++rr) {
+            const int sb0 = i[1], r00 = i[2];
+            if (i[4] || pair_rs[sb0].empty()) { ok = false; break; }
+            const int rc = pair_rs[sb0][2 * (r00 + rr)], sd = pair_rs[sb0][2 * (r00 + rr) + 1];
+            for (int p = 1; p < i[0]; ++p) {
+              const int sb = i[1 + 4 * p], r0 = i[2 + 4 * p];
+              if (i[4 + 4 * p] || pair_rs[sb].empty() || pair_rs[sb][2 * (r0 + rr)] != rc || pair_rs[sb][2 * (r0 + rr) + 1] != sd) ok = false;
+            }
+            if (i[25] >= 0) {
+              const int rb = i[25];
+              if (!compact[rb] || pair_rs[rb].empty() || pair_rs[rb][2 * (i[26] + rr)] != rc || pair_rs[rb][2 * (i[26] + rr) + 1] != sd) ok = false;
+            }
+            set_pairs(i[17], i[18] + rr, rc, sd);
+          }
+          break;
+        }
+        case DQMC_OP_CONV:
+          if (compact[i[1]] || compact[i[2]]) ok = false;
+          full_written[i[2]] = 1;
+          if (compact[i[0]])      // the table's (row, sender) of receiver el must be the row's own pair
+            for (int el = 0; el < N && ok; ++el)
+              for (int sdx = 0; sdx < i[5]; ++sdx) {
+                const int row = h_itable[i[4] + 2 * (el * i[5] + sdx)], snd = h_itable[i[4] + 2 * (el * i[5] + sdx) + 1];
+                if (row >= 0 && (pair_rs[i[0]][2 * row] != el || pair_rs[i[0]][2 * row + 1] != snd)) ok = false;
+              }
+          break;
+        case DQMC_OP_EDGE_SUM:
+          if (compact[i[2]]) ok = false;
+          full_written[i[2]] = 1;
+          if (compact[i[0]])
+            for (int el = 0; el < N && ok; ++el)
+              for (int sdx = 0; sdx < i[5]; ++sdx) {
+                const int row = h_itable[i[4] + 2 * (el * i[5] + sdx)], snd = h_itable[i[4] + 2 * (el * i[5] + sdx) + 1];
+                if (row >= 0 && (pair_rs[i[0]][2 * row] != el || pair_rs[i[0]][2 * row + 1] != snd)) ok = false;
+              }
+          break;
+        case DQMC_OP_FEAT_EN: full_written[i[0]] = 1; break;
+        case DQMC_OP_SPIN_MEAN: case DQMC_OP_ROW_SUM: if (compact[i[0]]) ok = false; full_written[i[1]] = 1; break;
+        case DQMC_OP_ORBITALS: if (compact[i[0]]) ok = false; full_written[i[1]] = 1; break;
+        case DQMC_OP_SLOGDET: if (compact[i[0]]) ok = false; break;
+        case DQMC_OP_FINAL: if (i[0] >= 0 && compact[i[0]]) ok = false; break;
+        case DQMC_OP_ATTENTION:
+          for (int q = 0; q < 3; ++q) if (compact[i[q]]) ok = false;
+          full_written[i[3]] = 1;
+          break;
+        default: break;
+      }
+    }
+    for (int b = 0; b < nb && ok; ++b)
+      if (compact[b]) for (int v : pair_rs[b]) if (v == -2) ok = false;   // every row of a compact buffer has a pair
+    if (!ok) { compact.assign(nb, 0); pair_rs.assign(nb, std::vector<int>()); }
+  }
+  // lanes of buffer b in an evaluation with TP lanes
+  int lanes_of(int b, int TP) const { return (TP > 1 && compact[b]) ? dqmc::PAIR_LANES : TP; }
+
   int set_weights(const double* w, size_t n) override {
     if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
     wtmp.resize(n);
@@ -278,6 +376,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
+    if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
@@ -773,7 +872,7 @@ struct Engine : dqmc_ctx {
     size_t off = 0;
     auto bump = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     for (size_t k = 0; k < bufs.size(); ++k)
-      buf_off[k] = bump(sizeof(real) * (size_t)B * bufs[k].rows * TP * bufs[k].width);
+      buf_off[k] = bump(sizeof(real) * (size_t)B * bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width);
     off_logdet = bump(sizeof(double) * (size_t)B * sys.n_det * TP);
     off_signk = bump(sizeof(int32_t) * (size_t)B * sys.n_det);
     if (off > ws_bytes) {
@@ -815,7 +914,8 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_FEAT_EE:
           t_begin("feat", 0);
-          dqmc::launch_feat_ee<real>(st, r, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3]);
+          dqmc::launch_feat_ee<real>(st, r, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
+                                     li.TP > 1 && compact[i[0]]);
           t_end();
           break;
         case DQMC_OP_LINEAR: {
@@ -841,6 +941,7 @@ struct Engine : dqmc_ctx {
           if (i[25] >= 0) { a.ld_res = bufs[i[25]].width; a.rpw_res = bufs[i[25]].rows; a.r0_res = i[26]; }
           a.res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
           a.act = i[24]; a.nrows = i[20]; a.B = B; a.T = li.T; a.TP = li.TP;
+          if (li.TP > 1 && compact[i[17]]) { a.T = dqmc::PAIR_LANES; a.TP = dqmc::PAIR_LANES; }   // row-wise op on edge rows
           t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21]);
           dqmc::launch_linear<real>(st, a);
           t_end();
@@ -854,13 +955,14 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_CONV:
           t_begin("graph", 0);
           dqmc::launch_conv<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, bptr(i[2]),
-                                  bufs[i[2]].width, i[3], d_it + i[4], i[5], i[6], B, li);
+                                  bufs[i[2]].width, i[3], d_it + i[4], i[5], i[6], B, li, li.TP > 1 && compact[i[0]]);
           t_end();
           break;
         case DQMC_OP_EDGE_SUM:
           t_begin("graph", 0);
           dqmc::launch_edge_sum<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[2]), bufs[i[2]].width, i[3],
-                                      d_it + i[4], i[5], i[6], 1.0 / (double)(i[1] > 0 ? i[1] : 1), B, li);
+                                      d_it + i[4], i[5], i[6], 1.0 / (double)(i[1] > 0 ? i[1] : 1), B, li,
+                                      li.TP > 1 && compact[i[0]]);
           t_end();
           break;
         case DQMC_OP_ATTENTION: {
@@ -1131,9 +1233,32 @@ struct Engine : dqmc_ctx {
     if (buf < 0 || buf >= (int)bufs.size()) return fail(DQMC_E_ARG, "no such buffer");
     const size_t cnt = (size_t)last_B * bufs[buf].rows * last_TP * bufs[buf].width;
     if (n != cnt) return fail(DQMC_E_ARG, "size mismatch: expected " + std::to_string(cnt));
-    std::vector<real> tmp(cnt);
-    HIP_TRY(hipMemcpy(tmp.data(), d_ws + buf_off[buf], sizeof(real) * cnt, hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < cnt; ++k) out[k] = (double)tmp[k];
+    const int lanes = lanes_of(buf, last_TP);
+    const size_t cnt_dev = (size_t)last_B * bufs[buf].rows * lanes * bufs[buf].width;
+    std::vector<real> tmp(cnt_dev);
+    HIP_TRY(hipMemcpy(tmp.data(), d_ws + buf_off[buf], sizeof(real) * cnt_dev, hipMemcpyDeviceToHost));
+    if (lanes == last_TP) {
+      for (size_t k = 0; k < cnt; ++k) out[k] = (double)tmp[k];
+      return DQMC_OK;
+    }
+    // pair-compact buffer: expand to the documented full-lane layout [B][rows][TP][width]
+    const int T = 3 * N + 2, W = bufs[buf].width, rows = bufs[buf].rows;
+    std::fill(out, out + cnt, 0.0);
+    for (int b = 0; b < last_B; ++b)
+      for (int row = 0; row < rows; ++row) {
+        const int rc = pair_rs[buf][2 * row], sd = pair_rs[buf][2 * row + 1];
+        for (int ct = 0; ct < lanes; ++ct) {
+          int t;
+          if (ct == 0) t = 0;
+          else if (ct == lanes - 1) t = T - 1;
+          else if (ct < 4) t = 1 + 3 * rc + (ct - 1);
+          else if (sd < 0 || sd == rc) continue;
+          else t = 1 + 3 * sd + (ct - 4);
+          const real* src = tmp.data() + (((size_t)b * rows + row) * lanes + ct) * W;
+          double* dst = out + (((size_t)b * rows + row) * last_TP + t) * W;
+          for (int c = 0; c < W; ++c) dst[c] = (double)src[c];
+        }
+      }
     return DQMC_OK;
   }
 };

@@ -41,6 +41,7 @@ template <typename real> __device__ __forceinline__ void act_derivs(int act, rea
 
 template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
 
+// GPW = -1: groups of 8 lanes (the pair-compact edge buffers of common.h), two per MFMA row block.
 // MR row blocks x NR column blocks per wave; GPW groups per wave (0: value-only rows); the
 // workgroup is 4 waves in M times WN waves in N (WN = 2: 512 threads, BN = 128, so a 128-wide
 // layer reads its A rows from HBM once).  A tile in LDS is row-major with stride BK + 2: the
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16;
   constexpr int AS = BK + 2, BS = BStride<BN>::v;
+  constexpr bool HALF = GPW < 0;                        // 8-lane groups: two per row block
   constexpr int GB = GPW > 0 ? MR / GPW : 1;            // row blocks per group
   constexpr int APT = MR / WN;                          // A float4 per thread and chunk
   constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
@@ -73,7 +75,11 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
     const int row = (tid >> 2) + (NT / 4) * j;
     a_row[j] = row;
     int g, t;
-    if (GPW > 0) {
+    if (HALF) {
+      const int w = row / (16 * MR), rb = (row >> 4) % MR;
+      g = ((blockIdx.x * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
+      t = row & 7;
+    } else if (GPW > 0) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
       g = (blockIdx.x * 4 + w) * GPW + rb / GB;
       t = (rb % GB) * 16 + (row & 15);
@@ -164,7 +170,60 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   // ---- epilogue ----
   const int cl = lane & 15;
   const int col_w0 = col_blk0 + wn * (16 * NR);
-  if (GPW > 0) {
+  if (HALF) {
+    // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15); a lane's four rows
+    // (Mfma::row_of) may belong to one group (f32 layout) or to both (f64 layout), so the value lane and
+    // the sum of squared derivative lanes of each group are gathered with quad reductions.
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      long drow0[2], rrow0[2];
+      bool g_ok[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = ((blockIdx.x * 4 + wm) * MR + i) * 2 + h;
+        g_ok[h] = g < n_groups;
+        const int gg = g_ok[h] ? g : 0;
+        const int b = gg / a.nrows, rr = gg - b * a.nrows;
+        drow0[h] = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
+        rrow0[h] = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
+      }
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int col = col_w0 + n * 16 + cl;
+        const bool col_ok = col < a.ldw;
+        real v_part[2] = {0, 0}, s_part[2] = {0, 0};
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
+          const real x = acc[i][n][rg];
+          if (tt == 0) v_part[h] += x;
+          else if (tt < a.T - 1) s_part[h] += x * x;
+        }
+        real y[2], d1[2], d2[2], S[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          real v = quad_sum<real>(v_part[h]);
+          S[h] = quad_sum<real>(s_part[h]);
+          if (a.bias != nullptr && col_ok) v += a.bias[col];
+          act_derivs<real>(a.act, v, y[h], d1[h], d2[h]);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
+          const real x = acc[i][n][rg];
+          real o;
+          if (tt == 0) o = y[h];
+          else if (tt < a.T - 1) o = d1[h] * x;
+          else if (tt == a.T - 1) o = d1[h] * x + d2[h] * S[h];
+          else o = 0;
+          if (col_ok && g_ok[h]) {
+            if (a.res != nullptr) o = (a.res[(rrow0[h] + tt) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
+            a.dst[(drow0[h] + tt) * a.ld_dst + a.col0_dst + col] = o;
+          }
+        }
+      }
+    }
+  } else if (GPW > 0) {
 #pragma unroll
     for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
       const int g = (blockIdx.x * 4 + wm) * GPW + gj;
@@ -236,7 +295,8 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   const long n_groups = (long)a.B * a.nrows;
-  const unsigned gx = GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
+  const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
+                      : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
 }
@@ -253,6 +313,7 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
     case 1: launch_nr<real, 4, 0>(st, a); break;
+    case 8: launch_nr<real, 4, -1>(st, a); break;
     case 16: launch_nr<real, 4, 4>(st, a); break;
     case 32: launch_nr<real, 4, 2>(st, a); break;
     case 48: launch_nr<real, 3, 1>(st, a); break;

@@ -37,22 +37,29 @@ __global__ void __launch_bounds__(256) k_feat_en(const real* __restrict__ r, con
 template <typename real>
 __global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, const int32_t* __restrict__ pairs,
                                                  real* __restrict__ e, int B, int n_rows, LaneInfo li, double eps,
-                                                 int log_rescale) {
+                                                 int log_rescale, int compact) {
+  // compact: the destination carries the 8 pair lanes of common.h (Laplacian mode only)
+  const int TPd = compact ? PAIR_LANES : li.TP;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * n_rows * li.TP;
+  const long total = (long)B * n_rows * TPd;
   if (idx >= total) return;
-  const int t = (int)(idx % li.TP);
-  long q = idx / li.TP;
+  const int td = (int)(idx % TPd);
+  long q = idx / TPd;
   const int k = (int)(q % n_rows);
   const int b = (int)(q / n_rows);
   const int rc = pairs[2 * k], sd = pairs[2 * k + 1];
-  double d[3];
-  for (int c = 0; c < 3; ++c)
-    d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (double)r[((long)b * li.N + sd) * 3 + c];
-  double f[4];
-  pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f);
+  const int t = compact ? pair_lane_full(td, li.T, rc, sd) : td;
   Vec4<real> o;
-  for (int c = 0; c < 4; ++c) o.v[c] = (real)f[c];
+  if (t < 0) {
+    for (int c = 0; c < 4; ++c) o.v[c] = (real)0;
+  } else {
+    double d[3];
+    for (int c = 0; c < 3; ++c)
+      d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (double)r[((long)b * li.N + sd) * 3 + c];
+    double f[4];
+    pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f);
+    for (int c = 0; c < 4; ++c) o.v[c] = (real)f[c];
+  }
   *reinterpret_cast<Vec4<real>*>(e + idx * 4) = o;
 }
 
@@ -96,7 +103,9 @@ template <typename real>
 __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int we_rows, int we_width,
                                               const real* __restrict__ hx, int hx_width, real* __restrict__ out,
                                               int out_width, int col0, const int32_t* __restrict__ tab, int S, int W,
-                                              int B, LaneInfo li) {
+                                              int B, LaneInfo li, int compact) {
+  // `compact`: the edge operand carries the 8 pair lanes of common.h; lane t of edge (i, snd) is then lane
+  // pair_lane(t) of its row, or zero.
   // One thread per (walker, receiver, column) walks the lanes once: out_t = sum_s (a_t h_0 + a_0 h_t), and the
   // Laplacian lane adds 2 sum_s sum_c a_c h_c from a running dot product -- every input element is read once
   // and no thread carries the whole Laplacian sum alone.
@@ -108,12 +117,13 @@ __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int w
   const int i = (int)(q % li.N);
   const int b = (int)(q / li.N);
   const int T = li.T;
+  const int TPe = (compact && T > 1) ? PAIR_LANES : li.TP;
   real* o = out + (((long)b * li.N + i) * li.TP) * out_width + col0 + c;
   real acc0 = 0, dot = 0;
   for (int s = 0; s < S; ++s) {
     const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
     if (row < 0) continue;
-    acc0 += we[(((long)b * we_rows + row) * li.TP) * we_width + c] * hx[(((long)b * li.N + snd) * li.TP) * hx_width + c];
+    acc0 += we[(((long)b * we_rows + row) * TPe) * we_width + c] * hx[(((long)b * li.N + snd) * li.TP) * hx_width + c];
   }
   o[0] = acc0;
   for (int t = 1; t < T; ++t) {
@@ -121,9 +131,10 @@ __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int w
     for (int s = 0; s < S; ++s) {
       const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
       if (row < 0) continue;
-      const real* a = we + (((long)b * we_rows + row) * li.TP) * we_width + c;
+      const real* a = we + (((long)b * we_rows + row) * TPe) * we_width + c;
       const real* h = hx + (((long)b * li.N + snd) * li.TP) * hx_width + c;
-      const real at = a[(long)t * we_width], ht = h[(long)t * hx_width];
+      const int ta = (compact && T > 1) ? pair_lane(t, T, i, snd) : t;
+      const real at = ta >= 0 ? a[(long)ta * we_width] : (real)0, ht = h[(long)t * hx_width];
       acc += at * h[0] + a[0] * ht;
       if (t < T - 1) dot += at * ht;
     }
@@ -138,7 +149,7 @@ template <typename real>
 __global__ void __launch_bounds__(256) k_edge_sum(const real* __restrict__ e, int e_rows, int e_width,
                                                   real* __restrict__ out, int out_width, int col0,
                                                   const int32_t* __restrict__ tab, int S, int W, real scale, int B,
-                                                  LaneInfo li) {
+                                                  LaneInfo li, int compact) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * li.N * li.TP * W;
   if (idx >= total) return;
@@ -147,11 +158,16 @@ __global__ void __launch_bounds__(256) k_edge_sum(const real* __restrict__ e, in
   const int t = (int)(q % li.TP); q /= li.TP;
   const int i = (int)(q % li.N);
   const int b = (int)(q / li.N);
+  const bool cp = compact && li.T > 1;
+  const int TPe = cp ? PAIR_LANES : li.TP;
   real acc = 0;
-  for (int s = 0; s < S; ++s) {
-    const int row = tab[2 * (i * S + s)];
-    if (row >= 0) acc += e[(((long)b * e_rows + row) * li.TP + t) * e_width + c];
-  }
+  if (t < li.T)
+    for (int s = 0; s < S; ++s) {
+      const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
+      if (row < 0) continue;
+      const int te = cp ? pair_lane(t, li.T, i, snd) : t;
+      if (te >= 0) acc += e[(((long)b * e_rows + row) * TPe + te) * e_width + c];
+    }
   out[(((long)b * li.N + i) * li.TP + t) * out_width + col0 + c] = acc * scale;
 }
 
@@ -169,10 +185,10 @@ void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B
 }
 template <typename real>
 void launch_feat_ee(hipStream_t st, const real* r, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
-                    double eps, int log_rescale) {
-  const long total = (long)B * n_rows * li.TP;
+                    double eps, int log_rescale, int compact) {
+  const long total = (long)B * n_rows * (compact ? PAIR_LANES : li.TP);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_ee<real>), dim3(nblk(total)), dim3(256), 0, st, r, pairs, e, B, n_rows,
-                     li, eps, log_rescale);
+                     li, eps, log_rescale, compact);
 }
 template <typename real>
 void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li) {
@@ -186,30 +202,30 @@ void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int
 }
 template <typename real>
 void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
-                 int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li) {
+                 int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li, int compact) {
   const long total = (long)B * li.N * W;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx,
-                     hx_width, out, out_width, col0, tab, S, W, B, li);
+                     hx_width, out, out_width, col0, tab, S, W, B, li, compact);
 }
 template <typename real>
 void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,
-                     const int32_t* tab, int S, int W, double scale, int B, LaneInfo li) {
+                     const int32_t* tab, int S, int W, double scale, int B, LaneInfo li, int compact) {
   const long total = (long)B * li.N * li.TP * W;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_sum<real>), dim3(nblk(total)), dim3(256), 0, st, e, e_rows, e_width, out,
-                     out_width, col0, tab, S, W, (real)scale, B, li);
+                     out_width, col0, tab, S, W, (real)scale, B, li, compact);
 }
 
 #define DQMC_INST(real)                                                                                              \
   template void launch_feat_en<real>(hipStream_t, const real*, const real*, real*, int, int, int, int, LaneInfo,     \
                                      double, int, int);                                                              \
   template void launch_feat_ee<real>(hipStream_t, const real*, const int32_t*, real*, int, int, LaneInfo, double,    \
-                                     int);                                                                           \
+                                     int, int);                                                                      \
   template void launch_spin_mean<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                    \
   template void launch_row_sum<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                      \
   template void launch_conv<real>(hipStream_t, const real*, int, int, const real*, int, real*, int, int,             \
-                                  const int32_t*, int, int, int, LaneInfo);                                          \
+                                  const int32_t*, int, int, int, LaneInfo, int);                                     \
   template void launch_edge_sum<real>(hipStream_t, const real*, int, int, real*, int, int, const int32_t*, int, int, \
-                                      double, int, LaneInfo);
+                                      double, int, LaneInfo, int);
 DQMC_INST(float)
 DQMC_INST(double)
 #undef DQMC_INST
