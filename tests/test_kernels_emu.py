@@ -144,3 +144,24 @@ def test_emu_value_slogdet_lu_n2():
     np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-10, atol=1e-10)
     np.testing.assert_array_equal(sign.numpy(), val['sign'])
     np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize('spec_fn', [paulinet, ferminet])
+def test_emu_pair_compact_lanes_equal_full_lanes(spec_fn):
+    """Edge buffers with 8 pair-compact lanes (the library's default) give the local energy, gradient and every
+    (expanded) buffer of the dense-lane evaluation -- only zeros are dropped."""
+    B = 2
+    spec, mol, h, eng, r, it = _setup(spec_fn, 'LiH', torch.float64, B)
+    e1, st1, g1 = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    bufs1 = {name: eng.debug_read(name, B) for name in eng.program.buf_names}
+    eng.set_option('lane_compact', 0)
+    e0, st0, g0 = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    np.testing.assert_allclose(e1.numpy(), e0.numpy(), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g1.numpy(), g0.numpy(), rtol=1e-12, atol=1e-12)
+    n_sparse = 0
+    for name in eng.program.buf_names:
+        full = eng.debug_read(name, B)
+        np.testing.assert_allclose(bufs1[name], full, rtol=1e-12, atol=1e-13, err_msg=name)
+        if name.startswith('e') and full.ndim == 4:
+            n_sparse += int((np.abs(full).sum(axis=(0, 1, 3)) == 0).sum() > 0)
+    assert n_sparse > 0      # the dense evaluation really carries all-zero lanes in the edge stream
