@@ -312,7 +312,16 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
 
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
-    case 1: launch_nr<real, 4, 0>(st, a); break;
+    case 1: {
+      // value-only rows (Metropolis sub-steps of the larger ansatzes): small batches would leave CUs idle with
+      // 256-row tiles, so the tile height follows the row count (aim: >= 2 workgroups per CU)
+      const long rows = (long)a.B * a.nrows;
+      const long col_blocks = (a.ldw + 127) / 128;
+      if ((rows + 255) / 256 * col_blocks >= 512) launch_nr<real, 4, 0>(st, a);
+      else if ((rows + 127) / 128 * col_blocks >= 512) launch_nr<real, 2, 0>(st, a);
+      else launch_nr<real, 1, 0>(st, a);
+      break;
+    }
     case 8: launch_nr<real, 4, -1>(st, a); break;
     case 16: launch_nr<real, 4, 4>(st, a); break;
     case 32: launch_nr<real, 4, 2>(st, a); break;
