@@ -116,6 +116,8 @@ def main():
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
     ap.add_argument('--overlap', type=int, default=0, help='1: E_loc of step k on a second HIP stream, overlapped with the '
                     'Metropolis sub-steps of step k+1 (software pipelining; same work per step)')
+    ap.add_argument('--attention-mfma', type=int, default=-1, help='0: scalar attention kernel, 2: MFMA kernel wherever supported '
+                    '(library default 1: MFMA where profitable)')
     ap.add_argument('--fused-version', type=int, default=0, help='1: first fused kernel (in-kernel op interpreter); 2 (library default): descriptor driven')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
@@ -148,6 +150,8 @@ def main():
     wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
+    if args.attention_mfma >= 0:
+        eng.set_option('attention_mfma', args.attention_mfma)
     if args.fused_version:
         eng.set_option('fused_version', args.fused_version)
     if args.fused_sched >= 0:

@@ -62,6 +62,17 @@ template <typename real> __device__ __forceinline__ real r_exp(real x);
 template <> __device__ __forceinline__ float r_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double r_exp<double>(double x) { return exp(x); }
 
+// Ordering point between LDS writes of a wave and reads of the same locations by other lanes of that wave.
+// The hardware executes a wave's LDS operations in order, so only the compiler (and the CPU emulation harness,
+// where lanes are fibers) needs a barrier here.
+__device__ __forceinline__ void wave_lds_fence() {
+#if defined(__HIPCC__)
+  __builtin_amdgcn_wave_barrier();
+#else
+  (void)__shfl(0, 0, 64);
+#endif
+}
+
 // Sum over the four 16-lane quads of a wave (same lane&15).
 template <typename real> __device__ __forceinline__ real quad_sum(real v) {
   v += __shfl_xor(v, 16, 64);

@@ -136,6 +136,7 @@ struct Engine : dqmc_ctx {
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
   bool lane_compact = true;
+  int attention_mfma = 1;      // 1: where profitable (N > 32), 2: wherever supported, 0: never
   std::vector<char> compact;
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
@@ -376,6 +377,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
+    if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
@@ -968,8 +970,15 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_ATTENTION: {
           // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
           t_begin("attention", 2.0 * B * i[4] * (double)N * (N + i[6]) * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
-          const int rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
-                                                        i[4], i[5], B, li, i[6], d_w + i[7], d_w + i[8]);
+          int rc2;
+          if (sizeof(real) == 4 && attention_mfma && dqmc::attention_mfma_supported(N, i[5], i[6]) &&
+              (attention_mfma >= 2 || dqmc::attention_mfma_profitable(N)))
+            rc2 = dqmc::launch_attention_mfma(st, (const float*)bptr(i[0]), (const float*)bptr(i[1]), (const float*)bptr(i[2]),
+                                              (float*)bptr(i[3]), bufs[i[0]].width, i[4], i[5], B, li, i[6],
+                                              (const float*)(d_w + i[7]), (const float*)(d_w + i[8]));
+          else
+            rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
+                                               i[4], i[5], B, li, i[6], d_w + i[7], d_w + i[8]);
           t_end();
           if (rc2) return fail(DQMC_E_HIP, "attention launch failed");
           break;

@@ -172,6 +172,12 @@ int launch_attention(hipStream_t st, const real* q, const real* k, const real* v
                      int B, LaneInfo li, int n_const, const real* k_const, const real* v_const);
 template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const);
 
+// ---- kernel_attention_mfma.hip: float32, contractions on MFMA (head_dim % 16 == 0, <= 64 queries / keys) ----
+bool attention_mfma_supported(int N, int hd, int n_const);
+bool attention_mfma_profitable(int N);
+int launch_attention_mfma(hipStream_t st, const float* q, const float* k, const float* v, float* out, int width, int H,
+                          int hd, int B, LaneInfo li, int n_const, const float* k_const, const float* v_const);
+
 // ---- kernels_head.hip ----
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,

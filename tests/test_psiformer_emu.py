@@ -13,6 +13,7 @@ from oracle.program_interp import Interp
 from simt_util import emu_lib
 from test_program_interp import make_walkers
 import dataclasses
+import pytest
 
 
 def small_psiformer():
@@ -74,3 +75,35 @@ def test_transpsiformer_emu_f64():
     from deepqmc_amd.engine import DqmcError
     with pytest.raises(DqmcError):
         eng.wf_eval(torch.as_tensor(r), R=torch.as_tensor(mol.coords + 0.1))
+
+
+@pytest.mark.parametrize('ansatz', ['psiformer', 'transpsiformer'])
+def test_attention_mfma_f32(ansatz):
+    """The MFMA attention kernel (float32 build, head_dim = 16: kernel_attention_mfma.hip) against the scalar
+    kernel on the attention output buffers, value and Laplacian mode, and against the float64 interpreter on
+    E_loc; with nuclear-token keys (constant rows) for the TransPsiformer."""
+    mol = Molecule.from_name('LiH')
+    base = transpsiformer(mol.charges) if ansatz == 'transpsiformer' else psiformer()
+    spec = dataclasses.replace(base, embedding_dim=64, n_interactions=2, n_determinants=4)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B).astype(np.float32)
+    names = [n for n in eng.program.buf_names if n.endswith('/att')]
+    assert names
+    out = {}
+    for flag in (1, 0):
+        eng.set_option('attention_mfma', 2 if flag else 0)       # 2: force the MFMA kernel on this small system
+        e, _ = eng.local_energy(torch.as_tensor(r))
+        out[flag] = (e.numpy().copy(), {n: eng.debug_read(n, B) for n in names})
+        s, l = eng.wf_eval(torch.as_tensor(r))
+        out[flag] += (l.numpy().copy(),)
+    for n in names:
+        a, b = out[1][1][n], out[0][1][n]
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-5 * max(1.0, np.abs(b).max()), err_msg=n)
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=1e-5, atol=1e-5)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r.astype(np.float64), mol.coords.astype(np.float32).astype(np.float64), laplacian=True)
+    np.testing.assert_allclose(out[1][0], ref['e_loc'], rtol=5e-4, atol=5e-4)
