@@ -236,3 +236,29 @@ def test_ecp_local_energy(dtype):
     e4, s4 = eng.local_energy(rd, rng=11)
     assert torch.equal(s4['hamil/V_nl'], s1['hamil/V_nl']) and torch.equal(e4, e1)
     report(f'ecp_{"f64" if dtype == torch.float64 else "f32"}', {'worst_rel_eloc': worst})
+
+
+@pytest.mark.parametrize('spec_fn,molname', [(transpsiformer, 'cyclobutadiene_square'), (psiformer, 'benzene')])
+def test_attention_mfma_vs_scalar_f32(spec_fn, molname):
+    """The MFMA attention kernel (f32, N > 16; kernel_attention_mfma.hip) against the scalar attention kernel on
+    the first layer's attention output (identical inputs: every lane incl. the Laplacian lane, 28 / 42 electrons,
+    with and without nuclear-token keys) and on log|psi| of the whole ansatz."""
+    spec, mol, h, tree, eng, it = setup(spec_fn, molname, torch.float32)
+    B = 2
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=4).astype(np.float32), device=DEV)
+    eng.set_option('fused', 0)
+    res = {}
+    for flag in (2, 0):
+        eng.set_option('attention_mfma', flag)
+        e, _ = eng.local_energy(r)
+        att = eng.debug_read('l0/att', B)
+        sign, logpsi = eng.wf_eval(r)
+        res[flag] = (att, logpsi.cpu().numpy(), sign.cpu().numpy(), e.cpu().numpy())
+    a, b = res[2][0], res[0][0]
+    scale = np.abs(b).max(axis=(0, 1, 3), keepdims=True) + 1e-30          # per lane: derivative lanes have their own magnitude
+    err = float((np.abs(a - b) / scale).max())
+    assert np.isfinite(a).all() and err < 2e-5, err
+    np.testing.assert_array_equal(res[2][2], res[0][2])
+    np.testing.assert_allclose(res[2][1], res[0][1], rtol=5e-5, atol=2e-4)     # f32 round-off through 4 layers + 42x42 determinants
+    report(f'attention_mfma_{molname}', {'l0_att_max_rel_err_per_lane': err,
+                                         'logpsi_max_abs_diff': float(np.abs(res[2][1] - res[0][1]).max())})
