@@ -303,7 +303,7 @@ template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg
 
 template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, const LinArgs<real>& a) {
   constexpr int NR_MAX = sizeof(real) == 8 ? 2 : 4;   // accumulator registers: MR*NR*4 per lane
-  constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0 && MR <= 4;
+  constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0;   // 8 waves, BN = 128: the A rows of a wide layer are read half as often
   if (a.ldw > 64 && WIDE) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, (WIDE ? 2 : 1)>(st, a);
   else if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, 1>(st, a);
   else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW, 1>(st, a);
