@@ -186,6 +186,7 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li);
+extern int slogdet_use_mfma;
 struct FinalArgs {
   const void* r;          // real[B][N][3]
   const void* R;          // real[n_nuc][3]

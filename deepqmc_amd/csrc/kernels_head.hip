@@ -184,6 +184,162 @@ __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, in
   for (int t = li.T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
 }
 
+// One 16 x 16 tile of A^-1 dA_c: the A fragments (a row block of A^-1, the same for every lane) live in
+// registers, the NK B fragments are requested from LDS before the first MFMA, so the chain of dependent
+// v_mfma_f64_16x16x4_f64 is not interleaved with LDS round trips.
+template <int NK>
+__device__ __forceinline__ Mfma<double>::acc_t slogdet_tile_mm(const double (&fa)[12], const double* ib, int NS) {
+  double fb[NK];
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) fb[kk] = ib[(kk * 4) * NS];
+  Mfma<double>::acc_t acc = Mfma<double>::acc_t{0, 0, 0, 0};
+#pragma unroll
+  for (int kk = 0; kk < NK; ++kk) acc = Mfma<double>::run(fa[kk], fb[kk], acc);
+  return acc;
+}
+
+// Laplacian-mode variant for larger determinants (N > 8): the per-lane products M_c = A^-1 dA_c -- N^3 each,
+// 3N + 1 of them per matrix, what dominates this kernel from ~14 electrons on -- run on the float64 matrix cores
+// (v_mfma_f64_16x16x4_f64) with A^-1 as the A operand and dA_c as the B operand, both in LDS; four waves share
+// the (N/16)^2 output tiles; traces tr(M) and tr(M^2) from the LDS copy of M.  The inverse itself is the same
+// pivoted Gauss-Jordan as k_slogdet (256 threads instead of 64).  One workgroup per (walker, determinant).
+template <typename real>
+__global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ orb, int orb_width,
+                                                      double* __restrict__ logdet, int32_t* __restrict__ sign_k,
+                                                      LaneInfo li) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  const int N = li.N, NN = N * N, T = li.T;
+  const int nt = (N + 15) / 16, N16 = nt * 16, NS = N16 + 1;
+  double* A = reinterpret_cast<double*>(smem_raw);     // [N16][NS] value matrix, then dA_c (B operand)
+  double* Inv = A + N16 * NS;                           // [N16][NS] (A operand), zero outside N x N
+  double* Mx = Inv + N16 * NS;                          // [N16][NS] M_c
+  double* colp = Mx + N16 * NS;                         // [N16]
+  double* red = colp + N16;                             // [2][8] block reductions, double buffered
+  __shared__ int piv_s;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const long bk = blockIdx.x;  // b*K + k
+  const real* base = orb + bk * li.TP * orb_width;
+  for (int e = tid; e < N16 * N16; e += nthr) {
+    const int i = e / N16, j = e - i * N16;
+    const bool in = i < N && j < N;
+    A[i * NS + j] = in ? (double)base[i * N + j] : 0.0;
+    Inv[i * NS + j] = (in && i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double logabs = 0.0;
+  int sgn = 1;
+  for (int p = 0; p < N; ++p) {
+    if (tid == 0) {
+      int best = p;
+      double bv = fabs(A[p * NS + p]);
+      for (int i = p + 1; i < N; ++i) {
+        const double x = fabs(A[i * NS + p]);
+        if (x > bv) { bv = x; best = i; }   // first maximum, as LAPACK idamax
+      }
+      piv_s = best;
+    }
+    __syncthreads();
+    const int q = piv_s;
+    if (q != p) {
+      for (int j = tid; j < N; j += nthr) {
+        double t0 = A[p * NS + j]; A[p * NS + j] = A[q * NS + j]; A[q * NS + j] = t0;
+        t0 = Inv[p * NS + j]; Inv[p * NS + j] = Inv[q * NS + j]; Inv[q * NS + j] = t0;
+      }
+      sgn = -sgn;
+    }
+    __syncthreads();
+    const double piv = A[p * NS + p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) sgn = 0;
+    __syncthreads();
+    const double ip = 1.0 / piv;
+    for (int j = tid; j < N; j += nthr) { A[p * NS + j] *= ip; Inv[p * NS + j] *= ip; }
+    for (int i = tid; i < N; i += nthr) colp[i] = A[i * NS + p];
+    __syncthreads();
+    for (int e = tid; e < NN; e += nthr) {
+      const int i = e / N, j = e - i * N;
+      if (i != p) {
+        const double f = colp[i];
+        A[i * NS + j] -= f * A[p * NS + j];
+        Inv[i * NS + j] -= f * Inv[p * NS + j];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
+  double tr2_sum = 0.0;
+  typedef Mfma<double>::acc_t acc_t;
+  // dA_c of the next lane travels global -> registers while the current lane is multiplied (all loads of a
+  // thread are issued back to back; N*N <= 2304 = 9 per thread), registers -> LDS after the barrier
+  constexpr int MAXE = 9;
+  real regs[MAXE];
+  int lds_off[MAXE];
+#pragma unroll
+  for (int u = 0; u < MAXE; ++u) {
+    const int e = tid + u * 256;
+    const int i = e / N, j = e - i * N;
+    lds_off[u] = e < NN ? i * NS + j : -1;
+  }
+  auto issue = [&](int t) {
+    const real* At = base + (long)t * orb_width;
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) regs[u] = lds_off[u] >= 0 ? At[tid + u * 256] : (real)0;
+  };
+  auto put = [&]() {
+#pragma unroll
+    for (int u = 0; u < MAXE; ++u) if (lds_off[u] >= 0) A[lds_off[u]] = (double)regs[u];
+  };
+  if (T > 1) { issue(1); put(); }
+  double fa[12];                                            // this wave's row block of A^-1 as MFMA A fragments
+#pragma unroll
+  for (int kk = 0; kk < 12; ++kk) fa[kk] = (wave < nt && kk * 4 < N16) ? Inv[(wave * 16 + l15) * NS + kk * 4 + l4] : 0.0;
+  __syncthreads();
+  for (int t = 1; t < T; ++t) {
+    if (t + 1 < T) issue(t + 1);
+    if (wave < nt) {                                        // wave w owns row block w of M = A^-1 dA_c
+      for (int cb = 0; cb < nt; ++cb) {
+        const double* ib = A + l4 * NS + cb * 16 + l15;
+        acc_t acc;
+        if (nt == 1) acc = slogdet_tile_mm<4>(fa, ib, NS);
+        else if (nt == 2) acc = slogdet_tile_mm<8>(fa, ib, NS);
+        else acc = slogdet_tile_mm<12>(fa, ib, NS);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) Mx[(wave * 16 + Mfma<double>::row_of(lane, rg)) * NS + cb * 16 + l15] = acc[rg];
+      }
+    }
+    __syncthreads();                                        // M complete, dA_c no longer read
+    if (t + 1 < T) put();
+    double tr = 0.0, t2 = 0.0;
+    const bool need2 = t < T - 1;
+    for (int e = tid; e < NN; e += nthr) {
+      const int i = e / N, l = e - i * N;
+      const double m = Mx[i * NS + l];
+      if (i == l) tr += m;
+      if (need2) t2 += m * Mx[l * NS + i];
+    }
+    tr = wave_sum<double>(tr);
+    t2 = wave_sum<double>(t2);
+    double* rd = red + 8 * (t & 1);                         // double buffered: consumed after the next barrier
+    if (lane == 0) { rd[wave] = tr; rd[4 + wave] = t2; }
+    __syncthreads();                                        // next dA_c and the partial sums visible, M free
+    if (tid == 0) {
+      const double trs = rd[0] + rd[1] + rd[2] + rd[3];
+      if (need2) {
+        tr2_sum += rd[4] + rd[5] + rd[6] + rd[7];
+        logdet[bk * li.TP + t] = trs;
+      } else {
+        logdet[bk * li.TP + t] = trs - tr2_sum;
+      }
+    }
+  }
+  for (int t = T + tid; t < li.TP; t += nthr) logdet[bk * li.TP + t] = 0.0;
+}
+
 // Value-only variant (Metropolis sub-steps, ECP quadrature walkers; T = 1): sign and log|det| need only
 // the LU factorisation, not the inverse.  One wave per matrix, the matrix in LDS (double, odd row stride);
 // per pivot: wave-wide arg-max over the column (first maximum, as LAPACK idamax), row swap, and the rank-1
@@ -470,6 +626,8 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
                      bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps);
 }
 
+int slogdet_use_mfma = 1;   // engine option "slogdet_mfma": 1 where profitable (N > 16), 2 from N > 8 on, 0 never
+
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li) {
@@ -488,6 +646,10 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
   else if (li.T == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu<real>), dim3(grid), dim3(64), sizeof(double) * li.N * (li.N | 1), st,
                        orb, orb_width, logdet, sign_k, li);
+  else if (li.N <= 48 && ((slogdet_use_mfma == 1 && li.N > 16) || (slogdet_use_mfma >= 2 && li.N > 8)))     // >= 2 x 2 tiles (14 x 14: the wave-per-matrix kernel is faster); N16 <= 48: 57 KB of LDS
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_mfma<real>), dim3(grid), dim3(256),
+                       sizeof(double) * ((size_t)3 * (((li.N + 15) / 16) * 16) * ((((li.N + 15) / 16) * 16) + 1) + (((li.N + 15) / 16) * 16) + 16),
+                       st, orb, orb_width, logdet, sign_k, li);
   else if (li.N <= 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
                        sign_k, K, li);

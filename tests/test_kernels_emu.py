@@ -165,3 +165,25 @@ def test_emu_pair_compact_lanes_equal_full_lanes(spec_fn):
         if name.startswith('e') and full.ndim == 4:
             n_sparse += int((np.abs(full).sum(axis=(0, 1, 3)) == 0).sum() > 0)
     assert n_sparse > 0      # the dense evaluation really carries all-zero lanes in the edge stream
+
+
+def test_emu_slogdet_mfma_laplacian_n2():
+    """Laplacian-mode determinants of N2 (14 x 14, 44 lanes): the float64-MFMA kernel (k_slogdet_mfma: A^-1 dA_c on
+    the matrix cores, traces from LDS) against the interpreter's numpy inverse/trace formulas and E_loc."""
+    import dataclasses
+    spec = dataclasses.replace(ferminet(), embedding_dim=16, n_interactions=1, n_determinants=2)
+    mol = Molecule.from_name('N2')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=2, perturb_envelopes=0.3)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 1
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    eng.set_option('slogdet_mfma', 2)                       # force the MFMA kernel below its N > 16 default
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    eng.set_option('slogdet_mfma', 1)
+    np.testing.assert_array_equal(eng.debug_read('sign_k', B), it.sign_k)
+    np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
