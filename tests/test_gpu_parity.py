@@ -48,6 +48,7 @@ def report(name, payload):
 
 
 @pytest.mark.parametrize('spec_fn,molname,B', [(paulinet, 'LiH', 8), (ferminet, 'LiH', 5), (paulinet, 'Be', 4), (ferminet, 'N2', 3),
+                                               (paulinet, 'H2', 5), (paulinet, 'C', 3),
                                                (psiformer, 'LiH', 4), (psiformer, 'N2', 2), (transpsiformer, 'LiH', 4),
                                                (transpsiformer, 'cyclobutadiene_square', 1)])
 def test_f64_every_buffer(spec_fn, molname, B):

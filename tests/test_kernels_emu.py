@@ -187,3 +187,36 @@ def test_emu_slogdet_mfma_laplacian_n2():
     np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+
+
+@pytest.mark.parametrize('molname,B', [('H2', 5), ('C', 3)])
+def test_emu_edge_sizes(molname, B):
+    """Size edge cases through the emulated kernels: H2 (one electron per spin: empty same-spin edge segments,
+    the N = 2 determinant path of the one-launch sub-step, a ragged last tile) and the carbon atom (6 electrons,
+    spin-polarised 4 up / 2 down, the wave-per-matrix determinant kernels) -- local energy, gradient, psi and a
+    Metropolis run bit-exact against the oracle on the same noise."""
+    from oracle import sampling as osamp
+    from oracle import wf as owf
+    spec, mol, h, eng, r0, it = _setup(paulinet, molname, torch.float64, B)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    ref = it.run(r0, mol.coords, laplacian=True)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r0), return_grad=True)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-9, atol=1e-9)
+    sign0, log0 = eng.wf_eval(torch.as_tensor(r0))
+    val = it.run(r0, mol.coords, laplacian=False)
+    np.testing.assert_array_equal(sign0.numpy(), val['sign'])
+    np.testing.assert_allclose(log0.numpy(), val['log'], rtol=1e-11, atol=1e-11)
+    n_sub = 2
+    rng = np.random.default_rng(3)
+    noise, unif = rng.standard_normal((n_sub, B, h.n_elec, 3)), rng.random((n_sub, B))
+    st = {'r': torch.as_tensor(r0).clone(), 'log': log0.clone(), 'sign': sign0.clone(),
+          'age': torch.zeros(B, dtype=torch.int32), 'tau': torch.full((1,), 0.4, dtype=torch.float64)}
+    stats, acc = eng.mcmc_steps(st, n_sub, noise=noise, unif=unif, return_accept=True)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    ost = {'r': T(r0), 'sign': T(sign0.numpy()), 'log': T(log0.numpy()), 'age': torch.zeros(B, dtype=torch.int64), 'tau': 0.4}
+    ost, ostats, oacc = osamp.decorr_sample(owf.to_torch(tree), spec, ost, T(mol.coords), h.n_up, geom.F32_EPS, T(noise), T(unif))
+    np.testing.assert_array_equal(acc.numpy().astype(bool), oacc.numpy())
+    np.testing.assert_array_equal(st['age'].numpy(), ost['age'].numpy())
+    np.testing.assert_allclose(st['r'].numpy(), ost['r'].numpy(), rtol=0, atol=1e-13)
+    np.testing.assert_allclose(st['log'].numpy(), ost['log'].numpy(), rtol=1e-11, atol=1e-11)
