@@ -118,6 +118,7 @@ struct Engine : dqmc_ctx {
   char* d_mc = nullptr;
   size_t mc_bytes = 0;
   int32_t* d_nacc = nullptr;
+  void* d_tau_ring = nullptr;   // real[2]: step sizes of the last two one-launch sub-steps
   double* d_acc = nullptr;     // [1] acceptance, then [7] stats, then [7] energy record
   std::vector<real> wtmp;
   // fused value-only plan
@@ -174,6 +175,7 @@ struct Engine : dqmc_ctx {
     if (d_ws) (void)hipFree(d_ws);
     if (d_mc) (void)hipFree(d_mc);
     if (d_nacc) (void)hipFree(d_nacc);
+    if (d_tau_ring) (void)hipFree(d_tau_ring);
     if (d_acc) (void)hipFree(d_acc);
     if (d_ops) (void)hipFree(d_ops);
     if (d_fbufs) (void)hipFree(d_fbufs);
@@ -195,9 +197,10 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipMalloc((void**)&d_w, sizeof(real) * (nw ? nw : 1)));
     HIP_TRY(hipMalloc((void**)&d_it, sizeof(int32_t) * (nit ? nit : 1)));
     HIP_TRY(hipMalloc((void**)&d_charges, sizeof(double) * sys.n_nuc));
-    HIP_TRY(hipMalloc((void**)&d_nacc, sizeof(int32_t) * 2));
+    HIP_TRY(hipMalloc((void**)&d_nacc, sizeof(int32_t) * 4));
+    HIP_TRY(hipMalloc((void**)&d_tau_ring, sizeof(double) * 2));
     HIP_TRY(hipMalloc((void**)&d_acc, sizeof(double) * 16));
-    HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t) * 2, st));
+    HIP_TRY(hipMemsetAsync(d_nacc, 0, sizeof(int32_t) * 4, st));
     HIP_TRY(hipMemcpyAsync(d_charges, charges, sizeof(double) * sys.n_nuc, hipMemcpyHostToDevice, st));
     if (nit) HIP_TRY(hipMemcpyAsync(d_it, it, sizeof(int32_t) * nit, hipMemcpyHostToDevice, st));
     h_itable.assign(it, it + nit);
@@ -1167,7 +1170,8 @@ struct Engine : dqmc_ctx {
         const dqmc_op& fin = ops[fused_n_ops + 1];
         dqmc::FusedMc mc{};
         mc.enabled = 1; mc.noise = noise_s; mc.unif = unif_s; mc.r = r; mc.logpsi = logpsi; mc.sign = sign; mc.age = age;
-        mc.tau = tau; mc.counters = d_nacc; mc.accept_out = accept_out ? accept_out + (size_t)s * B : nullptr;
+        mc.tau_in = tau; mc.tau_ring = d_tau_ring; mc.counters = d_nacc; mc.s = s; mc.target = target;
+        mc.accept_out = accept_out ? accept_out + (size_t)s * B : nullptr;
         mc.max_age = max_age;
         mc.orb_op = -1;
         for (int j = 0; j < fused_n_ops; ++j) if (ops[f_order[j]].kind == DQMC_OP_ORBITALS) mc.orb_op = j;
@@ -1177,9 +1181,11 @@ struct Engine : dqmc_ctx {
         mc.same_scale = fin.f[0]; mc.anti_scale = fin.f[1];
         rc = run_fused2(nullptr, R, B, li, &mc);
         if (rc) return rc;
-        t_begin("mcmc", 0);
-        dqmc::launch_tau_update<real>(st, tau, d_nacc, B, target, d_acc);
-        t_end();
+        if (s + 1 == n_sub) {
+          t_begin("mcmc", 0);
+          dqmc::launch_tau_finalize<real>(st, tau, (const real*)d_tau_ring, d_nacc, s, B, target, d_acc);
+          t_end();
+        }
         continue;
       }
       if (noise_) {

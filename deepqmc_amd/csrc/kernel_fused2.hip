@@ -557,9 +557,9 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   }
   if (tid < 64) {                                   // WT <= 16 < 64: the walkers of the tile sit in wave 0
     for (int m = 1; m < 64; m <<= 1) n_acc += __shfl_xor(n_acc, m, 64);
-    // acceptance count: a fire-and-forget atomic (no return value, no fence); k_tau_update, launched right
-    // after this kernel on the same stream, turns it into the new step size (electron_samplers.py:121-126)
-    if (tid == 0 && n_acc) atomicAdd(a.mc.counters, n_acc);
+    // acceptance count: a fire-and-forget atomic (no return value, no fence); the NEXT sub-step's prologue
+    // turns it into the new step size (FusedMc in kernels.h)
+    if (tid == 0 && n_acc) atomicAdd(a.mc.counters + a.mc.s % 3, n_acc);
   }
 }
 
@@ -580,7 +580,22 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     const int n = nw * a.li.N * 3;
     const long g0 = (long)w0 * a.li.N * 3;
     if (a.mc.enabled) {
-      const real tau = reinterpret_cast<const real*>(a.mc.tau)[0];
+      // step size of this sub-step from the previous one's acceptance (the arithmetic of k_tau_update)
+      real tau;
+      if (a.mc.s == 0) {
+        tau = reinterpret_cast<const real*>(a.mc.tau_in)[0];
+      } else {
+        tau = reinterpret_cast<const real*>(a.mc.tau_ring)[(a.mc.s + 1) & 1];
+        if (a.mc.target > 0) {
+          const real acceptance = (real)a.mc.counters[(a.mc.s + 2) % 3] / (real)a.B;
+          const real m = acceptance > (real)0.05 ? acceptance : (real)0.05;
+          tau = tau / ((real)a.mc.target / m);
+        }
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        reinterpret_cast<real*>(a.mc.tau_ring)[a.mc.s & 1] = tau;
+        a.mc.counters[(a.mc.s + 1) % 3] = 0;
+      }
       const real* rg = reinterpret_cast<const real*>(a.mc.r) + g0;
       const real* nz = reinterpret_cast<const real*>(a.mc.noise) + g0;
       for (int e = threadIdx.x; e < n; e += blockDim.x) rs[e] = rg[e] + tau * nz[e];

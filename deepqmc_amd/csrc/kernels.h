@@ -130,8 +130,15 @@ struct FusedMc {
   void* logpsi;           // real[B]
   int32_t* sign;          // [B]
   int32_t* age;           // [B]
-  const void* tau;        // real[1]
-  int32_t* counters;      // [0] accepted walkers (k_tau_update consumes and clears it)
+  // Step size without a launch of its own: sub-step s reads the step size and the acceptance count of sub-step
+  // s-1 (tau_ring[(s+1)&1], counters[(s+2)%3]), every workgroup derives the same tau_s
+  // (electron_samplers.py:121-126), workgroup 0 records it in tau_ring[s&1] and clears counters[(s+1)%3];
+  // accepts of this sub-step go to counters[s%3].  k_tau_finalize after the last sub-step writes the caller's tau.
+  const void* tau_in;     // real[1]: the caller's step size (used by sub-step 0)
+  void* tau_ring;         // real[2]
+  int32_t* counters;      // int[3], all zero between calls
+  int s;                  // sub-step index within this call
+  double target;          // target acceptance (<= 0: no adaptation)
   uint8_t* accept_out;    // [B] or nullptr
   int max_age;
   int orb_op;             // scheduled index of the ORBITALS op (backflow buffer, envelope tables)
@@ -240,6 +247,9 @@ void launch_accept(hipStream_t st, real* r, real* logpsi, int32_t* sign, int32_t
                    int32_t* n_accept, uint8_t* accept_out);
 template <typename real>
 void launch_tau_update(hipStream_t st, real* tau, int32_t* n_accept, int B, double target, double* acc_out);
+template <typename real>
+void launch_tau_finalize(hipStream_t st, real* tau, const real* tau_ring, int32_t* counters, int s_last, int B, double target,
+                         double* acc_out);
 template <typename real>
 void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, const int32_t* age, const real* tau,
                           const double* acc, int B, int N, double eps, double* stats7);

@@ -77,6 +77,25 @@ __global__ void k_tau_update(real* __restrict__ tau, int32_t* __restrict__ n_acc
   }
 }
 
+// After the last one-launch sub-step (index s_last) of a call: the step size for the next call from the last
+// acceptance count, the acceptance for the sampler statistics, counters back to zero (FusedMc in kernels.h).
+template <typename real>
+__global__ void k_tau_finalize(real* __restrict__ tau, const real* __restrict__ tau_ring, int32_t* __restrict__ counters,
+                               int s_last, int B, double target, double* __restrict__ acc_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int n = counters[s_last % 3];
+    real t = tau_ring[s_last & 1];
+    const real acceptance = (real)n / (real)B;
+    if (target > 0) {
+      const real m = acceptance > (real)0.05 ? acceptance : (real)0.05;
+      t = t / ((real)target / m);
+    }
+    tau[0] = t;
+    acc_out[0] = (double)n / (double)B;
+    counters[0] = 0; counters[1] = 0; counters[2] = 0;
+  }
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh) {
   v = wave_sum<double>(v);
   const int w = threadIdx.x >> 6;
@@ -185,6 +204,12 @@ void launch_tau_update(hipStream_t st, real* tau, int32_t* n_accept, int B, doub
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tau_update<real>), dim3(1), dim3(64), 0, st, tau, n_accept, B, target, acc_out);
 }
 template <typename real>
+void launch_tau_finalize(hipStream_t st, real* tau, const real* tau_ring, int32_t* counters, int s_last, int B, double target,
+                         double* acc_out) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tau_finalize<real>), dim3(1), dim3(64), 0, st, tau, tau_ring, counters, s_last, B, target,
+                     acc_out);
+}
+template <typename real>
 void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, const int32_t* age, const real* tau,
                           const double* acc, int B, int N, double eps, double* stats7) {
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sampler_stats<real>), dim3(1), dim3(256), 0, st, r, logpsi, age, tau, acc, B, N,
@@ -201,6 +226,7 @@ void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B
   template void launch_accept<real>(hipStream_t, real*, real*, int32_t*, int32_t*, const real*, const real*,        \
                                     const int32_t*, const real*, int, int, int, int32_t*, uint8_t*);                \
   template void launch_tau_update<real>(hipStream_t, real*, int32_t*, int, double, double*);                        \
+  template void launch_tau_finalize<real>(hipStream_t, real*, const real*, int32_t*, int, int, double, double*);    \
   template void launch_sampler_stats<real>(hipStream_t, const real*, const real*, const int32_t*, const real*,      \
                                            const double*, int, int, double, double*);                               \
   template void launch_energy_stats<real>(hipStream_t, const real*, const real*, int, double*);
