@@ -744,6 +744,7 @@ struct Engine : dqmc_ctx {
             u.d.col0 = cg * 32;
             u.d.w_off = words[2 * j] / 4 + (cg * 2) * 64;
             u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
+            if ((rb0 + u.d.ma) * 16 <= Rtot && cg * 32 + 32 <= ldw) u.d.flags |= 16;
             u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
             level_units.push_back(u);
           }

@@ -188,13 +188,22 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
   }
   if (!dst_global) {
     const int db = d->dst_base, ds = d->dst_stride;
+    if (flags & 16) {                              // every row and column of the unit is valid: no exec masking
 #pragma unroll
-    for (int x = 0; x < MA; ++x)
+      for (int x = 0; x < MA; ++x)
 #pragma unroll
-      for (int rgi = 0; rgi < 4; ++rgi)
+        for (int rgi = 0; rgi < 4; ++rgi)
 #pragma unroll
-        for (int y = 0; y < NRW; ++y)
-          if (r_ok[x][rgi] && c_ok[y]) smem[db + m_e[x][rgi] * ds + colv[y]] = ov[x][rgi][y];
+          for (int y = 0; y < NRW; ++y) smem[db + m_e[x][rgi] * ds + colv[y]] = ov[x][rgi][y];
+    } else {
+#pragma unroll
+      for (int x = 0; x < MA; ++x)
+#pragma unroll
+        for (int rgi = 0; rgi < 4; ++rgi)
+#pragma unroll
+          for (int y = 0; y < NRW; ++y)
+            if (r_ok[x][rgi] && c_ok[y]) smem[db + m_e[x][rgi] * ds + colv[y]] = ov[x][rgi][y];
+    }
   } else {
     // walker-major HBM layout [B][rows][width]; m = rr*WT + wl
     const BufPtr fb = (BufPtr)a.fbufs + d->dst_base;

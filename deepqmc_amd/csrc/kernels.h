@@ -114,7 +114,7 @@ struct FDesc {
   int32_t dst_stride;
   int32_t res_base;     // LDS offset of (residual segment row 0, col0_dst), or -1
   int32_t res_stride;
-  int32_t flags;        // bits 0-1 activation, bit 2 scale by 1/sqrt(2), bit 3 destination in HBM
+  int32_t flags;        // bits 0-1 activation, bit 2 scale by 1/sqrt(2), bit 3 destination in HBM, bit 4 no partial row/column block
   int32_t g_r0, g_col0; // HBM destination: first row / column
   int32_t pad[4];
 };
