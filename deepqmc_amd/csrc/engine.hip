@@ -137,7 +137,8 @@ struct Engine : dqmc_ctx {
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
   bool lane_compact = true;
-  int attention_mfma = 1;      // 1: where profitable (N > 32), 2: wherever supported, 0: never
+  int attention_mfma = 1;      // 1: where profitable (N > 16), 2: wherever supported, 0: never
+  int slogdet_mfma = 1;        // 1: where profitable (N > 16), 2: from N > 8 on, 0: never
   std::vector<char> compact;
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
@@ -381,7 +382,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
     if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
-    if (s == "slogdet_mfma") { dqmc::slogdet_use_mfma = value; return DQMC_OK; }   // process-wide tuning switch
+    if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
@@ -1003,7 +1004,7 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_SLOGDET:
           t_begin("slogdet", 0);
           dqmc::launch_slogdet<real>(st, bptr(i[0]), bufs[i[0]].width, reinterpret_cast<double*>(d_ws + off_logdet),
-                                     reinterpret_cast<int32_t*>(d_ws + off_signk), B, sys.n_det, li);
+                                     reinterpret_cast<int32_t*>(d_ws + off_signk), B, sys.n_det, li, slogdet_mfma);
           t_end();
           break;
         case DQMC_OP_FINAL: {

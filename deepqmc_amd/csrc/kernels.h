@@ -192,8 +192,7 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
                      int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps);
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
-                    LaneInfo li);
-extern int slogdet_use_mfma;
+                    LaneInfo li, int use_mfma);
 struct FinalArgs {
   const void* r;          // real[B][N][3]
   const void* R;          // real[n_nuc][3]

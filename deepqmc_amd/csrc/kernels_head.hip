@@ -626,11 +626,12 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
                      bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps);
 }
 
-int slogdet_use_mfma = 1;   // engine option "slogdet_mfma": 1 where profitable (N > 16), 2 from N > 8 on, 0 never
-
+// use_mfma (engine option "slogdet_mfma"): 1 = f64-MFMA derivative traces where profitable (N > 16), 2 = from
+// N > 8 on, 0 = never
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
-                    LaneInfo li) {
+                    LaneInfo li, int use_mfma) {
+  const int slogdet_use_mfma = use_mfma;
   const unsigned grid = (unsigned)((long)B * K);
   const long n_mat = (long)B * K;
   const unsigned gsm = (unsigned)((n_mat + 255) / 256);
@@ -669,7 +670,7 @@ template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
   template void launch_orbitals<real>(hipStream_t, const real*, const real*, const real*, int, real*, int,           \
                                       const real*, const real*, const real*, const real*, int, int, int, int, int,   \
                                       LaneInfo, double);                                                             \
-  template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo);          \
+  template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo, int);     \
   template void launch_final<real>(hipStream_t, const FinalArgs&);
 DQMC_INST(float)
 DQMC_INST(double)
