@@ -57,3 +57,31 @@ def test_shard_bounds():
     import pytest
     with pytest.raises(ValueError):
         parallel.shard_bounds(10, 0, 3)
+
+
+def _overlap_worker(rank, world, port, ratio, weight, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from deepqmc_amd import loss
+    B = ratio.shape[-1]
+    lo, hi = parallel.shard_bounds(B, rank, world)
+    ov, stats = loss.compute_mean_overlap(torch.as_tensor(ratio[..., lo:hi]).contiguous(), torch.as_tensor(weight[..., lo:hi]).contiguous())
+    out[rank] = (float(ov), stats['overlap/pairwise/mean'].numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_mean_overlap():
+    """compute_mean_overlap (loss/overlap.py:124-149: all_device_mean over every rank's walkers) on two gloo ranks
+    equals the single-process value."""
+    from deepqmc_amd import loss
+    rng = np.random.default_rng(1)
+    ratio = rng.standard_normal((1, 3, 3, 16))
+    ratio[:, np.arange(3), np.arange(3)] = 1.0
+    weight = rng.random((1, 3, 16)) + 0.5
+    ref_ov, ref_stats = loss.compute_mean_overlap(torch.as_tensor(ratio), torch.as_tensor(weight))
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_overlap_worker, args=(2, _free_port(), ratio, weight, out), nprocs=2, join=True)
+    for rank in (0, 1):
+        np.testing.assert_allclose(out[rank][0], float(ref_ov), rtol=1e-12)
+        np.testing.assert_allclose(out[rank][1], ref_stats['overlap/pairwise/mean'].numpy(), rtol=1e-12, atol=1e-15)
