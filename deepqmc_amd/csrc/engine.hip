@@ -136,6 +136,7 @@ struct Engine : dqmc_ctx {
   long long* d_prof = nullptr;
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
+  size_t ws_budget = (size_t)64 << 30;   // activation workspace per evaluation chunk (option "ws_budget_mb")
   bool lane_compact = true;
   int attention_mfma = 1;      // 1: where profitable (N > 16), 2: wherever supported, 0: never
   int slogdet_mfma = 1;        // 1: where profitable (N > 16), 2: from N > 8 on, 0: never
@@ -382,6 +383,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
     if (s == "fused_version") { fused_version = value; return DQMC_OK; }
     if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
+    if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
@@ -894,10 +896,35 @@ struct Engine : dqmc_ctx {
   }
   real* bptr(int b) { return reinterpret_cast<real*>(d_ws + buf_off[b]); }
 
-  // Execute the layer program on B walkers.  laplacian: TP lanes and local-energy outputs.
+  // Workspace bytes per walker for an evaluation with TP lanes (what plan() allocates, without alignment slack).
+  size_t ws_bytes_per_walker(int TP) const {
+    size_t b = 0;
+    for (size_t k = 0; k < bufs.size(); ++k) b += sizeof(real) * (size_t)bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width;
+    return b + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det;
+  }
+
+  // Execute the layer program on B walkers, in chunks if the activation workspace of the whole batch would exceed
+  // ws_budget (benzene/Psiformer in Laplacian mode needs ~0.2 GB per walker: 2048 walkers per GPU do not fit 288 GB
+  // at once).  Chunks are still thousands of MFMA row blocks each.
   int run(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
           real* grad) {
     if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    const int T = laplacian ? 3 * N + 2 : 1, TP = laplacian ? (T + 15) / 16 * 16 : 1;
+    const size_t per = ws_bytes_per_walker(TP);
+    long chunk = per ? (long)(ws_budget / per) : B;
+    if (chunk < 1) chunk = 1;
+    if (chunk >= B) return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad);
+    for (int b0 = 0; b0 < B; b0 += (int)chunk) {
+      const int nb = (B - b0) < chunk ? (B - b0) : (int)chunk;
+      const int rc = run_chunk(r + (size_t)b0 * N * 3, R, nb, laplacian, logpsi ? logpsi + b0 : nullptr, sign ? sign + b0 : nullptr,
+                               e_loc ? e_loc + b0 : nullptr, stats ? stats + b0 : nullptr, B, grad ? grad + (size_t)b0 * 3 * N : nullptr);
+      if (rc) return rc;
+    }
+    return DQMC_OK;
+  }
+
+  int run_chunk(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
+                long stats_ld, real* grad) {
     dqmc::LaneInfo li;
     li.N = N;
     li.T = laplacian ? 3 * N + 2 : 1;
@@ -1021,7 +1048,7 @@ struct Engine : dqmc_ctx {
           a.same_scale = op.f[0]; a.anti_scale = op.f[1];
           a.eps = sys.norm_eps; a.e_nuc = sys.e_nuc;
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
-          a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.grad = grad;
+          a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
           t_begin("final", 0);
           dqmc::launch_final<real>(st, a);
           t_end();

@@ -214,7 +214,8 @@ struct FinalArgs {
   void* logpsi;   // real[B]
   int32_t* sign;  // [B]
   void* e_loc;    // real[B]
-  void* stats;    // real[6][B]
+  void* stats;    // real[6][stats_ld], this call's walkers at columns 0..B-1
+  long stats_ld;  // leading dimension of stats (the caller's total batch when evaluating a chunk)
   void* grad;     // real[B][3N]
 };
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a);

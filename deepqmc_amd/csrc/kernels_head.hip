@@ -644,12 +644,12 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.stats) {
     real* s = reinterpret_cast<real*>(a.stats);
-    s[0L * a.B + b] = (real)v_el;
-    s[1L * a.B + b] = (real)e_kin;
-    s[2L * a.B + b] = (real)v_loc;
-    s[3L * a.B + b] = (real)0;
-    s[4L * a.B + b] = (real)lap;
-    s[5L * a.B + b] = (real)qf2;
+    s[0L * a.stats_ld + b] = (real)v_el;
+    s[1L * a.stats_ld + b] = (real)e_kin;
+    s[2L * a.stats_ld + b] = (real)v_loc;
+    s[3L * a.stats_ld + b] = (real)0;
+    s[4L * a.stats_ld + b] = (real)lap;
+    s[5L * a.stats_ld + b] = (real)qf2;
   }
 }
 

@@ -203,7 +203,10 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * levels, 0: program order); "fused_occ": register budget as workgroups per CU (0 = from the LDS size);
  * "fused_lds_kb", "fused_sched_kb": LDS budgets; "fused_dbg": clock stamps readable through
  * dqmc_debug_read(buf = -3); "fused_print": plan summary on stderr; "ecp_max_cfg": quadrature walkers
- * per value-mode batch of the non-local ECP term.  Unknown names return DQMC_E_ARG. */
+ * per value-mode batch of the non-local ECP term; "ws_budget_mb": activation workspace per evaluation
+ * (larger batches are split into walker chunks); "lane_compact" (1): 8-lane storage of the edge stream;
+ * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never).
+ * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 
 /* Per-kernel timing (HIP events on the context's stream).  enable != 0 starts recording
