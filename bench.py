@@ -8,7 +8,14 @@ record).  Workload = BASELINE.json configs[1]: LiH (4 e-), PauliNet ansatz, 4096
 GPU (weak scaling), synthetic walkers and random-init weights, float32.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...      (re-executes itself under torch.distributed.run, one rank per GPU, RCCL)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+The walkers of an N-GPU run are the reference's split of ONE global batch of N x `--walkers` walkers
+(`electron_batch_size // device_count`, sampling_utils.py:253-262 -> parallel.shard_bounds).  The timed
+region is `--steps` VMC steps bracketed by barrier + synchronize, repeated back to back until >= 2 s of
+steady state have been measured (at least 10 blocks); `ms_per_step` is the median block (max over ranks
+per block), min / max are reported beside it.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (the forward-Laplacian
 linear layer) against the exact-f32 MFMA peak; `cpu_baseline` is the PyTorch-CPU oracle timed
@@ -34,53 +41,94 @@ from deepqmc_amd.wf import NeuralNetworkWaveFunction  # noqa: E402
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
-def _cpu_worker(args):
-    """One single-threaded oracle process: times psi and local-energy evaluations."""
-    molname, spec_name, seed, n_sub, budget_s, widx = args
+def _cpu_eloc_fns(molname, spec_name, dtype_name):
+    """Batched oracle closures: vmap over walkers of the per-walker local energy (forward-over-reverse Hessian
+    trace, `jacfwd(grad(log|psi|))`) and of psi -- the CPU stand-in SURVEY.md section 8d specifies."""
     import torch as _t
-    _t.set_num_threads(1)
+    from torch.func import grad, jacfwd, vmap
     from deepqmc_amd.params import init_params
-    from deepqmc_amd.sampling import synthetic_walkers
     from deepqmc_amd.spec import ANSATZES
     from oracle import geom, physics
     from oracle import wf as owf
-    hamil = MolecularHamiltonian(mol=Molecule.from_name(molname))
-    spec = ANSATZES[spec_name]()
-    p = owf.to_torch(init_params(spec, hamil.n_up, hamil.n_down, hamil.n_nuc, seed=seed, perturb_envelopes=0.05))
-    T = lambda a: _t.as_tensor(np.asarray(a), dtype=_t.float64)
+    dt = _t.float32 if dtype_name == 'f32' else _t.float64
+    mol = Molecule.from_name(molname)
+    hamil = MolecularHamiltonian(mol=mol)
+    spec = ANSATZES[spec_name](mol.charges) if spec_name == 'transpsiformer' else ANSATZES[spec_name]()
+    p = owf.to_torch(init_params(spec, hamil.n_up, hamil.n_down, hamil.n_nuc, seed=0, perturb_envelopes=0.05), dtype=dt)
+    T = lambda a: _t.as_tensor(np.asarray(a), dtype=dt)
     R, Z = T(hamil.mol.coords), T(hamil.mol.charges)
-    r = T(synthetic_walkers(hamil, 256, seed=100 + widx))
-    physics.batch_local_energy(p, spec, r[:1], R, Z, hamil.n_up, geom.F32_EPS)      # warm-up
-    t0, n_e = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 0.6 * budget_s:
-        physics.batch_local_energy(p, spec, r[n_e % 256:n_e % 256 + 1], R, Z, hamil.n_up, geom.F32_EPS)
-        n_e += 1
-    t_e = time.perf_counter() - t0
-    t0, n_w = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 0.4 * budget_s:
-        physics.batch_wave_function(p, spec, r[n_w % 256:n_w % 256 + 1], R, hamil.n_up, geom.F32_EPS)
-        n_w += 1
-    t_w = time.perf_counter() - t0
-    return n_e, t_e, n_w, t_w
+    eps = geom.F32_EPS
+
+    def logpsi(flat):
+        return owf.wave_function(p, spec, flat.reshape(-1, 3), R, hamil.n_up, eps)[1]
+
+    def eloc(rw):
+        x = rw.reshape(-1)
+        g = grad(logpsi)(x)
+        lap = _t.diagonal(jacfwd(grad(logpsi))(x)).sum()
+        return (-0.5 * (lap + (g ** 2).sum()) + physics.electronic_potential(rw, eps) + physics.local_potential(rw, R, Z)
+                + physics.nuclear_energy(R, Z))
+
+    return hamil, T, vmap(eloc), vmap(lambda rw: logpsi(rw.reshape(-1)))
 
 
-def cpu_baseline(molname, spec_name, n_sub, budget_s=20.0):
-    """The oracle ("port" of the reference's JAX-CPU path: same per-walker algorithm,
-    Hessian-trace Laplacian by forward-over-reverse autodiff, float64 PyTorch) timed on this
-    box's host cores: one single-threaded process per core (<= 64), a bounded sample each."""
+def _cpu_time(fn, x, budget_s, min_rep=3):
+    fn(x)                                       # warm-up (first call traces the functorch transforms)
+    ts = []
+    t_end = time.perf_counter() + budget_s
+    while len(ts) < min_rep or (time.perf_counter() < t_end and len(ts) < 50):
+        t0 = time.perf_counter()
+        fn(x)
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), len(ts)
+
+
+def _cpu_worker(args):
+    """One oracle process with `threads` intra-op threads: median time of a batched E_loc and a batched psi call."""
+    molname, spec_name, dtype_name, batch, threads, budget_s, widx = args
+    import torch as _t
+    _t.set_num_threads(threads)
+    from deepqmc_amd.sampling import synthetic_walkers
+    hamil, T, f_eloc, f_psi = _cpu_eloc_fns(molname, spec_name, dtype_name)
+    r = T(synthetic_walkers(hamil, batch, seed=100 + widx))
+    with _t.no_grad():
+        t_e, n_e = _cpu_time(f_eloc, r, 0.6 * budget_s)
+        t_w, n_w = _cpu_time(f_psi, r, 0.3 * budget_s)
+    return batch / t_e, batch / t_w, n_e, n_w
+
+
+def cpu_baseline(molname, spec_name, n_sub, dtype_name='f32', batch=256, budget_s=10.0):
+    """The oracle ("port": the reference's per-walker algorithm restated in PyTorch -- NOT the reference JAX-CPU
+    path, which cannot run in this image) timed on this box's host cores in the reference's production dtype,
+    batched with torch.func.vmap.  Two layouts are timed on a bounded sample and the faster one is reported:
+    one process with all threads, and one process per 8 cores with 8 threads each."""
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    with mp.get_context('spawn').Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(molname, spec_name, 0, n_sub, budget_s, w) for w in range(cores)])
-    eloc_rate = sum(n_e / t_e for n_e, t_e, _, _ in res)      # aggregate over processes
-    wf_rate = sum(n_w / t_w for _, _, n_w, t_w in res)
-    per_walker_step = n_sub / wf_rate + 1.0 / eloc_rate
+    cores = os.cpu_count() or 1
+    layouts = [(1, cores)]
+    if cores >= 16:
+        layouts.append((cores // 8, 8))
+    best = None
+    for n_proc, threads in layouts:
+        jobs = [(molname, spec_name, dtype_name, batch, threads, budget_s, w) for w in range(n_proc)]
+        if n_proc == 1:
+            res = [_cpu_worker(jobs[0])]
+        else:
+            with mp.get_context('spawn').Pool(n_proc) as pool:
+                res = pool.map(_cpu_worker, jobs)
+        eloc_rate, wf_rate = sum(x[0] for x in res), sum(x[1] for x in res)
+        cand = {'eloc_rate': eloc_rate, 'wf_rate': wf_rate, 'n_proc': n_proc, 'threads': threads,
+                'n_eloc_calls': sum(x[2] for x in res), 'n_psi_calls': sum(x[3] for x in res)}
+        if best is None or cand['eloc_rate'] > best['eloc_rate']:
+            best = cand
+    per_walker_step = n_sub / best['wf_rate'] + 1.0 / best['eloc_rate']
     return {
         'value': 1.0 / per_walker_step, 'unit': 'walker*E_loc evals/s (VMC step incl. %d sub-steps)' % n_sub,
-        'eloc_only_evals_per_s': eloc_rate, 'psi_evals_per_s': wf_rate, 'cores': cores, 'kind': 'port',
-        'sample': f'{sum(x[0] for x in res)} local energies + {sum(x[2] for x in res)} psi evaluations in '
-                  f'{budget_s:.0f} s over {cores} single-threaded processes, PyTorch-CPU float64 oracle '
-                  f'(the reference JAX-CPU path is not runnable in this image)',
+        'eloc_only_evals_per_s': best['eloc_rate'], 'psi_evals_per_s': best['wf_rate'],
+        'cores': best['n_proc'] * best['threads'], 'kind': 'port',
+        'sample': f"oracle-CPU stand-in (not the reference JAX-CPU path): torch.func.vmap over {batch} walkers of the per-walker "
+                  f"local energy (jacfwd(grad) Laplacian) and of psi, {dtype_name}, {best['n_proc']} process(es) x {best['threads']} "
+                  f"threads, median of {best['n_eloc_calls']} E_loc + {best['n_psi_calls']} psi batched calls "
+                  f"(~{budget_s:.0f} s per layout, layouts tried: {layouts})",
     }
 
 
@@ -118,24 +166,60 @@ def main():
                     'Metropolis sub-steps of step k+1 (software pipelining; same work per step)')
     ap.add_argument('--attention-mfma', type=int, default=-1, help='0: scalar attention kernel, 2: MFMA kernel wherever supported '
                     '(library default 1: MFMA where profitable)')
-    ap.add_argument('--fused-version', type=int, default=0, help='1: first fused kernel (in-kernel op interpreter); 2 (library default): descriptor driven')
     ap.add_argument('--fused-wt', type=int, default=0, help='walkers per workgroup tile of the fused psi kernel')
     ap.add_argument('--fused-dbg', type=int, default=0, help='ablation bitmask of the fused kernel (profiling only)')
     ap.add_argument('--fused-occ', type=int, default=0, help='register budget of the fused kernel: workgroups per CU (2..4)')
     ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
     ap.add_argument('--fused-sched', type=int, default=-1, help='0: keep program order; 1 (library default): reorder ops into full dependency levels (more LDS)')
+    ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
+    ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state time the timed blocks must cover')
+    ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
+                    'launch / shard / reduce path without a GPU; the numbers mean nothing)')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # launched as plain `python bench.py --gpus N`: become N ranks (one process per GPU) under torch.distributed.run
+        n_dev = args.gpus if args.emulated else (torch.cuda.device_count() if torch.cuda.is_available() else 0)
+        if n_dev < args.gpus:
+            sys.exit(f'bench.py: --gpus {args.gpus} requested but only {n_dev} GPU device(s) are visible on this node')
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (no CPU fallback)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    if world != args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} does not match the launcher\'s WORLD_SIZE={world}')
+    lib = None
+    if args.emulated:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from simt_util import emu_lib
+        lib = emu_lib()
+        device = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            sys.exit('bench.py needs a GPU (there is no CPU fallback; --emulated is a test harness)')
+        if local_rank >= torch.cuda.device_count():
+            sys.exit(f'bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} device(s) are visible')
+        torch.cuda.set_device(local_rank)
+        device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if args.emulated:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=device)
+
+    def sync():
+        if device.type == 'cuda':
+            torch.cuda.synchronize(device)
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     mol = Molecule.from_name(args.molecule)
@@ -147,13 +231,11 @@ def main():
                                      ecp_tables={ELEMENTS[int(z)]: tab(int(z)) for z in set(mol.charges) if z > 2})
     else:
         hamil = MolecularHamiltonian(mol=mol)
-    wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device)
+    wf = NeuralNetworkWaveFunction(hamil, args.ansatz, dtype=dtype, device=device, lib=lib)
     params = wf.init(0, perturb_envelopes=0.05)
     eng = wf.engine(params)
     if args.attention_mfma >= 0:
         eng.set_option('attention_mfma', args.attention_mfma)
-    if args.fused_version:
-        eng.set_option('fused_version', args.fused_version)
     if args.fused_sched >= 0:
         eng.set_option('fused_sched', args.fused_sched)
     if args.fused_occ:
@@ -166,15 +248,26 @@ def main():
     if args.fused_dbg:
         eng.set_option('fused_dbg', args.fused_dbg)
     B = args.walkers
-    sampler = DecorrSampler(hamil, wf, length=args.n_sub)
-    state = sampler.init(1000 + rank, params, B)
+    # this rank's shard of the global batch: electron_batch_size // device_count (sampling_utils.py:253-262)
+    lo, hi = parallel.shard_bounds(B * world, rank, world)
+    from deepqmc_amd.sampling import synthetic_walkers
+
+    def shard_initializer(hamil_, n, seed):
+        assert n == hi - lo
+        return synthetic_walkers(hamil_, B * world, seed=seed)[lo:hi]
+
+    sampler = DecorrSampler(hamil, wf, length=args.n_sub, sample_initializer=shard_initializer)
+    state = sampler.init(1000, params, B)
     loc_ene = hamil.local_energy(wf)
+    n_ranks_seen = len(parallel.all_gather_records(np.zeros(7), device if not args.emulated else 'cpu'))   # one real collective
+    if world > 1:
+        assert n_ranks_seen == torch.distributed.get_world_size() == world
 
     def barrier():
-        torch.cuda.synchronize(device)
+        sync()
         if world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize(device)
+        sync()
 
     def vmc_step(step, state):
         if args.n_sub > 0:
@@ -215,71 +308,92 @@ def main():
             return pipe['stats']
 
     step_fn = vmc_step_pipelined if args.overlap else vmc_step
+    stats = None
     for s in range(args.warmup):
         state, stats = step_fn(s, state)
     if args.overlap:
         stats = drain()
-    barrier()
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        state, stats = step_fn(args.warmup + s, state)
-    if args.overlap:
-        stats = drain()          # the last step's E_loc and reduction are inside the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_block(first_step):
+        nonlocal state, stats
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(args.steps):
+            state, stats = step_fn(first_step + s, state)
+        if args.overlap:
+            stats = drain()          # the last step's E_loc and reduction are inside the timed region
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    blocks = [timed_block(args.warmup)]
+    n_blocks = args.repeats if args.repeats > 0 else max(10, int(np.ceil(args.min_seconds / max(blocks[0], 1e-6))))
+    n_blocks = min(n_blocks, 2000)
+    if world > 1:            # every rank must run the same number of blocks
+        t = torch.tensor([n_blocks], dtype=torch.int64, device=device)
+        torch.distributed.broadcast(t, 0)
+        n_blocks = int(t.item())
+    for k in range(1, n_blocks):
+        blocks.append(timed_block(args.warmup + k * args.steps))
+    elapsed = float(np.median(blocks))
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world / (elapsed / args.steps)
 
-    # ---- pure E_loc throughput (n_sub = 0), not the headline ----
-    r = state['r']
-    for _ in range(2):
-        loc_ene(None, params, r)
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    n_rep = max(5, args.steps)
-    for _ in range(n_rep):
-        loc_ene(None, params, r)
-    torch.cuda.synchronize(device)
-    eloc_only = B * world / ((time.perf_counter() - t0) / n_rep)
+    eloc_only, roofline = None, None
+    if not args.emulated:       # (the emulated test harness only exercises launch / shard / reduce)
+        # ---- pure E_loc throughput (n_sub = 0), not the headline ----
+        r = state['r']
+        for _ in range(2):
+            loc_ene(0, params, r)
+        sync()
+        t0 = time.perf_counter()
+        n_rep = max(5, args.steps)
+        for k in range(n_rep):
+            loc_ene(k, params, r)
+        sync()
+        eloc_only = B * world / ((time.perf_counter() - t0) / n_rep)
 
-    # ---- roofline of the dominant kernel: HIP events around every launch, same workload ----
-    eng.timing(True)
-    eng.timing_reset()
-    for s in range(3):
-        state, stats = vmc_step(10_000 + s, state)
-    torch.cuda.synchronize(device)
-    rep = eng.timing_report()
-    eng.timing(False)
-    names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
-             'fused_psi': 'k_fused2_value (LDS-resident psi evaluation, v_mfma_f32_16x16x4_f32)',
-             'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + '
-                              'determinants + accept, v_mfma_f32_16x16x4_f32)'}
-    cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
-    dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
-    lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
-    total_ms = sum(v['ms'] for v in rep.values()) or 1.0
-    achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
-    traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused2_value', 'fused_substep': 'k_fused2_value'}[dom],
-                                             f'{args.molecule}/{args.ansatz}/{B}/{args.dtype}')
-    roofline = {
-        'bound': 'mfma', 'kernel': names[dom],
-        'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
-        'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-        'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
-        'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
-        'share_of_kernel_time': lin['ms'] / total_ms,
-        'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items()},
-    }
+        # ---- roofline of the dominant kernel: HIP events around every launch, same workload ----
+        eng.timing(True)
+        eng.timing_reset()
+        for s in range(3):
+            state, stats = vmc_step(10_000_000 + s, state)
+        sync()
+        rep = eng.timing_report()
+        eng.timing(False)
+        names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
+                 'fused_psi': 'k_fused2_value (LDS-resident psi evaluation, v_mfma_f32_16x16x4_f32)',
+                 'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + '
+                                  'determinants + accept, v_mfma_f32_16x16x4_f32)'}
+        cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
+        dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
+        lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
+        total_ms = sum(v['ms'] for v in rep.values()) or 1.0
+        achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
+        traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused2_value', 'fused_substep': 'k_fused2_value'}[dom],
+                                                 f'{args.molecule}/{args.ansatz}/{B}/{args.dtype}')
+        roofline = {
+            'bound': 'mfma', 'kernel': names[dom],
+            'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
+            'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
+            'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
+            'share_of_kernel_time': lin['ms'] / total_ms,
+            'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items()},
+        }
 
     if rank == 0:
         out = {
             'metric': 'walker*local-energy evals/sec (VMC step: n_sub Metropolis sub-steps + E_loc + energy reduction)',
             'value': value, 'unit': 'walker*E_loc evals/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'timed_blocks': len(blocks), 'timed_seconds': float(np.sum(blocks)),
+            'ms_per_step_min': 1e3 * float(np.min(blocks)) / args.steps, 'ms_per_step_max': 1e3 * float(np.max(blocks)) / args.steps,
+            'n_ranks_seen': n_ranks_seen,
             'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
             'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, {B} walkers/GPU, '
                                    f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats',
@@ -289,11 +403,13 @@ def main():
             'flops_per_eloc': (3 * hamil.n_elec + 2) * eng.program.flops_per_walker,
             'roofline': roofline,
         }
+        if args.emulated:
+            out['data'] = 'EMULATED on the CPU (test harness): not a measurement'
         if args.ecp:
             out['data'] += ', synthetic ECP coefficients'
             out['config']['workload'] += ' + Gaussian-type ECP (12-point quadrature)'
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub)
+            out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub, args.dtype)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -24,6 +24,7 @@ SIGNATURES = [
     ('dqmc_set_weights', c_int, [c_void_p, POINTER(c_double), c_size_t]),
     ('dqmc_wf_eval', c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     ('dqmc_local_energy', c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ('dqmc_psi_grad', c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     ('dqmc_mcmc_steps', c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_double, c_uint64, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
     ('dqmc_set_ecp', c_int, [c_void_p, c_int, POINTER(c_double), c_int, c_int, POINTER(c_double)]),

@@ -47,6 +47,7 @@ struct dqmc_ctx {
   virtual int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) = 0;
   virtual int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
                            int32_t* sign) = 0;
+  virtual int psi_grad(const void* r, const void* R, int B, void* logpsi, int32_t* sign, void* grad) = 0;
   virtual int mcmc(void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R, int B, int n_sub,
                    int max_age, double target, uint64_t seed, const void* noise, const void* unif, uint8_t* accept_out,
                    double* stats7) = 0;
@@ -56,6 +57,7 @@ struct dqmc_ctx {
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
+  int device = 0;           // every entry point makes this the calling thread's current device
   // timing
   bool timing = false;
   std::map<std::string, TimingRec> trec;
@@ -123,14 +125,10 @@ struct Engine : dqmc_ctx {
   std::vector<real> wtmp;
   // fused value-only plan
   bool fused_enabled = true;
-  // measured on MI355X (LiH/PauliNet, 4096 walkers): full dependency levels + 4-walker tiles
-  // (2 workgroups per CU) is the fastest configuration of the latency-bound fused kernel
-  int fused_n_ops = 0, fused_WT = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 3, fused_occ = 2, fused_occ_req = 0;
-  size_t fused_lds = 0, fused_lds_budget = 80 * 1024, wpk_cap = 0;
-  std::vector<dqmc::FusedBuf> fbufs_h;
+  int fused_n_ops = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 3, fused_occ_req = 0;
+  size_t wpk_cap = 0;
   std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
   dqmc_op* d_ops = nullptr;
-  dqmc::FusedBuf* d_fbufs = nullptr;
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
@@ -143,7 +141,7 @@ struct Engine : dqmc_ctx {
   std::vector<char> compact;
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
-  int fused_version = 2, fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
+  int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
   size_t fused_sched_budget = 36 * 1024;   // bytes live per level the list scheduler (mode 3) aims for
   const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
@@ -180,7 +178,6 @@ struct Engine : dqmc_ctx {
     if (d_tau_ring) (void)hipFree(d_tau_ring);
     if (d_acc) (void)hipFree(d_acc);
     if (d_ops) (void)hipFree(d_ops);
-    if (d_fbufs) (void)hipFree(d_fbufs);
     if (d_wpk_off) (void)hipFree(d_wpk_off);
     if (d_wpk) (void)hipFree(d_wpk);
   }
@@ -373,15 +370,14 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
-  // ---- fused value-only evaluation (kernel_fused.hip) -----------------------------------
+  // ---- fused value-only evaluation (kernel_fused2.hip) ----------------------------------
   // Ops [0, fused_n_ops) (everything up to and including ORBITALS) run in one kernel on a tile
   // of WT walkers with LDS-resident buffers; buffers read by later ops stay in the workspace.
   int option(const char* name, int value) override {
     const std::string s(name);
     if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
-    if (s == "fused_occ") { fused_occ = value > 0 ? value : 2; fused_occ_req = value; return DQMC_OK; }
-    if (s == "fused_version") { fused_version = value; return DQMC_OK; }
+    if (s == "fused_occ") { fused_occ_req = value; return DQMC_OK; }
     if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
@@ -389,8 +385,8 @@ struct Engine : dqmc_ctx {
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
-      fprintf(stderr, "[dqmc] fused plan: v1 WT=%d lds=%zu B; v2 WT=%d lds=%zu B; %d fused ops, %d levels\n", fused_WT, fused_lds,
-              fused2_WT, fused2_lds, fused_n_ops, fused_n_ops ? f_level[fused_n_ops - 1] + 1 : 0);
+      fprintf(stderr, "[dqmc] fused plan: WT=%d lds=%zu B; %d fused ops, %d levels\n", fused2_WT, fused2_lds, fused_n_ops,
+              fused_n_ops ? f_level[fused_n_ops - 1] + 1 : 0);
       return DQMC_OK;
     }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
@@ -400,7 +396,7 @@ struct Engine : dqmc_ctx {
       if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80 + 1024)));
       return DQMC_OK;
     }
-    if (s == "fused_lds_kb") { fused_lds_budget = fused2_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
+    if (s == "fused_lds_kb") { fused2_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
     return fail(DQMC_E_ARG, "unknown option " + s);
   }
 
@@ -549,12 +545,8 @@ struct Engine : dqmc_ctx {
     for (int j = 0; j < no; ++j) f_level[j] = lvl[f_order[j]];
   }
 
-  // LDS placement of the buffers for a tile of WT walkers: first-fit over live level intervals.
-  // The first `meta` bytes of LDS hold the program (ops, buffer table, per-op words).
-  size_t fused_meta_bytes() const {
-    return (size_t)dqmc::fused_meta_bytes(fused_n_ops, (int)bufs.size());
-  }
-  size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb, bool with_meta = true) const {
+  // LDS placement of the buffers for a tile of WT walkers: interval colouring over live level ranges.
+  size_t fused_layout(int WT, std::vector<dqmc::FusedBuf>& fb) const {
     const int nb = (int)bufs.size(), no = fused_n_ops;
     const int BIG = 1 << 30;
     std::vector<int> first(nb, BIG), last(nb, -1);
@@ -574,7 +566,7 @@ struct Engine : dqmc_ctx {
     // first-fit-in-time by ~10 % here, which decides how many workgroups share a CU).
     struct Seg { size_t off, len; int a, b; };
     std::vector<Seg> placed;
-    const size_t base = with_meta ? fused_meta_bytes() / sizeof(real) : 0;
+    const size_t base = 0;
     size_t peak = base;
     std::vector<int> order;
     for (int b = 0; b < nb; ++b) {
@@ -628,32 +620,19 @@ struct Engine : dqmc_ctx {
         fused_sched_budget = (size_t)kb * 1024;
         fused_schedule();
         std::vector<dqmc::FusedBuf> fbt;
-        fit = fused_layout(4, fbt, false) + 16 + dqmc::fused2_scratch_bytes(4, N, sys.n_det, (int)sizeof(real)) <= fused2_lds_quarter;
+        fit = fused_layout(4, fbt) + 16 + dqmc::fused2_scratch_bytes(4, N, sys.n_det, (int)sizeof(real)) <= fused2_lds_quarter;
       }
       if (!fit) { fused_sched_mode = 1; fused_schedule(); fused_sched_mode = 3; }   // too big for that: full levels
     } else {
       fused_schedule();
     }
-    fused_WT = 0;
-    const int cand[] = {32, 24, 16, 12, 8, 6, 4, 3, 2, 1};
-    for (int WT : cand) {
-      if (fused_wt_req > 0 && WT != fused_wt_req) continue;
-      std::vector<dqmc::FusedBuf> fb;
-      const size_t bytes = fused_layout(WT, fb);
-      if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused_lds_budget)) { fused_WT = WT; fused_lds = bytes; fbufs_h = fb; break; }
-    }
-    if (fused_WT == 0) { fused_n_ops = 0; return DQMC_OK; }   // does not fit: layered path only
-    for (int k = 0; k < fused_n_ops; ++k)                     // residual inputs must be LDS-resident
-      if (ops[k].kind == DQMC_OP_LINEAR && ops[k].i[25] >= 0 && fbufs_h[ops[k].i[25]].is_global) { fused_n_ops = 0; return DQMC_OK; }
     if (!d_ops) {
       HIP_TRY(hipMalloc((void**)&d_ops, sizeof(dqmc_op) * ops.size()));
-      HIP_TRY(hipMalloc((void**)&d_fbufs, sizeof(dqmc::FusedBuf) * bufs.size()));
       HIP_TRY(hipMalloc((void**)&d_wpk_off, 2 * sizeof(int32_t) * ops.size()));
     }
     std::vector<dqmc_op> sched(fused_n_ops);
     for (int j = 0; j < fused_n_ops; ++j) sched[j] = ops[f_order[j]];
     HIP_TRY(hipMemcpy(d_ops, sched.data(), sizeof(dqmc_op) * fused_n_ops, hipMemcpyHostToDevice));
-    if (dqmc::fused_set_lds_limit<real>(fused_lds) != 0) { fused_n_ops = 0; return DQMC_OK; }
     const int rc = pack_fused_weights();
     if (rc) return rc;
     return build_fused2_plan();
@@ -668,14 +647,14 @@ struct Engine : dqmc_ctx {
     const int cand[] = {16, 8, 4, 2, 1};
     std::vector<dqmc::FusedBuf> fb;
     auto with_scratch = [&](size_t act, int WT) { return (act + 15) / 16 * 16 + (size_t)dqmc::fused2_scratch_bytes(WT, N, sys.n_det, (int)sizeof(real)); };
-    if (fused_wt_req <= 0 && with_scratch(fused_layout(4, fb, false), 4) <= fused2_lds_quarter) {
+    if (fused_wt_req <= 0 && with_scratch(fused_layout(4, fb), 4) <= fused2_lds_quarter) {
       // 4 walkers per tile and 4 tiles per CU: for the batch sizes of the north star (4096 walkers = 1024 tiles =
       // 256 CUs x 4) the whole batch is ONE round of co-resident workgroups (measured fastest)
-      fused2_WT = 4; fused2_lds = with_scratch(fused_layout(4, fb, false), 4);
+      fused2_WT = 4; fused2_lds = with_scratch(fused_layout(4, fb), 4);
     } else {
       for (int WT : cand) {
         if (fused_wt_req > 0 && WT != fused_wt_req) continue;
-        const size_t bytes = with_scratch(fused_layout(WT, fb, false), WT);
+        const size_t bytes = with_scratch(fused_layout(WT, fb), WT);
         if (bytes <= (fused_wt_req > 0 ? (size_t)160 * 1024 : fused2_lds_budget)) { fused2_WT = WT; fused2_lds = bytes; break; }
       }
     }
@@ -853,26 +832,6 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
-  int run_fused(const real* r, const real* R, int B, dqmc::LaneInfo li) {
-    for (size_t b = 0; b < bufs.size(); ++b) fbufs_h[b].goff = (long)buf_off[b];
-    HIP_TRY(hipMemcpyAsync(d_fbufs, fbufs_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
-    dqmc::FusedArgs<real> a{};
-    a.ops = d_ops; a.n_ops = fused_n_ops; a.fbufs = d_fbufs; a.n_bufs = (int)bufs.size(); a.op_words = d_wpk_off;
-    a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
-    a.B = B; a.WT = fused_WT; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
-    double flops = 0;
-    for (int k = 0; k < fused_n_ops; ++k)
-      if (ops[k].kind == DQMC_OP_LINEAR) {
-        int ktot = 0;
-        for (int p = 0; p < ops[k].i[0]; ++p) ktot += ops[k].i[3 + 4 * p];
-        flops += 2.0 * B * ops[k].i[20] * (double)ktot * ops[k].i[21];
-      }
-    t_begin("fused_psi", flops);
-    dqmc::launch_fused_value<real>(st, a, (B + fused_WT - 1) / fused_WT, fused_lds, fused_occ);
-    t_end();
-    return DQMC_OK;
-  }
-
   static bool lanes_supported(int TP) {
     return TP == 1 || TP == 16 || TP == 32 || TP == 48 || TP == 64 || TP == 96 || TP == 128;
   }
@@ -933,8 +892,8 @@ struct Engine : dqmc_ctx {
     int rc = plan(B, li.TP);
     if (rc) return rc;
     size_t first_op = 0;
-    if (!laplacian && fused_enabled && fused_n_ops > 0) {
-      rc = (fused_version >= 2 && fused2_WT > 0) ? run_fused2(r, R, B, li) : run_fused(r, R, B, li);
+    if (!laplacian && fused_enabled && fused_n_ops > 0 && fused2_WT > 0) {
+      rc = run_fused2(r, R, B, li);
       if (rc) return rc;
       first_op = (size_t)fused_n_ops;
     }
@@ -1046,7 +1005,7 @@ struct Engine : dqmc_ctx {
           a.alphas = d_w + i[3];
           a.cusp_kind = i[2];
           a.same_scale = op.f[0]; a.anti_scale = op.f[1];
-          a.eps = sys.norm_eps; a.e_nuc = sys.e_nuc;
+          a.eps = sys.norm_eps;
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
           a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
           t_begin("final", 0);
@@ -1070,6 +1029,12 @@ struct Engine : dqmc_ctx {
     if (ecp_n_nl == 0)
       return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, (real*)e_loc, (real*)stats, (real*)grad);
     return local_energy_ecp((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
+  }
+
+  // log|psi|, sign and grad log|psi| from the forward-Laplacian pass alone: no potentials beyond k_final's, no
+  // non-local ECP quadrature (what value_and_grad(psi) gives the reference's Langevin sampler)
+  int psi_grad(const void* r, const void* R, int B, void* logpsi, int32_t* sign, void* grad) override {
+    return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, nullptr, nullptr, (real*)grad);
   }
 
   // Effective core potentials: host tables (ecp/gaussian_type_ecp.py:32-93 layout) -> device.
@@ -1180,7 +1145,7 @@ struct Engine : dqmc_ctx {
     }
     // whole sub-step in one launch (kernel_fused2.hip: propose in the prologue, determinants / CI sum / accept /
     // tau adaptation in the tail) when the ansatz tail is the plain SLOGDET + FINAL pair and N <= 4
-    const bool one_launch = fused_enabled && fused_version >= 2 && fused2_WT > 0 && fused_substep && N >= 2 && N <= 4 &&
+    const bool one_launch = fused_enabled && fused2_WT > 0 && fused_substep && N >= 2 && N <= 4 &&
                             sys.n_nuc <= 8 && fused2_WT <= 16 && (int)ops.size() == fused_n_ops + 2 &&
                             ops[fused_n_ops].kind == DQMC_OP_SLOGDET && ops[fused_n_ops + 1].kind == DQMC_OP_FINAL &&
                             substep_mat_off() >= 0;
@@ -1325,12 +1290,12 @@ int dqmc_create(dqmc_ctx** out, int device, void* stream, const dqmc_system* sys
   int rc;
   if (sys->dtype == 0) {
     auto* e = new Engine<float>();
-    e->st = (hipStream_t)stream;
+    e->st = (hipStream_t)stream; e->device = device;
     rc = e->init(sys, charges_host, bufs_host, n_bufs, ops_host, n_ops, weights_host, n_weights, itable_host, n_itable);
     ctx = e;
   } else if (sys->dtype == 1) {
     auto* e = new Engine<double>();
-    e->st = (hipStream_t)stream;
+    e->st = (hipStream_t)stream; e->device = device;
     rc = e->init(sys, charges_host, bufs_host, n_bufs, ops_host, n_ops, weights_host, n_weights, itable_host, n_itable);
     ctx = e;
   } else {
@@ -1341,30 +1306,44 @@ int dqmc_create(dqmc_ctx** out, int device, void* stream, const dqmc_system* sys
   return DQMC_OK;
 }
 
-void dqmc_destroy(dqmc_ctx* ctx) { delete ctx; }
+void dqmc_destroy(dqmc_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  delete ctx;
+}
 
 int dqmc_set_weights(dqmc_ctx* ctx, const double* w, size_t n) {
   if (!ctx || !w) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->set_weights(w, n);
 }
 int dqmc_wf_eval(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logpsi, int32_t* sign) {
   if (!ctx || !r || !R || !logpsi || !sign) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->wf_eval(r, R, B, logpsi, sign);
 }
 int dqmc_local_energy(dqmc_ctx* ctx, const void* r, const void* R, int B, void* e_loc, void* stats, void* grad,
                       void* logpsi, int32_t* sign) {
   if (!ctx || !r || !R || !e_loc) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->local_energy(r, R, B, e_loc, stats, grad, logpsi, sign);
+}
+int dqmc_psi_grad(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logpsi, int32_t* sign, void* grad) {
+  if (!ctx || !r || !R || !grad) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->psi_grad(r, R, B, logpsi, sign, grad);
 }
 int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R,
                     int B, int n_sub, int max_age, double target_acceptance, uint64_t seed, const void* noise,
                     const void* unif, uint8_t* accept_out, double* stats7_host) {
   if (!ctx || !r || !logpsi || !sign || !age || !tau || !R) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->mcmc(r, logpsi, sign, age, tau, R, B, n_sub, max_age, target_acceptance, seed, noise, unif, accept_out,
                    stats7_host);
 }
 int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l, int n_terms_nl, const double* nl_host) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->set_ecp(n_terms_loc, loc_host, n_l, n_terms_nl, nl_host);
 }
 int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi) {
@@ -1373,6 +1352,7 @@ int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi) {
 }
 int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, double* out7_host) {
   if (!ctx || !e_loc || !out7_host) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->energy_stats(e_loc, w, B, out7_host);
 }
 
@@ -1396,11 +1376,13 @@ int dqmc_merge_energy_stats(const double* rec, int n_ranks, double* out5) {
 
 int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
   if (!ctx || !out) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->debug_read(buf, out, n);
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
   return ctx->option(name, value);
 }
 

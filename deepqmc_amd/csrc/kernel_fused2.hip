@@ -1,9 +1,9 @@
 // kernel_fused2.hip -- value-only psi evaluation (the Metropolis hot loop) as ONE kernel, descriptor driven.
 //
-// Same job as kernel_fused.hip (a workgroup owns a tile of WT walkers and runs the whole layer program
-// on it with every activation resident in LDS; reference sampling/electron_samplers.py:76-81 vmap(wf)),
-// but everything that is identical for all workgroups is decided on the HOST once per program
-// (engine.hip: build_fused2_plan) instead of being recomputed by every wave of every workgroup:
+// A workgroup owns a tile of WT walkers and runs the whole layer program on it with every activation
+// resident in LDS (reference sampling/electron_samplers.py:76-81 vmap(wf)).  Everything that is identical
+// for all workgroups is decided on the HOST once per program (engine.hip: build_fused2_plan) instead of
+// being recomputed by every wave of every workgroup:
 //
 //   * the linear layers are cut into units (row blocks x 2 column blocks) and the units of a dependency
 //     level are dealt to the 4 waves by cost; each wave walks its own list of 160-byte unit descriptors

@@ -53,7 +53,7 @@ template <typename real> struct LinArgs {
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 
-// ---- kernel_fused.hip ----
+// ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
 struct FusedBuf {
   int off;        // LDS offset in elements (LDS-resident buffers)
   int stride;     // LDS row stride in elements (width + 2)
@@ -62,35 +62,6 @@ struct FusedBuf {
   int is_global;  // 1: lives in the HBM workspace (read by later kernels)
   long goff;      // byte offset of the buffer in the workspace
 };
-template <typename real> struct FusedArgs {
-  const ::dqmc_op* ops;   // device: the scheduled ops (dependency-level order), up to ORBITALS
-  int n_ops;
-  const FusedBuf* fbufs;  // device
-  int n_bufs;
-  const int32_t* op_words; // device: per scheduled op {packed-weight offset, barrier-after flag}
-  const real* w;          // plain weights (biases, envelope parameters)
-  const real* wpk;        // packed weights: [k/4][col block][64 lanes]
-  const int32_t* itable;
-  char* ws;               // HBM workspace base
-  const real* r;          // [B][N][3]
-  const real* R;          // [n_nuc][3]
-  int B, WT, n_up, n_nuc, K;
-  long long* prof;        // optional: shader-clock stamp per op of workgroup 0 (profiling only, else nullptr)
-  LaneInfo li;
-  double eps;
-};
-// Layout of the program copy at the start of the fused kernel's LDS (16-byte aligned sections).
-__host__ __device__ inline int fused_meta_off_bufs(int n_ops) { return ((int)sizeof(::dqmc_op) * n_ops + 15) / 16 * 16; }
-__host__ __device__ inline int fused_meta_off_words(int n_ops, int n_bufs) {
-  return fused_meta_off_bufs(n_ops) + ((int)sizeof(FusedBuf) * n_bufs + 15) / 16 * 16;
-}
-__host__ __device__ inline int fused_meta_bytes(int n_ops, int n_bufs) {
-  return fused_meta_off_words(n_ops, n_bufs) + (8 * n_ops + 15) / 16 * 16;
-}
-template <typename real> void launch_fused_value(hipStream_t st, const FusedArgs<real>& a, int n_blocks, size_t lds_bytes, int occ);
-template <typename real> int fused_set_lds_limit(size_t lds_bytes);
-
-// ---- kernel_fused2.hip: descriptor-driven variant (the default) ----
 // One entry of a wave's work list; built on the host (engine.hip: build_fused2_plan), read through scalar loads.
 struct FDesc {
   int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves)
@@ -207,7 +178,7 @@ struct FinalArgs {
   const void* alphas;     // real[2]
   int cusp_kind;
   double same_scale, anti_scale;
-  double eps, e_nuc;
+  double eps;
   int B, n_up, n_nuc, K;
   LaneInfo li;
   // outputs (any may be nullptr)

@@ -639,8 +639,16 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
         }
       }
     }
+  // nuclear repulsion of the geometry of THIS call (reference physics.py:112-116: recomputed from phys_conf.R)
+  double e_nuc = 0.0;
+  for (int n = 0; n < a.n_nuc; ++n)
+    for (int m = n + 1; m < a.n_nuc; ++m) {
+      double d2 = 0.0;
+      for (int c = 0; c < 3; ++c) { const double d = (double)R[n * 3 + c] - (double)R[m * 3 + c]; d2 += d * d; }
+      e_nuc += a.charges[n] * a.charges[m] / sqrt(d2);
+    }
   const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
-  const double e_loc = e_kin + v_loc + v_el + a.e_nuc;      // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
+  const double e_loc = e_kin + v_loc + v_el + e_nuc;        // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.stats) {
     real* s = reinterpret_cast<real*>(a.stats);

@@ -29,7 +29,8 @@ class DqmcError(RuntimeError):
 
 
 def nuclear_energy(coords: np.ndarray, charges: np.ndarray) -> float:
-    """sum_{a<b} Z_a Z_b / R_ab (reference physics.py:112-116); constant per geometry."""
+    """sum_{a<b} Z_a Z_b / R_ab (reference physics.py:112-116).  Host-side helper (reports, tests); the
+    library recomputes the term on the device from the R of every call."""
     e = 0.0
     for a in range(len(charges)):
         for b in range(a + 1, len(charges)):
@@ -52,8 +53,7 @@ class Engine:
                                                 R=hamil.mol.coords, eps=self.norm_eps)
         self.N = hamil.n_up + hamil.n_down
         sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,
-                          0 if dtype == torch.float32 else 1, 0, self.norm_eps,
-                          nuclear_energy(hamil.mol.coords, hamil.ns_valence))
+                          0 if dtype == torch.float32 else 1, 0, self.norm_eps, 0.0)
         p = self.program
         self._bufs, self._ops = p.c_bufs(), p.c_ops()
         w = np.ascontiguousarray(p.weights, np.float64)
@@ -139,8 +139,14 @@ class Engine:
         r = self._t(r)
         B = r.shape[0]
         assert r.shape[1:] == (self.N, 3)
-        if getattr(self.hamil, 'pot', None) is not None:
+        if getattr(self.hamil, 'pot', None) is not None and self.hamil.pot.nl_params.size:
+            if rng is None and ecp_phi is None:      # gaussian_type_ecp.py:183 `assert rng is not None`
+                raise DqmcError('a Hamiltonian with a non-local ECP needs `rng` (the seed of the quadrature rotation)')
+            if ecp_phi is None and not isinstance(rng, (int, np.integer)):
+                raise DqmcError('`rng` must be an integer seed')
             self._ecp_phi = self._t(ecp_phi) if ecp_phi is not None else None      # keep alive during the call
+            if self._ecp_phi is not None and self._ecp_phi.shape[0] != B:
+                raise DqmcError('ecp_phi must have one row per walker')
             seed = int(rng) & (2 ** 64 - 1) if isinstance(rng, (int, np.integer)) else 0
             self._check(self.lib.dqmc_ecp_rotation(self._ctx, seed,
                                                    self._ecp_phi.data_ptr() if self._ecp_phi is not None else None))
@@ -154,15 +160,15 @@ class Engine:
 
     def psi_and_grad(self, r, R=None):
         """(sign, log|psi|, grad log|psi| [B,N,3]) in one forward-Laplacian pass -- what the reference's
-        LangevinSampler obtains with value_and_grad (electron_samplers.py:193-201)."""
+        LangevinSampler obtains with value_and_grad (electron_samplers.py:193-201).  No potential terms and
+        no ECP quadrature run (dqmc_psi_grad)."""
         r = self._t(r)
         B = r.shape[0]
-        e = torch.empty(B, dtype=self.dtype, device=self.device)
         grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device)
         logpsi = torch.empty(B, dtype=self.dtype, device=self.device)
         sign = torch.empty(B, dtype=torch.int32, device=self.device)
-        self._check(self.lib.dqmc_local_energy(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, e.data_ptr(), None,
-                                               grad.data_ptr(), logpsi.data_ptr(), sign.data_ptr()))
+        self._check(self.lib.dqmc_psi_grad(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, logpsi.data_ptr(),
+                                           sign.data_ptr(), grad.data_ptr()))
         return sign, logpsi, grad.reshape(B, self.N, 3)
 
     # ---- sampler ----------------------------------------------------------
@@ -170,6 +176,13 @@ class Engine:
                    seed: int = 0, noise=None, unif=None, R=None, want_stats=True, return_accept=False):
         """In-place Metropolis sub-steps on state {'r','log','sign','age','tau'} (device tensors)."""
         r, B = state['r'], state['r'].shape[0]
+        want = {'r': self.dtype, 'log': self.dtype, 'tau': self.dtype, 'sign': torch.int32, 'age': torch.int32}
+        for k, dt in want.items():     # raw device pointers cross the C ABI: the layout must be exactly the documented one
+            t = state[k]
+            if t.dtype != dt or not t.is_contiguous() or t.device.type != self.device.type:
+                raise DqmcError(f"sampler state '{k}' must be a contiguous {dt} tensor on {self.device}")
+        if r.shape != (B, self.N, 3) or any(state[k].shape[0] != B for k in ('log', 'sign', 'age')):
+            raise DqmcError('sampler state shapes do not match [B, N, 3] / [B]')
         acc = torch.empty(n_sub, B, dtype=torch.uint8, device=self.device) if return_accept else None
         stats = (ctypes.c_double * 7)()
         if noise is not None:

@@ -57,7 +57,10 @@ class MetropolisSampler:
     def sample(self, rng, state, params, R=None, noise=None, unif=None):
         """electron_samplers.py:140-152 / :347-357.  Returns (state, phys_conf, stats)."""
         eng = self.wf.engine(params)
-        st = {'r': state['r'], 'log': state['psi'].log, 'sign': state['psi'].sign, 'age': state['age'], 'tau': state['tau']}
+        # the reference's samplers are functional (a new state per call); dqmc_mcmc_steps updates its arguments
+        # in place, so it gets copies and the caller's previous state stays intact (rollback, multi-state loops)
+        st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
+              'age': state['age'].clone(), 'tau': state['tau'].clone()}
         stats = eng.mcmc_steps(st, self.length, max_age=self.max_age, target_acceptance=self.target_acceptance,
                                seed=int(rng), noise=noise, unif=unif, R=R)
         state = {'r': st['r'], 'psi': Psi(st['sign'], st['log']), 'age': st['age'], 'tau': st['tau']}

@@ -6,8 +6,11 @@
     psi    = ansatz.apply(params, phys_conf)   # Psi(sign[B], log[B]) on the GPU
 
 `apply` evaluates a whole batch (the reference vmaps its single-walker apply,
-sampling/electron_samplers.py:76-81).  One engine (HIP context) is cached per parameter
-tree identity; pass a new tree after an optimiser step and its weights are uploaded.
+sampling/electron_samplers.py:76-81).  One engine (HIP context) is kept per live parameter
+tree OBJECT: the cache holds a reference to the tree and matches it with `is`, so a recycled
+`id()` can never alias an engine holding other weights.  Pass a new tree object after an
+optimiser step and its weights are uploaded into the least recently used context; leaves
+mutated in place are not detected -- call `invalidate(params)` after doing that.
 """
 from __future__ import annotations
 
@@ -29,7 +32,7 @@ class NeuralNetworkWaveFunction:
         else:
             self.spec = ANSATZES[spec]() if isinstance(spec, str) else spec
         self.dtype, self.device, self.norm_eps, self._lib = dtype, device, norm_eps, lib
-        self._engines = {}       # id(params) -> Engine, most recently used last (one per electronic state)
+        self._engines = []       # [(params tree, Engine)], most recently used last (one per electronic state)
         self.max_engines = 8
 
     def init(self, rng=0, phys_conf=None, **kw):
@@ -39,20 +42,27 @@ class NeuralNetworkWaveFunction:
 
     def engine(self, params) -> Engine:
         """One HIP context per live parameter tree (e.g. per electronic state, the leading `S` axis of
-        the reference's params, wf/base.py:27); the least recently used context is re-targeted with
-        `set_params` once `max_engines` trees are alive."""
-        key = id(params)
-        eng = self._engines.pop(key, None)
-        if eng is None:
-            if len(self._engines) >= self.max_engines:
-                old_key = next(iter(self._engines))
-                eng = self._engines.pop(old_key)
-                eng.set_params(params)
-            else:
-                eng = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,
-                             norm_eps=self.norm_eps, lib=self._lib)
-        self._engines[key] = eng
+        the reference's params, wf/base.py:27).  The cache entry keeps the tree alive and is matched by
+        identity; once `max_engines` trees are alive the least recently used context is re-targeted
+        with `set_params` (no new allocation)."""
+        for k, (tree, eng) in enumerate(self._engines):
+            if tree is params:
+                self._engines.append(self._engines.pop(k))
+                return eng
+        if len(self._engines) >= self.max_engines:
+            _, eng = self._engines.pop(0)
+            eng.set_params(params)
+        else:
+            eng = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,
+                         norm_eps=self.norm_eps, lib=self._lib)
+        self._engines.append((params, eng))
         return eng
+
+    def invalidate(self, params=None):
+        """Re-upload the weights of `params` (all cached trees if None) after their leaves were changed in place."""
+        for tree, eng in self._engines:
+            if params is None or tree is params:
+                eng.set_params(tree)
 
     def apply(self, params, phys_conf, return_mos: bool = False) -> Psi:
         """types.py:135-150 (batched)."""

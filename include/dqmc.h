@@ -21,7 +21,8 @@
  * DEVICE pointer.  Walker-major contiguous layouts: r[B][N][3], R[n_nuc][3].  `real` is
  * float (dtype 0) or double (dtype 1), fixed per context.  Every function returns 0 on
  * success or a negative DQMC_E_* code and never throws; dqmc_last_error() gives a message.
- * A context is bound to one device and is not thread-safe; use one context per GPU.
+ * A context is bound to one device (every entry point makes it the calling thread's current device) and is
+ * not thread-safe; use one context per GPU.
  * All work is enqueued on the stream given at creation (0 = the null stream); functions
  * that return host values synchronise that stream.
  */
@@ -119,7 +120,8 @@ typedef struct dqmc_system {
   int32_t dtype;        /* 0 = float32, 1 = float64 */
   int32_t reserved;
   double norm_eps;      /* eps under the safe norm, utils.py:79-85 (finfo(dtype).eps) */
-  double e_nuc;         /* nuclear repulsion, physics.py:112-116 (constant per geometry) */
+  double e_nuc;         /* unused (kept for layout): the nuclear repulsion is recomputed from the R of every call,
+                           physics.py:112-116 */
 } dqmc_system;
 
 typedef struct dqmc_ctx dqmc_ctx;
@@ -145,6 +147,11 @@ int dqmc_wf_eval(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logps
  * (d log|psi| / dr, the quantum force), may be NULL; logpsi/sign may be NULL. */
 int dqmc_local_energy(dqmc_ctx* ctx, const void* r, const void* R, int B, void* e_loc,
                       void* stats, void* grad, void* logpsi, int32_t* sign);
+
+/* sign, log|psi| and grad log|psi| (real[B][3N]) from the forward-Laplacian pass alone -- no potentials, no
+ * non-local ECP quadrature: what jax.value_and_grad(psi) hands the reference's LangevinSampler
+ * (sampling/electron_samplers.py:193-201).  logpsi / sign may be NULL. */
+int dqmc_psi_grad(dqmc_ctx* ctx, const void* r, const void* R, int B, void* logpsi, int32_t* sign, void* grad);
 
 /* Gaussian-type effective core potential (reference ecp/gaussian_type_ecp.py:32-93 table layout,
  * :127-159 local part, :161-255 non-local part; replaces GaussianTypeECP.__init__'s pyscf lookup by
@@ -197,8 +204,7 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op (0 keeps every
  * activation buffer readable by dqmc_debug_read); "fused_substep" (1): fold propose / determinants /
- * accept of a Metropolis sub-step into that kernel when N <= 4; "fused_version" (2: descriptor-driven
- * kernel, 1: the first interpreter-style kernel); "fused_wt": walkers per workgroup tile (0 = automatic);
+ * accept of a Metropolis sub-step into that kernel when N <= 4; "fused_wt": walkers per workgroup tile (0 = automatic);
  * "fused_sched" (3: list scheduling under an LDS budget, 2: as late as possible, 1: full dependency
  * levels, 0: program order); "fused_occ": register budget as workgroups per CU (0 = from the LDS size);
  * "fused_lds_kb", "fused_sched_kb": LDS budgets; "fused_dbg": clock stamps readable through

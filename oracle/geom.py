@@ -48,10 +48,12 @@ def pairwise_self_distance(c: torch.Tensor, full: bool = False, eps: float = F64
     d = c[..., :, None, :] - c[..., None, :, :]
     dists = norm(d[..., i, j, :], safe=True, eps=eps)
     if full:
-        out = torch.zeros(d.shape[:-1], dtype=c.dtype)
-        out[..., i, j] = dists
-        out[..., j, i] = dists
-        return out
+        # out-of-place scatter (one-hot matrix) so that the function composes with torch.func.vmap / jacfwd
+        P = torch.zeros(len(i), n * n, dtype=c.dtype)
+        k = torch.arange(len(i))
+        P[k, i * n + j] = 1
+        P[k, j * n + i] = 1
+        return (dists @ P).reshape(*dists.shape[:-1], n, n)
     return dists
 
 

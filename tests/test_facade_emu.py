@@ -1,0 +1,104 @@
+"""Host facade contracts through the SIMT emulator: engine cache keyed by tree identity (no stale weights when
+CPython recycles an id), nuclear repulsion recomputed from the R of every call (reference physics.py:112-116),
+functional sampler states (reference samplers return new states), rng required with a non-local ECP
+(gaussian_type_ecp.py:183)."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from deepqmc_amd import MolecularHamiltonian, Molecule
+from deepqmc_amd.engine import DqmcError, Engine
+from deepqmc_amd.sampling import DecorrSampler, synthetic_walkers
+from deepqmc_amd.types import PhysicalConfiguration
+from deepqmc_amd.wf import NeuralNetworkWaveFunction
+from oracle import geom
+from simt_util import emu_lib
+
+
+def make(spec='paulinet', **kw):
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'), **kw)
+    wf = NeuralNetworkWaveFunction(h, spec, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    return h, wf
+
+
+def test_engine_cache_never_serves_stale_weights():
+    """The documented training-loop flow: a NEW parameter tree each iteration while old ones are freed.  An
+    id()-keyed cache returned engines holding old weights; identity-checked entries cannot."""
+    h, wf = make()
+    wf.max_engines = 2
+    r = torch.as_tensor(synthetic_walkers(h, 2, seed=3))
+    for it in range(8):
+        params = wf.init(it, perturb_envelopes=0.1)
+        got = wf.apply(params, r).log.numpy()
+        fresh = Engine(wf.spec, h, params, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+        np.testing.assert_array_equal(got, fresh.wf_eval(r)[1].numpy())
+        fresh.close()
+        del params
+        gc.collect()
+    assert len(wf._engines) <= 2
+    # leaves changed in place are picked up after invalidate()
+    params = wf.init(100, perturb_envelopes=0.1)
+    a = wf.apply(params, r).log.numpy().copy()
+    for mod in params.values():
+        for k in mod:
+            mod[k] = mod[k] * 1.01
+    wf.invalidate(params)
+    assert not np.allclose(wf.apply(params, r).log.numpy(), a)
+
+
+def test_nuclear_repulsion_follows_the_call_geometry():
+    h, wf = make()
+    params = wf.init(0, perturb_envelopes=0.1)
+    eng = wf.engine(params)
+    r = torch.as_tensor(synthetic_walkers(h, 2, seed=4))
+    R2 = h.mol.coords * 1.5
+    e_call, _ = eng.local_energy(PhysicalConfiguration(torch.as_tensor(R2), r, None))
+    mol2 = Molecule(coords=R2, charges=h.mol.charges, charge=h.mol.charge, spin=h.mol.spin)
+    h2 = MolecularHamiltonian(mol=mol2)
+    eng2 = Engine(wf.spec, h2, params, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    e_built, _ = eng2.local_energy(r)
+    np.testing.assert_allclose(e_call.numpy(), e_built.numpy(), rtol=1e-13, atol=1e-13)
+    e_orig, _ = eng.local_energy(r)
+    assert np.abs(e_orig.numpy() - e_call.numpy()).min() > 1e-3
+
+
+def test_sampler_states_are_not_aliased():
+    h, wf = make()
+    params = wf.init(0, perturb_envelopes=0.1)
+    sampler = DecorrSampler(h, wf, length=3, tau=0.4)
+    s0 = sampler.init(1, params, 4)
+    keep = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in s0.items() if k != 'psi'}
+    keep_log = s0['psi'].log.clone()
+    s1, pc, stats = sampler.sample(2, s0, params)
+    assert not torch.equal(s1['r'], s0['r'])                       # something moved ...
+    for k, v in keep.items():                                      # ... and the previous state is intact
+        assert torch.equal(s0[k], v), k
+    assert torch.equal(s0['psi'].log, keep_log)
+    with pytest.raises(DqmcError):
+        wf.engine(params).mcmc_steps({'r': s1['r'].float(), 'log': s1['psi'].log, 'sign': s1['psi'].sign, 'age': s1['age'],
+                                      'tau': s1['tau']}, 1)
+
+
+ECP_TABLES = {'Li': [0, [[-1, [[], [[5.41, 1.0]], [[4.6, -4.6]], [[2.7, 5.41]]]], [0, [[], [], [[1.33, 6.75]]]], [1, [[], [], [[1.25, 0.45]]]]]]}
+
+
+def test_ecp_needs_rng_and_psi_grad_skips_the_quadrature():
+    h, wf = make(ecp_type='synthetic', ecp_tables=ECP_TABLES)
+    params = wf.init(0, perturb_envelopes=0.1)
+    eng = wf.engine(params)
+    r = torch.as_tensor(synthetic_walkers(h, 2, seed=5))
+    with pytest.raises(DqmcError):
+        eng.local_energy(r, rng=None)
+    e, st, g = eng.local_energy(r, rng=3, return_grad=True)
+    eng.timing(True)
+    eng.timing_reset()
+    sign, log, grad = eng.psi_and_grad(r)
+    rep = eng.timing_report()
+    eng.timing(False)
+    assert 'ecp' not in rep                                        # no quadrature walkers were evaluated
+    np.testing.assert_allclose(grad.reshape(2, -1).numpy(), g.numpy(), rtol=1e-13)
+    s2, l2 = eng.wf_eval(r)
+    np.testing.assert_array_equal(sign.numpy(), s2.numpy())
+    np.testing.assert_allclose(log.numpy(), l2.numpy(), rtol=1e-12)

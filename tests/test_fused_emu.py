@@ -1,6 +1,5 @@
-"""The fused LDS-resident psi kernels (kernel_fused2.hip: descriptor driven, the default; kernel_fused.hip: the
-first, interpreter-style version) against the one-launch-per-op path and the oracle, through the SIMT
-emulator: same program, same weights, ragged last tile."""
+"""The fused LDS-resident psi kernel (kernel_fused2.hip, descriptor driven) against the one-launch-per-op path
+and the oracle, through the SIMT emulator: same program, same weights, ragged last tile."""
 import numpy as np
 import pytest
 import torch
@@ -16,9 +15,8 @@ from simt_util import emu_lib
 from test_program_interp import make_walkers
 
 
-@pytest.mark.parametrize('version', [2, 1])
 @pytest.mark.parametrize('spec_fn,dtype,wt', [(paulinet, torch.float64, 0), (paulinet, torch.float32, 4), (ferminet, torch.float64, 2)])
-def test_fused_matches_layered_and_oracle(spec_fn, dtype, wt, version):
+def test_fused_matches_layered_and_oracle(spec_fn, dtype, wt):
     spec = spec_fn()
     mol = Molecule.from_name('LiH')
     h = MolecularHamiltonian(mol=mol)
@@ -29,7 +27,6 @@ def test_fused_matches_layered_and_oracle(spec_fn, dtype, wt, version):
     rt = torch.as_tensor(r)
     if wt:
         eng.set_option('fused_wt', wt)
-    eng.set_option('fused_version', version)
     eng.set_option('fused', 1)
     s1, l1 = eng.wf_eval(rt)
     eng.set_option('fused', 0)
