@@ -57,6 +57,7 @@ struct dqmc_ctx {
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
+  int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   int device = 0;           // every entry point makes this the calling thread's current device
   // timing
   bool timing = false;
@@ -159,8 +160,24 @@ struct Engine : dqmc_ctx {
   char* d_ecp = nullptr;        // quadrature walkers + their psi + psi of the walkers themselves
   size_t ecp_bytes = 0;
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
+  // float64 refinement (float32 build): walkers flagged by k_final as ill conditioned (near a node of psi the kinetic
+  // energy is a difference of huge numbers and float32 round-off is amplified by the CI cancellation) are
+  // re-evaluated by a float64 twin of this context and their results replace the float32 ones
+  int refine = 1;
+  double refine_thresh = 16.0;
+  bool flag_on = false;
+  std::vector<double> w64_h, ecp_loc_h;
+  int ecp_loc_nt_h = 0;
+  dqmc_ctx* twin = nullptr;
+  int32_t* d_flag = nullptr;     // [0] = count, [1..] = walker indices
+  size_t flag_cap = 0;
+  char* d_ref = nullptr;
+  size_t ref_bytes = 0;
 
   ~Engine() override {
+    delete twin;
+    if (d_flag) (void)hipFree(d_flag);
+    if (d_ref) (void)hipFree(d_ref);
     if (d_descs) (void)hipFree(d_descs);
     if (d_wave_begin) (void)hipFree(d_wave_begin);
     if (d_fbufs2) (void)hipFree(d_fbufs2);
@@ -364,6 +381,10 @@ struct Engine : dqmc_ctx {
     if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
     wtmp.resize(n);
     for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
+    if (sizeof(real) == 4) {
+      w64_h.assign(w, w + n);
+      if (twin) { const int rc = twin->set_weights(w, n); if (rc) return rc; }
+    }
     HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (fused_n_ops > 0) return pack_fused_weights();
@@ -383,6 +404,8 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "refine") { refine = value; return DQMC_OK; }
+    if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
       fprintf(stderr, "[dqmc] fused plan: WT=%d lds=%zu B; %d fused ops, %d levels\n", fused2_WT, fused2_lds, fused_n_ops,
@@ -872,18 +895,18 @@ struct Engine : dqmc_ctx {
     const size_t per = ws_bytes_per_walker(TP);
     long chunk = per ? (long)(ws_budget / per) : B;
     if (chunk < 1) chunk = 1;
-    if (chunk >= B) return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad);
+    if (chunk >= B) return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
     for (int b0 = 0; b0 < B; b0 += (int)chunk) {
       const int nb = (B - b0) < chunk ? (B - b0) : (int)chunk;
       const int rc = run_chunk(r + (size_t)b0 * N * 3, R, nb, laplacian, logpsi ? logpsi + b0 : nullptr, sign ? sign + b0 : nullptr,
-                               e_loc ? e_loc + b0 : nullptr, stats ? stats + b0 : nullptr, B, grad ? grad + (size_t)b0 * 3 * N : nullptr);
+                               e_loc ? e_loc + b0 : nullptr, stats ? stats + b0 : nullptr, B, grad ? grad + (size_t)b0 * 3 * N : nullptr, b0);
       if (rc) return rc;
     }
     return DQMC_OK;
   }
 
   int run_chunk(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
-                long stats_ld, real* grad) {
+                long stats_ld, real* grad, int b_offset) {
     dqmc::LaneInfo li;
     li.N = N;
     li.T = laplacian ? 3 * N + 2 : 1;
@@ -1008,6 +1031,7 @@ struct Engine : dqmc_ctx {
           a.eps = sys.norm_eps;
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
           a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
+          if (flag_on && laplacian) { a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset; }
           t_begin("final", 0);
           dqmc::launch_final<real>(st, a);
           t_end();
@@ -1027,14 +1051,78 @@ struct Engine : dqmc_ctx {
   int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
                    int32_t* sign) override {
     if (ecp_n_nl == 0)
-      return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, (real*)e_loc, (real*)stats, (real*)grad);
+      return lap_refined((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
     return local_energy_ecp((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
   }
 
   // log|psi|, sign and grad log|psi| from the forward-Laplacian pass alone: no potentials beyond k_final's, no
   // non-local ECP quadrature (what value_and_grad(psi) gives the reference's Langevin sampler)
   int psi_grad(const void* r, const void* R, int B, void* logpsi, int32_t* sign, void* grad) override {
-    return run((const real*)r, (const real*)R, B, true, (real*)logpsi, sign, nullptr, nullptr, (real*)grad);
+    return lap_refined((const real*)r, (const real*)R, B, nullptr, nullptr, (real*)grad, (real*)logpsi, sign);
+  }
+
+  // The forward-Laplacian pass; in the float32 build followed by the float64 re-evaluation of the walkers k_final
+  // flagged (typically ~1 % of |psi|^2-distributed walkers; option "refine" 0 turns it off).
+  int lap_refined(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
+    last_refined = 0;
+    if constexpr (sizeof(real) == 8) {
+      return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+    } else {
+      if (!refine) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      if ((size_t)B + 1 > flag_cap) {
+        if (d_flag) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_flag)); d_flag = nullptr; }
+        HIP_TRY(hipMalloc((void**)&d_flag, sizeof(int32_t) * ((size_t)B + 1)));
+        flag_cap = (size_t)B + 1;
+      }
+      HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+      flag_on = true;
+      int rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      flag_on = false;
+      if (rc) return rc;
+      int32_t n = 0;
+      HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (n <= 0) return DQMC_OK;
+      if (n > B) n = B;
+      if (!twin) {
+        auto* t = new Engine<double>();
+        t->st = st; t->device = device;
+        dqmc_system s2 = sys;
+        s2.dtype = 1;
+        rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
+                     h_itable.data(), h_itable.size());
+        if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
+        if (rc) { delete t; return rc; }
+        t->ws_budget = ws_budget;
+        twin = t;
+      }
+      const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
+      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+      const size_t o_r = 0, o_R = o_r + al(sizeof(double) * (size_t)n * n3), o_e = o_R + al(sizeof(double) * nR3),
+                   o_s = o_e + al(sizeof(double) * n), o_g = o_s + al(sizeof(double) * 6 * (size_t)n),
+                   o_l = o_g + al(sizeof(double) * (size_t)n * n3), o_sg = o_l + al(sizeof(double) * n),
+                   tot = o_sg + al(sizeof(int32_t) * n);
+      if (tot > ref_bytes) {
+        if (d_ref) { HIP_TRY(hipFree(d_ref)); d_ref = nullptr; ref_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&d_ref, tot));
+        ref_bytes = tot;
+      }
+      double* r64 = (double*)(d_ref + o_r); double* R64 = (double*)(d_ref + o_R); double* e64 = (double*)(d_ref + o_e);
+      double* s64 = (double*)(d_ref + o_s); double* g64 = (double*)(d_ref + o_g); double* l64 = (double*)(d_ref + o_l);
+      int32_t* sg64 = (int32_t*)(d_ref + o_sg);
+      t_begin("refine", 0);
+      dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_flag + 1, n, n3, nR3, r64, R64);
+      t_end();
+      rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
+      if (rc) return rc;
+      t_begin("refine", 0);
+      dqmc::launch_refine_scatter(st, d_flag + 1, n, n3, e64, s64, g64, l64, sg64, (float*)e_loc, (float*)stats, (long)B, (float*)grad,
+                                  (float*)logpsi, sign);
+      t_end();
+      last_refined = n;
+      HIP_TRY(hipGetLastError());
+      return DQMC_OK;
+    }
   }
 
   // Effective core potentials: host tables (ecp/gaussian_type_ecp.py:32-93 layout) -> device.
@@ -1047,6 +1135,9 @@ struct Engine : dqmc_ctx {
     if (d_ecp_nl) { HIP_TRY(hipFree(d_ecp_nl)); d_ecp_nl = nullptr; }
     if (d_ecp_nuc) { HIP_TRY(hipFree(d_ecp_nuc)); d_ecp_nuc = nullptr; }
     ecp_nt_loc = ecp_n_nl = ecp_L = ecp_nt_nl = 0;
+    ecp_loc_h.clear(); ecp_loc_nt_h = 0;
+    if (loc && n_t_loc > 0 && sizeof(real) == 4) { ecp_loc_h.assign(loc, loc + (size_t)sys.n_nuc * 6 * n_t_loc); ecp_loc_nt_h = n_t_loc; }
+    if (twin) { const int rc = twin->set_ecp(n_t_loc, loc, 0, 0, nullptr); if (rc) return rc; }
     if (loc && n_t_loc > 0) {
       const size_t n = (size_t)sys.n_nuc * 6 * n_t_loc;
       HIP_TRY(hipMalloc((void**)&d_ecp_loc, sizeof(double) * n));
@@ -1097,7 +1188,7 @@ struct Engine : dqmc_ctx {
     real* rq = (real*)(d_ecp + o_rq); real* lq = (real*)(d_ecp + o_lq); int32_t* sq = (int32_t*)(d_ecp + o_sq);
     real* l0 = logpsi ? logpsi : (real*)(d_ecp + o_l0);
     int32_t* s0 = sign ? sign : (int32_t*)(d_ecp + o_s0);
-    int rc = run(r, R, B, true, l0, s0, e_loc, stats, grad);
+    int rc = lap_refined(r, R, B, e_loc, stats, grad, l0, s0);
     if (rc) return rc;
     dqmc::EcpArgs a{};
     a.r = r; a.R = R; a.nl_nuc = d_ecp_nuc; a.nl = d_ecp_nl; a.phi = ecp_phi; a.seed = ecp_seed;
@@ -1380,6 +1471,7 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
   return ctx->debug_read(buf, out, n);
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
+int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));

@@ -188,6 +188,13 @@ struct FinalArgs {
   void* stats;    // real[6][stats_ld], this call's walkers at columns 0..B-1
   long stats_ld;  // leading dimension of stats (the caller's total batch when evaluating a chunk)
   void* grad;     // real[B][3N]
+  // float64 refinement (float32 build): walkers whose E_loc is ill conditioned -- (|lap| + |grad|^2) / max(1, |E_loc|)
+  // above refine_thresh, i.e. near a node of psi where the kinetic energy is a difference of huge numbers, or a
+  // non-finite result -- are appended to flag_idx (global walker index b_offset + b); nullptr: no flagging
+  int32_t* flag_count;
+  int32_t* flag_idx;
+  double refine_thresh;
+  int b_offset;
 };
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a);
 
@@ -226,5 +233,10 @@ void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, con
                           const double* acc, int B, int N, double eps, double* stats7);
 template <typename real>
 void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B, double* out7);
+void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, int n, int n3, int nR3,
+                          double* r64, double* R64);
+void launch_refine_scatter(hipStream_t st, const int32_t* idx, int n, int n3, const double* e64, const double* st64,
+                           const double* g64, const double* lp64, const int32_t* sg64, float* e_loc, float* stats,
+                           long stats_ld, float* grad, float* logpsi, int32_t* sign);
 
 }  // namespace dqmc

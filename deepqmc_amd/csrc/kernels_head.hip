@@ -650,6 +650,10 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
   const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
   const double e_loc = e_kin + v_loc + v_el + e_nuc;        // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
+  if (a.flag_idx) {      // float32 build: hand ill-conditioned walkers to the float64 refinement pass
+    const double ratio = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc));
+    if (!(ratio <= a.refine_thresh)) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;
+  }
   if (a.stats) {
     real* s = reinterpret_cast<real*>(a.stats);
     s[0L * a.stats_ld + b] = (real)v_el;

@@ -227,6 +227,10 @@ class Engine:
         self._check(self.lib.dqmc_debug_read(self._ctx, idx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
         return out
 
+    def last_refined(self) -> int:
+        """Walkers the last local-energy call re-evaluated in float64 (dqmc_last_refined)."""
+        return int(self.lib.dqmc_last_refined(self._ctx))
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
 

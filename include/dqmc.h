@@ -201,6 +201,11 @@ int dqmc_merge_energy_stats(const double* records_host, int n_ranks, double* out
 int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out_host, size_t n);
 /* Lanes (TP) used by the last evaluation. */
 int dqmc_debug_lanes(dqmc_ctx* ctx);
+/* Walkers the last dqmc_local_energy / dqmc_psi_grad call re-evaluated in float64 (float32 contexts: the local
+ * energy near a node of psi is a difference of huge numbers, E_kin = -(lap + |grad|^2)/2 with both terms ~ 1/psi^2;
+ * walkers with (|lap| + |grad|^2) / max(1, |E_loc|) > "refine_thresh" (default 16) or a non-finite E_loc are run
+ * again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign replaced). */
+int dqmc_last_refined(dqmc_ctx* ctx);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op (0 keeps every
  * activation buffer readable by dqmc_debug_read); "fused_substep" (1): fold propose / determinants /
@@ -211,7 +216,8 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * dqmc_debug_read(buf = -3); "fused_print": plan summary on stderr; "ecp_max_cfg": quadrature walkers
  * per value-mode batch of the non-local ECP term; "ws_budget_mb": activation workspace per evaluation
  * (larger batches are split into walker chunks); "lane_compact" (1): 8-lane storage of the edge stream;
- * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never).
+ * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never);
+ * "refine" (1; float32 contexts): float64 re-evaluation of ill-conditioned walkers, "refine_thresh" (16): its trigger.
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 

@@ -102,3 +102,41 @@ def test_ecp_needs_rng_and_psi_grad_skips_the_quadrature():
     s2, l2 = eng.wf_eval(r)
     np.testing.assert_array_equal(sign.numpy(), s2.numpy())
     np.testing.assert_allclose(log.numpy(), l2.numpy(), rtol=1e-12)
+
+
+def test_f64_refinement_of_ill_conditioned_walkers():
+    """float32 context: walkers k_final flags ((|lap| + |grad|^2) / max(1, |E_loc|) above the threshold) are re-evaluated
+    by the float64 twin; their results equal a float64 engine's (rounded to float32), the others stay float32."""
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf32 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    wf64 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf32.init(5, perturb_envelopes=0.1)
+    e32, e64 = wf32.engine(params), wf64.engine(params)
+    B = 12
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=11).astype(np.float32))
+    e32.set_option('refine', 0)
+    e_plain, st_plain, g_plain = e32.local_energy(r, return_grad=True)
+    assert e32.last_refined() == 0
+    e32.set_option('refine', 1)
+    e32.set_option('refine_thresh', 3)            # low threshold: several of the 12 walkers qualify
+    e_ref, st_ref, g_ref = e32.local_energy(r, return_grad=True)
+    n = e32.last_refined()
+    ratio = ((st_plain['hamil/lap'].abs() + st_plain['hamil/quantum_force']) / e_plain.abs().clamp(min=1.0)).numpy()
+    flagged = ratio > 3
+    assert n == int(flagged.sum()) and 0 < n < B
+    R32 = torch.as_tensor(h.mol.coords, dtype=torch.float32).double()      # the twin sees the float32 context's geometry
+    e_d, st_d, g_d = e64.local_energy(PhysicalConfiguration(R32, r.double(), None), return_grad=True)
+    np.testing.assert_array_equal(e_ref.numpy()[flagged], e_d.numpy()[flagged].astype(np.float32))
+    np.testing.assert_array_equal(e_ref.numpy()[~flagged], e_plain.numpy()[~flagged])
+    np.testing.assert_array_equal(g_ref.numpy()[flagged], g_d.numpy()[flagged].astype(np.float32))
+    for k in st_ref:
+        np.testing.assert_array_equal(st_ref[k].numpy()[flagged], st_d[k].numpy()[flagged].astype(np.float32))
+        np.testing.assert_array_equal(st_ref[k].numpy()[~flagged], st_plain[k].numpy()[~flagged])
+    # set_params reaches the twin too
+    p2 = wf32.init(6, perturb_envelopes=0.1)
+    e32.set_params(p2)
+    e2, _ = e32.local_energy(r)
+    fresh = Engine(wf32.spec, h, p2, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    fresh.set_option('refine_thresh', 3)
+    e3, _ = fresh.local_energy(r)
+    np.testing.assert_array_equal(e2.numpy(), e3.numpy())
