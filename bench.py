@@ -97,16 +97,17 @@ def _cpu_worker(args):
     return batch / t_e, batch / t_w, n_e, n_w
 
 
-def cpu_baseline(molname, spec_name, n_sub, dtype_name='f32', batch=256, budget_s=10.0):
+def cpu_baseline_measure(molname, spec_name, n_sub, dtype_name='f32', batch=256, budget_s=8.0):
     """The oracle ("port": the reference's per-walker algorithm restated in PyTorch -- NOT the reference JAX-CPU
     path, which cannot run in this image) timed on this box's host cores in the reference's production dtype,
     batched with torch.func.vmap.  Two layouts are timed on a bounded sample and the faster one is reported:
-    one process with all threads, and one process per 8 cores with 8 threads each."""
+    one process with up to 16 intra-op threads, and one process per 8 cores (at most 24) with 8 threads each
+    (hundreds of intra-op threads on these small tensors only thrash)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    layouts = [(1, cores)]
+    layouts = [(1, min(cores, 16))]
     if cores >= 16:
-        layouts.append((cores // 8, 8))
+        layouts.append((min(cores // 8, 24), 8))
     best = None
     for n_proc, threads in layouts:
         jobs = [(molname, spec_name, dtype_name, batch, threads, budget_s, w) for w in range(n_proc)]
@@ -114,7 +115,10 @@ def cpu_baseline(molname, spec_name, n_sub, dtype_name='f32', batch=256, budget_
             res = [_cpu_worker(jobs[0])]
         else:
             with mp.get_context('spawn').Pool(n_proc) as pool:
-                res = pool.map(_cpu_worker, jobs)
+                try:
+                    res = pool.map_async(_cpu_worker, jobs).get(timeout=20 * budget_s)
+                except mp.TimeoutError:
+                    continue
         eloc_rate, wf_rate = sum(x[0] for x in res), sum(x[1] for x in res)
         cand = {'eloc_rate': eloc_rate, 'wf_rate': wf_rate, 'n_proc': n_proc, 'threads': threads,
                 'n_eloc_calls': sum(x[2] for x in res), 'n_psi_calls': sum(x[3] for x in res)}
@@ -124,12 +128,29 @@ def cpu_baseline(molname, spec_name, n_sub, dtype_name='f32', batch=256, budget_
     return {
         'value': 1.0 / per_walker_step, 'unit': 'walker*E_loc evals/s (VMC step incl. %d sub-steps)' % n_sub,
         'eloc_only_evals_per_s': best['eloc_rate'], 'psi_evals_per_s': best['wf_rate'],
-        'cores': best['n_proc'] * best['threads'], 'kind': 'port',
+        'cores': best['n_proc'] * best['threads'], 'host_logical_cores': cores, 'kind': 'port',
         'sample': f"oracle-CPU stand-in (not the reference JAX-CPU path): torch.func.vmap over {batch} walkers of the per-walker "
                   f"local energy (jacfwd(grad) Laplacian) and of psi, {dtype_name}, {best['n_proc']} process(es) x {best['threads']} "
                   f"threads, median of {best['n_eloc_calls']} E_loc + {best['n_psi_calls']} psi batched calls "
-                  f"(~{budget_s:.0f} s per layout, layouts tried: {layouts})",
+                  f"(~{budget_s:.0f} s per layout; layouts tried (processes, threads): {layouts})",
     }
+
+
+def cpu_baseline(molname, spec_name, n_sub, dtype_name='f32', timeout_s=240.0):
+    """Runs cpu_baseline_measure in a child process with a hard wall-clock limit, so that a slow host can never
+    keep the GPU numbers from being printed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-baseline-only', '--molecule', molname, '--ansatz', spec_name,
+           '--n-sub', str(n_sub), '--dtype', dtype_name]
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+        if p.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {'value': None, 'kind': 'port', 'error': (p.stderr or 'no output')[-400:]}
+    except subprocess.TimeoutExpired:
+        return {'value': None, 'kind': 'port', 'error': f'CPU baseline did not finish within {timeout_s:.0f} s'}
 
 
 def committed_traffic(kernel, workload):
@@ -175,8 +196,12 @@ def main():
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state time the timed blocks must cover')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
                     'launch / shard / reduce path without a GPU; the numbers mean nothing)')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: print the cpu_baseline JSON object and exit')
     args = ap.parse_args()
 
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_measure(args.molecule, args.ansatz, args.n_sub, args.dtype)))
+        return
     if args.gpus < 1:
         sys.exit('bench.py: --gpus must be >= 1')
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -220,6 +245,12 @@ def main():
     def sync():
         if device.type == 'cuda':
             torch.cuda.synchronize(device)
+
+    t_start = time.perf_counter()
+
+    def log(msg):
+        if rank == 0:
+            print(f'[bench {time.perf_counter() - t_start:7.1f} s] {msg}', file=sys.stderr, flush=True)
 
     dtype = torch.float32 if args.dtype == 'f32' else torch.float64
     mol = Molecule.from_name(args.molecule)
@@ -330,6 +361,7 @@ def main():
             dt = float(t.item())
         return dt
 
+    log('warm-up done; timing')
     blocks = [timed_block(args.warmup)]
     n_blocks = args.repeats if args.repeats > 0 else max(10, int(np.ceil(args.min_seconds / max(blocks[0], 1e-6))))
     n_blocks = min(n_blocks, 2000)
@@ -339,6 +371,7 @@ def main():
         n_blocks = int(t.item())
     for k in range(1, n_blocks):
         blocks.append(timed_block(args.warmup + k * args.steps))
+    log(f'{len(blocks)} timed blocks done')
     elapsed = float(np.median(blocks))
     ms_per_step = 1e3 * elapsed / args.steps
     value = B * world / (elapsed / args.steps)
@@ -408,6 +441,7 @@ def main():
         if args.ecp:
             out['data'] += ', synthetic ECP coefficients'
             out['config']['workload'] += ' + Gaussian-type ECP (12-point quadrature)'
+        log('GPU sections done; CPU baseline')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub, args.dtype)
         print(json.dumps(out))

@@ -147,6 +147,7 @@ struct Engine : dqmc_ctx {
   const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
+  std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
   dqmc::FDesc* d_descs = nullptr;
   int32_t* d_wave_begin = nullptr;
   dqmc::FusedBuf* d_fbufs2 = nullptr;
@@ -410,6 +411,15 @@ struct Engine : dqmc_ctx {
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
       fprintf(stderr, "[dqmc] fused plan: WT=%d lds=%zu B; %d fused ops, %d levels\n", fused2_WT, fused2_lds, fused_n_ops,
               fused_n_ops ? f_level[fused_n_ops - 1] + 1 : 0);
+      if (value >= 2)        // one line per descriptor of every wave list: kind, scheduled op, its op kind, row blocks, quads of k-steps
+        for (size_t w = 0; w < plan_lists.size(); ++w)
+          for (size_t k = 0; k < plan_lists[w].size(); ++k) {
+            const dqmc::FDesc& d = plan_lists[w][k];
+            int nq = 0;
+            for (int p = 0; p < d.n_pieces; ++p) nq += d.a_nq[p];
+            fprintf(stderr, "[dqmc] wave %zu desc %zu kind %d op %d opkind %d ma %d row0 %d col0 %d quads %d ldw %d\n", w, k, d.kind, d.op,
+                    d.kind == 2 ? 0 : ops[f_order[d.op]].kind, d.ma, d.row0, d.col0, nq, d.ldw);
+          }
       return DQMC_OK;
     }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
@@ -756,6 +766,7 @@ struct Engine : dqmc_ctx {
       }
       if (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) flush_level();
     }
+    plan_lists = lists;
     std::vector<dqmc::FDesc> flat;
     int32_t begin[4];
     for (int w = 0; w < n_waves; ++w) {
@@ -1074,16 +1085,26 @@ struct Engine : dqmc_ctx {
         HIP_TRY(hipMalloc((void**)&d_flag, sizeof(int32_t) * ((size_t)B + 1)));
         flag_cap = (size_t)B + 1;
       }
-      HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
-      flag_on = true;
-      int rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
-      flag_on = false;
-      if (rc) return rc;
+      int rc = DQMC_OK;
       int32_t n = 0;
-      HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      if (n <= 0) return DQMC_OK;
-      if (n > B) n = B;
+      if (refine >= 2) {           // the whole forward-Laplacian pass in float64 (float32 stays the sampling dtype)
+        std::vector<int32_t> iota((size_t)B + 1);
+        iota[0] = B;
+        for (int k = 0; k < B; ++k) iota[k + 1] = k;
+        HIP_TRY(hipMemcpyAsync(d_flag, iota.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        n = B;
+      } else {
+        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+        flag_on = true;
+        rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+        flag_on = false;
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (n <= 0) return DQMC_OK;
+        if (n > B) n = B;
+      }
       if (!twin) {
         auto* t = new Engine<double>();
         t->st = st; t->device = device;
@@ -1092,6 +1113,13 @@ struct Engine : dqmc_ctx {
         rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
                      h_itable.data(), h_itable.size());
         if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
+        if (rc == DQMC_E_UNSUPPORTED && refine == 1) {
+          // no float64 kernel set for this program (e.g. the scalar attention tiles of 42 electrons exceed the LDS):
+          // the float32 results stand and the refinement switches itself off
+          delete t;
+          refine = 0;
+          return DQMC_OK;
+        }
         if (rc) { delete t; return rc; }
         t->ws_budget = ws_budget;
         twin = t;

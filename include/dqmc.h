@@ -217,7 +217,8 @@ int dqmc_last_refined(dqmc_ctx* ctx);
  * per value-mode batch of the non-local ECP term; "ws_budget_mb": activation workspace per evaluation
  * (larger batches are split into walker chunks); "lane_compact" (1): 8-lane storage of the edge stream;
  * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never);
- * "refine" (1; float32 contexts): float64 re-evaluation of ill-conditioned walkers, "refine_thresh" (16): its trigger.
+ * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
+ * float64 while sampling stays float32, 0: off), "refine_thresh" (16): the trigger of mode 1.
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 

@@ -32,3 +32,5 @@ for w in range(4):
     row = st[w]
     n = int((row > 0).sum())
     print('wave', w, 'start', int(row[0] - t0), 'end', int(row[n - 1] - t0), 'deltas', [int(x) for x in np.diff(row[:n])])
+# time between consecutive barriers as seen by wave 0 (level durations) is in the deltas: descriptor k of the plan
+# printed on stderr ("[dqmc] wave w desc k ...") took deltas[k] cycles

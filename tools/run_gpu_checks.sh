@@ -8,8 +8,8 @@ rm -f gpurun_out/parity_report.json gpurun_out/other_configs.log
 nproc > gpurun_out/device.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
 timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
-./run_traffic.sh > gpurun_out/traffic.log 2>&1          # HBM counters first: bench.py reports them as roofline.traffic
-cp gpurun_out/pmc_hbm_traffic.json profiles/r01_pmc_hbm_traffic.json
+tools/run_traffic.sh > gpurun_out/traffic.log 2>&1          # HBM counters first: bench.py reports them as roofline.traffic
+cp gpurun_out/pmc_hbm_traffic.json profiles/r02_pmc_hbm_traffic.json
 timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
 for cfg in "--molecule N2 --ansatz ferminet --n-sub 10 --steps 3 --warmup 1" \
            "--molecule benzene --ansatz psiformer --walkers 256 --n-sub 10 --steps 2 --warmup 1" \
@@ -19,7 +19,7 @@ for cfg in "--molecule N2 --ansatz ferminet --n-sub 10 --steps 3 --warmup 1" \
 done
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$ROOT/gpurun_out/prof"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o r01 -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$ROOT/gpurun_out/prof.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o r02 -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$ROOT/gpurun_out/prof.log" 2>&1
 echo "prof rc=$?" >> "$ROOT/gpurun_out/prof.log"
 cd "$ROOT"
 tail -3 gpurun_out/smoke.log; tail -5 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/bench.log | cut -c1-600; wc -l gpurun_out/other_configs.log; tail -5 gpurun_out/traffic.log
