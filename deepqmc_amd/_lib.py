@@ -27,6 +27,11 @@ SIGNATURES = [
     ('dqmc_psi_grad', c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     ('dqmc_mcmc_steps', c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                 c_int, c_double, c_uint64, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
+    ('dqmc_langevin_update', c_int, [c_void_p, c_void_p, c_void_p, POINTER(c_double), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    ('dqmc_langevin_steps', c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, POINTER(c_double),
+                                    c_int, c_int, c_int, c_double, c_uint64, c_void_p, c_void_p, c_void_p, POINTER(c_double)]),
+    ('dqmc_exchange_step', c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, POINTER(c_double)]),
     ('dqmc_set_ecp', c_int, [c_void_p, c_int, POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     ('dqmc_ecp_rotation', c_int, [c_void_p, c_uint64, c_void_p]),
     ('dqmc_energy_stats', c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_double)]),

@@ -51,6 +51,13 @@ struct dqmc_ctx {
   virtual int mcmc(void* r, void* logpsi, int32_t* sign, int32_t* age, void* tau, const void* R, int B, int n_sub,
                    int max_age, double target, uint64_t seed, const void* noise, const void* unif, uint8_t* accept_out,
                    double* stats7) = 0;
+  virtual int langevin_update(const void* r, const void* R, const double* mol_charges, int B, const void* tau, void* logpsi,
+                              int32_t* sign, void* force) = 0;
+  virtual int langevin(void* r, void* logpsi, int32_t* sign, int32_t* age, void* force, void* tau, const void* R,
+                       const double* mol_charges, int B, int n_sub, int max_age, double target, uint64_t seed, const void* noise,
+                       const void* unif, uint8_t* accept_out, double* stats7) = 0;
+  virtual int exchange(void* r, void* logpsi, int32_t* sign, int32_t* age, const void* tau, const void* R, int B,
+                       const int32_t* up_idx, const int32_t* down_idx, const void* unif, uint8_t* accept_out, double* stats7) = 0;
   virtual int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) = 0;
   virtual int ecp_rotation(uint64_t seed, const void* phi) = 0;
   virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
@@ -177,6 +184,7 @@ struct Engine : dqmc_ctx {
 
   ~Engine() override {
     delete twin;
+    if (d_molz) (void)hipFree(d_molz);
     if (d_flag) (void)hipFree(d_flag);
     if (d_ref) (void)hipFree(d_ref);
     if (d_descs) (void)hipFree(d_descs);
@@ -1327,6 +1335,116 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
+  // ---- Langevin (MALA) and exchange steps (electron_samplers.py:176-330, sampling_utils.py:72-101) ----
+  double* d_molz = nullptr;     // device copy of the full nuclear charges the drift cleaning uses
+  int upload_molz(const double* z) {
+    if (!d_molz) HIP_TRY(hipMalloc((void**)&d_molz, sizeof(double) * sys.n_nuc));
+    HIP_TRY(hipMemcpyAsync(d_molz, z, sizeof(double) * sys.n_nuc, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));     // `z` is pageable host memory of the caller
+    return DQMC_OK;
+  }
+  int ensure_mc(size_t tot) {
+    if (tot > mc_bytes) {
+      if (d_mc) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_mc)); d_mc = nullptr; }
+      HIP_TRY(hipMalloc((void**)&d_mc, tot));
+      mc_bytes = tot;
+    }
+    return DQMC_OK;
+  }
+  int langevin_update(const void* r_, const void* R_, const double* molz, int B, const void* tau_, void* logpsi, int32_t* sign,
+                      void* force_) override {
+    if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    int rc = upload_molz(molz);
+    if (rc) return rc;
+    const size_t n_r = (size_t)B * N * 3;
+    rc = ensure_mc(sizeof(real) * n_r + 256);
+    if (rc) return rc;
+    real* g = (real*)d_mc;
+    rc = lap_refined((const real*)r_, (const real*)R_, B, nullptr, nullptr, g, (real*)logpsi, sign);
+    if (rc) return rc;
+    t_begin("mcmc", 0);
+    dqmc::launch_clean_force<real>(st, g, (const real*)r_, (const real*)R_, d_molz, (const real*)tau_, B, N, sys.n_nuc, (real*)force_);
+    t_end();
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+  int langevin(void* r_, void* logpsi_, int32_t* sign, int32_t* age, void* force_, void* tau_, const void* R_, const double* molz,
+               int B, int n_sub, int max_age, double target, uint64_t seed, const void* noise_, const void* unif_,
+               uint8_t* accept_out, double* stats7) override {
+    if (B < 1 || n_sub < 0) return fail(DQMC_E_ARG, "bad B / n_sub");
+    if ((noise_ == nullptr) != (unif_ == nullptr)) return fail(DQMC_E_ARG, "noise and unif must both be given or both NULL");
+    int rc = upload_molz(molz);
+    if (rc) return rc;
+    real* r = (real*)r_; real* logpsi = (real*)logpsi_; real* tau = (real*)tau_; real* force = (real*)force_;
+    const real* R = (const real*)R_;
+    const size_t n_r = (size_t)B * N * 3, ns = (size_t)(n_sub > 0 ? n_sub : 1);
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_rp = 0, o_g = o_rp + al(sizeof(real) * n_r), o_fp = o_g + al(sizeof(real) * n_r), o_lp = o_fp + al(sizeof(real) * n_r),
+                 o_sp = o_lp + al(sizeof(real) * B), o_nz = o_sp + al(sizeof(int32_t) * B), o_un = o_nz + al(sizeof(real) * n_r * ns),
+                 tot = o_un + al(sizeof(real) * B * ns);
+    rc = ensure_mc(tot);
+    if (rc) return rc;
+    real* r_prop = (real*)(d_mc + o_rp); real* g_prop = (real*)(d_mc + o_g); real* f_prop = (real*)(d_mc + o_fp);
+    real* lp_prop = (real*)(d_mc + o_lp); int32_t* s_prop = (int32_t*)(d_mc + o_sp);
+    real* nz = (real*)(d_mc + o_nz); real* un = (real*)(d_mc + o_un);
+    if (!noise_ && n_sub > 0) {
+      t_begin("mcmc", 0);
+      dqmc::launch_rng<real>(st, nz, (long)(n_r * n_sub), un, (long)B * n_sub, seed, (uint64_t)1);
+      t_end();
+    }
+    for (int s = 0; s < n_sub; ++s) {
+      const real* noise_s = noise_ ? (const real*)noise_ + (size_t)s * n_r : nz + (size_t)s * n_r;
+      const real* unif_s = unif_ ? (const real*)unif_ + (size_t)s * B : un + (size_t)s * B;
+      t_begin("mcmc", 0);
+      dqmc::launch_langevin_propose<real>(st, r, force, noise_s, tau, r_prop, (long)n_r);
+      t_end();
+      rc = lap_refined(r_prop, R, B, nullptr, nullptr, g_prop, lp_prop, s_prop);
+      if (rc) return rc;
+      t_begin("mcmc", 0);
+      dqmc::launch_clean_force<real>(st, g_prop, r_prop, R, d_molz, tau, B, N, sys.n_nuc, f_prop);
+      dqmc::launch_langevin_accept<real>(st, r, logpsi, sign, age, force, r_prop, lp_prop, s_prop, f_prop, unif_s, tau, max_age, B, N,
+                                         d_nacc, accept_out ? accept_out + (size_t)s * B : nullptr);
+      dqmc::launch_tau_update<real>(st, tau, d_nacc, B, target, d_acc);
+      t_end();
+    }
+    if (stats7) {
+      dqmc::launch_sampler_stats<real>(st, r, logpsi, age, tau, d_acc, B, N, sys.norm_eps, d_acc + 1);
+      HIP_TRY(hipMemcpyAsync(stats7, d_acc + 1, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+  int exchange(void* r_, void* logpsi_, int32_t* sign, int32_t* age, const void* tau_, const void* R_, int B, const int32_t* up_idx,
+               const int32_t* down_idx, const void* unif_, uint8_t* accept_out, double* stats7) override {
+    if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    if (sys.n_up < 1 || sys.n_down < 1) return fail(DQMC_E_ARG, "an exchange step needs electrons of both spins");
+    real* r = (real*)r_; real* logpsi = (real*)logpsi_;
+    const size_t n_r = (size_t)B * N * 3;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_rp = 0, o_lp = o_rp + al(sizeof(real) * n_r), o_sp = o_lp + al(sizeof(real) * B), tot = o_sp + al(sizeof(int32_t) * B);
+    int rc = ensure_mc(tot);
+    if (rc) return rc;
+    real* r_prop = (real*)(d_mc + o_rp); real* lp_prop = (real*)(d_mc + o_lp); int32_t* s_prop = (int32_t*)(d_mc + o_sp);
+    t_begin("mcmc", 0);
+    dqmc::launch_exchange_propose<real>(st, r, up_idx, down_idx, sys.n_up, B, N, r_prop);
+    t_end();
+    rc = run(r_prop, (const real*)R_, B, false, lp_prop, s_prop, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    t_begin("mcmc", 0);
+    // `_accept` without max_age / target_acceptance (electron_samplers.py:312-313): no age override, tau unchanged
+    dqmc::launch_accept<real>(st, r, logpsi, sign, age, r_prop, lp_prop, s_prop, (const real*)unif_, -1, B, N, d_nacc, accept_out);
+    dqmc::launch_read_accept(st, d_nacc, B, d_acc);
+    t_end();
+    if (stats7) {
+      dqmc::launch_sampler_stats<real>(st, r, logpsi, age, (const real*)tau_, d_acc, B, N, sys.norm_eps, d_acc + 1);
+      HIP_TRY(hipMemcpyAsync(stats7, d_acc + 1, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+
   int energy_stats(const void* e, const void* w, int B, double* out7) override {
     if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
     dqmc::launch_energy_stats<real>(st, (const real*)e, (const real*)w, B, d_acc + 8);
@@ -1459,6 +1577,26 @@ int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t
   HIP_TRY(hipSetDevice(ctx->device));
   return ctx->mcmc(r, logpsi, sign, age, tau, R, B, n_sub, max_age, target_acceptance, seed, noise, unif, accept_out,
                    stats7_host);
+}
+int dqmc_langevin_update(dqmc_ctx* ctx, const void* r, const void* R, const double* mol_charges_host, int B, const void* tau,
+                         void* logpsi, int32_t* sign, void* force) {
+  if (!ctx || !r || !R || !mol_charges_host || !tau || !force) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->langevin_update(r, R, mol_charges_host, B, tau, logpsi, sign, force);
+}
+int dqmc_langevin_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, void* force, void* tau, const void* R,
+                        const double* mol_charges_host, int B, int n_sub, int max_age, double target_acceptance, uint64_t seed,
+                        const void* noise, const void* unif, uint8_t* accept_out, double* stats7_host) {
+  if (!ctx || !r || !logpsi || !sign || !age || !force || !tau || !R || !mol_charges_host) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->langevin(r, logpsi, sign, age, force, tau, R, mol_charges_host, B, n_sub, max_age, target_acceptance, seed, noise, unif,
+                       accept_out, stats7_host);
+}
+int dqmc_exchange_step(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, const void* tau, const void* R, int B,
+                       const int32_t* up_idx, const int32_t* down_idx, const void* unif, uint8_t* accept_out, double* stats7_host) {
+  if (!ctx || !r || !logpsi || !sign || !age || !tau || !R || !up_idx || !down_idx || !unif) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->exchange(r, logpsi, sign, age, tau, R, B, up_idx, down_idx, unif, accept_out, stats7_host);
 }
 int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l, int n_terms_nl, const double* nl_host) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");

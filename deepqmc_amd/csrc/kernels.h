@@ -233,6 +233,19 @@ void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, con
                           const double* acc, int B, int N, double eps, double* stats7);
 template <typename real>
 void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B, double* out7);
+template <typename real>
+void launch_clean_force(hipStream_t st, const real* grad, const real* r, const real* R, const double* Z, const real* tau, int B,
+                        int N, int n_nuc, real* force);
+template <typename real>
+void launch_langevin_propose(hipStream_t st, const real* r, const real* force, const real* noise, const real* tau, real* r_prop, long n);
+template <typename real>
+void launch_langevin_accept(hipStream_t st, real* r, real* logpsi, int32_t* sign, int32_t* age, real* force, const real* r_prop,
+                            const real* lp_prop, const int32_t* sign_prop, const real* force_prop, const real* unif, const real* tau,
+                            int max_age, int B, int N, int32_t* n_accept, uint8_t* accept_out);
+template <typename real>
+void launch_exchange_propose(hipStream_t st, const real* r, const int32_t* up_idx, const int32_t* down_idx, int n_up, int B, int N,
+                             real* r_prop);
+void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_out);
 void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, int n, int n3, int nR3,
                           double* r64, double* R64);
 void launch_refine_scatter(hipStream_t st, const int32_t* idx, int n, int n3, const double* e64, const double* st64,

@@ -220,6 +220,132 @@ void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_energy_stats<real>), dim3(1), dim3(256), 0, st, e_loc, w, B, out7);
 }
 
+// ---- Metropolis-adjusted Langevin sampler and opposite-spin exchange steps --------------------------------
+// Drift cleaning (reference sampling/sampling_utils.py:72-101): one thread per (walker, electron).  z = r_i - R of the
+// nearest nucleus; crossover parameter a = (1 + f^.z^)/2 + Z^2 z^2 / (10 (4 + Z^2 z^2)) with the FULL nuclear charge
+// Z of that nucleus (mol.charges, not the valence charge); force scaled by 2 / (sqrt(1 + 2 a |f|^2 tau) + 1) and
+// then capped so that tau |f| <= |z| (a step cannot overshoot the nearest nucleus).  eps = finfo(real).eps.
+template <typename real>
+__global__ void __launch_bounds__(256) k_clean_force(const real* __restrict__ grad, const real* __restrict__ r,
+                                                     const real* __restrict__ R, const double* __restrict__ Z,
+                                                     const real* __restrict__ tau_p, int B, int N, int n_nuc,
+                                                     real* __restrict__ force) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * N) return;
+  const double eps = sizeof(real) == 4 ? 1.1920928955078125e-07 : 2.220446049250313e-16;
+  const double tau = (double)tau_p[0];
+  const real* ri = r + idx * 3;
+  double f[3] = {(double)grad[idx * 3], (double)grad[idx * 3 + 1], (double)grad[idx * 3 + 2]};
+  double z[3] = {0, 0, 0}, z2 = INFINITY, zc = 0;
+  for (int n = 0; n < n_nuc; ++n) {                    // argmin keeps the first of equal distances (jnp.argmin)
+    double d[3], d2 = 0;
+    for (int c = 0; c < 3; ++c) { d[c] = (double)ri[c] - (double)R[n * 3 + c]; d2 += d[c] * d[c]; }
+    if (d2 < z2) { z2 = d2; z[0] = d[0]; z[1] = d[1]; z[2] = d[2]; zc = Z[n]; }
+  }
+  const double zn = sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  const double f2 = f[0] * f[0] + f[1] * f[1] + f[2] * f[2];
+  const double fn = fmax(sqrt(f2), eps);
+  const double fz = (f[0] * z[0] + f[1] * z[1] + f[2] * z[2]) / (fn * zn);
+  const double Z2z2 = zc * zc * z2;
+  const double a = (1.0 + fz) / 2.0 + Z2z2 / (10.0 * (4.0 + Z2z2));
+  const double factor = 2.0 / (sqrt(1.0 + 2.0 * a * f2 * tau) + 1.0);
+  for (int c = 0; c < 3; ++c) f[c] *= factor;
+  const double fn2 = fmax(sqrt(f[0] * f[0] + f[1] * f[1] + f[2] * f[2]), eps);
+  const double cap = fmin(1.0, sqrt(z2) / (tau * fn2));
+  for (int c = 0; c < 3; ++c) force[idx * 3 + c] = (real)(f[c] * cap);
+}
+// r' = r + tau F + sqrt(tau) xi   (electron_samplers.py:214-221)
+template <typename real>
+__global__ void __launch_bounds__(256) k_langevin_propose(const real* __restrict__ r, const real* __restrict__ force,
+                                                          const real* __restrict__ noise, const real* __restrict__ tau,
+                                                          real* __restrict__ r_prop, long n) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n) return;
+  const real t = tau[0];
+  const real st = sizeof(real) == 4 ? (real)sqrtf((float)t) : (real)sqrt((double)t);
+  r_prop[idx] = r[idx] + t * force[idx] + st * noise[idx];
+}
+// log of the Green's-function ratio + 2 (log|psi'| - log|psi|) > log u  [| age >= max_age]; select the state
+// including the drift (electron_samplers.py:223-232 + :106-138).  One thread per walker.
+template <typename real>
+__global__ void __launch_bounds__(256) k_langevin_accept(real* __restrict__ r, real* __restrict__ logpsi,
+                                                         int32_t* __restrict__ sign, int32_t* __restrict__ age,
+                                                         real* __restrict__ force, const real* __restrict__ r_prop,
+                                                         const real* __restrict__ lp_prop, const int32_t* __restrict__ sign_prop,
+                                                         const real* __restrict__ force_prop, const real* __restrict__ unif,
+                                                         const real* __restrict__ tau_p, int max_age, int B, int N,
+                                                         int32_t* __restrict__ n_accept, uint8_t* __restrict__ accept_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const real tau = tau_p[0];
+  const long o = (long)b * 3 * N;
+  real log_G = 0;
+  for (int k = 0; k < 3 * N; ++k) {
+    const real f0 = force[o + k], f1 = force_prop[o + k];
+    log_G += (f0 + f1) * ((r[o + k] - r_prop[o + k]) + tau / 2 * (f0 - f1));
+  }
+  const real log_prob = log_G + 2 * (lp_prop[b] - logpsi[b]);
+  const real lu = sizeof(real) == 4 ? (real)logf((float)unif[b]) : (real)log((double)unif[b]);
+  bool acc = log_prob > lu;
+  if (max_age >= 0) acc = acc || (age[b] >= max_age);
+  if (acc) {
+    for (int k = 0; k < 3 * N; ++k) { r[o + k] = r_prop[o + k]; force[o + k] = force_prop[o + k]; }
+    logpsi[b] = lp_prop[b];
+    sign[b] = sign_prop[b];
+    age[b] = 0;
+    atomicAdd(n_accept, 1);
+  } else {
+    age[b] = age[b] + 1;
+  }
+  if (accept_out) accept_out[b] = acc ? 1 : 0;
+}
+// r' = r with the positions of spin-up electron up_idx[b] and spin-down electron n_up + down_idx[b] swapped
+// (electron_samplers.py:277-288)
+template <typename real>
+__global__ void __launch_bounds__(256) k_exchange_propose(const real* __restrict__ r, const int32_t* __restrict__ up_idx,
+                                                          const int32_t* __restrict__ down_idx, int n_up, int B, int N,
+                                                          real* __restrict__ r_prop) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * N) return;
+  const int b = (int)(idx / N), i = (int)(idx - (long)b * N);
+  const int u = up_idx[b], d = n_up + down_idx[b];
+  const int src = i == u ? d : (i == d ? u : i);
+  for (int c = 0; c < 3; ++c) r_prop[idx * 3 + c] = r[((long)b * N + src) * 3 + c];
+}
+// acceptance of a step whose count sits in n_accept -> acc_out, counter back to zero (no step-size change)
+__global__ void k_read_accept(int32_t* __restrict__ n_accept, int B, double* __restrict__ acc_out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { acc_out[0] = (double)n_accept[0] / (double)B; n_accept[0] = 0; }
+}
+template <typename real>
+void launch_clean_force(hipStream_t st, const real* grad, const real* r, const real* R, const double* Z, const real* tau, int B,
+                        int N, int n_nuc, real* force) {
+  const long n = (long)B * N;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_clean_force<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, grad, r, R, Z, tau,
+                     B, N, n_nuc, force);
+}
+template <typename real>
+void launch_langevin_propose(hipStream_t st, const real* r, const real* force, const real* noise, const real* tau, real* r_prop, long n) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_langevin_propose<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, force, noise,
+                     tau, r_prop, n);
+}
+template <typename real>
+void launch_langevin_accept(hipStream_t st, real* r, real* logpsi, int32_t* sign, int32_t* age, real* force, const real* r_prop,
+                            const real* lp_prop, const int32_t* sign_prop, const real* force_prop, const real* unif, const real* tau,
+                            int max_age, int B, int N, int32_t* n_accept, uint8_t* accept_out) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_langevin_accept<real>), dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, r, logpsi, sign,
+                     age, force, r_prop, lp_prop, sign_prop, force_prop, unif, tau, max_age, B, N, n_accept, accept_out);
+}
+template <typename real>
+void launch_exchange_propose(hipStream_t st, const real* r, const int32_t* up_idx, const int32_t* down_idx, int n_up, int B, int N,
+                             real* r_prop) {
+  const long n = (long)B * N;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_exchange_propose<real>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, r, up_idx,
+                     down_idx, n_up, B, N, r_prop);
+}
+void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_out) {
+  hipLaunchKernelGGL(k_read_accept, dim3(1), dim3(64), 0, st, n_accept, B, acc_out);
+}
+
 // ---- float64 refinement of flagged walkers (engine.hip: Engine<float>::lap_refined) ----
 // gather: positions of the flagged walkers (and the geometry) widened to double
 __global__ void __launch_bounds__(256) k_refine_gather(const float* __restrict__ r, const float* __restrict__ R,
@@ -269,7 +395,14 @@ void launch_refine_scatter(hipStream_t st, const int32_t* idx, int n, int n3, co
   template void launch_tau_finalize<real>(hipStream_t, real*, const real*, int32_t*, int, int, double, double*);    \
   template void launch_sampler_stats<real>(hipStream_t, const real*, const real*, const int32_t*, const real*,      \
                                            const double*, int, int, double, double*);                               \
-  template void launch_energy_stats<real>(hipStream_t, const real*, const real*, int, double*);
+  template void launch_energy_stats<real>(hipStream_t, const real*, const real*, int, double*);                     \
+  template void launch_clean_force<real>(hipStream_t, const real*, const real*, const real*, const double*, const real*, int, int, \
+                                         int, real*);                                                               \
+  template void launch_langevin_propose<real>(hipStream_t, const real*, const real*, const real*, const real*, real*, long); \
+  template void launch_langevin_accept<real>(hipStream_t, real*, real*, int32_t*, int32_t*, real*, const real*, const real*, \
+                                             const int32_t*, const real*, const real*, const real*, int, int, int, int32_t*, \
+                                             uint8_t*);                                                             \
+  template void launch_exchange_propose<real>(hipStream_t, const real*, const int32_t*, const int32_t*, int, int, int, real*);
 DQMC_INST(float)
 DQMC_INST(double)
 #undef DQMC_INST

@@ -198,6 +198,70 @@ class Engine:
         out = dict(zip(SAMPLER_STAT_KEYS, list(stats))) if want_stats else {}
         return (out, acc) if return_accept else out
 
+    def _check_state(self, state, keys):
+        B = state['r'].shape[0]
+        want = {'r': self.dtype, 'log': self.dtype, 'tau': self.dtype, 'force': self.dtype, 'sign': torch.int32, 'age': torch.int32}
+        for k in keys:     # raw device pointers cross the C ABI: the layout must be exactly the documented one
+            t = state[k]
+            if t.dtype != want[k] or not t.is_contiguous() or t.device.type != self.device.type:
+                raise DqmcError(f"sampler state '{k}' must be a contiguous {want[k]} tensor on {self.device}")
+        if state['r'].shape != (B, self.N, 3) or any(state[k].shape[0] != B for k in keys if k not in ('r', 'tau')):
+            raise DqmcError('sampler state shapes do not match [B, N, 3] / [B]')
+        return B
+
+    def _molz(self, charges):
+        z = np.ascontiguousarray(charges, np.float64)
+        assert z.shape == (self.hamil.n_nuc,)
+        return z, z.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+    def langevin_update(self, r, tau, mol_charges, R=None):
+        """LangevinSampler._update (electron_samplers.py:193-208): (sign, log|psi|, cleaned drift [B,N,3])."""
+        r = self._t(r)
+        B = r.shape[0]
+        tau = self._t(tau).reshape(1)
+        z, zp = self._molz(mol_charges)
+        logpsi = torch.empty(B, dtype=self.dtype, device=self.device)
+        sign = torch.empty(B, dtype=torch.int32, device=self.device)
+        force = torch.empty(B, self.N, 3, dtype=self.dtype, device=self.device)
+        self._check(self.lib.dqmc_langevin_update(self._ctx, r.data_ptr(), self._R(R).data_ptr(), zp, B, tau.data_ptr(),
+                                                  logpsi.data_ptr(), sign.data_ptr(), force.data_ptr()))
+        return sign, logpsi, force
+
+    def langevin_steps(self, state, n_sub, mol_charges, *, max_age=None, target_acceptance=0.57, seed=0, noise=None, unif=None,
+                       R=None, want_stats=True, return_accept=False):
+        """In-place Langevin sub-steps on state {'r','log','sign','age','tau','force'} (dqmc_langevin_steps)."""
+        B = self._check_state(state, ('r', 'log', 'sign', 'age', 'tau', 'force'))
+        acc = torch.empty(n_sub, B, dtype=torch.uint8, device=self.device) if return_accept else None
+        stats = (ctypes.c_double * 7)()
+        if noise is not None:
+            noise, unif = self._t(noise), self._t(unif)
+            assert noise.shape == (n_sub, B, self.N, 3) and unif.shape == (n_sub, B)
+        z, zp = self._molz(mol_charges)
+        self._check(self.lib.dqmc_langevin_steps(
+            self._ctx, state['r'].data_ptr(), state['log'].data_ptr(), state['sign'].data_ptr(), state['age'].data_ptr(),
+            state['force'].data_ptr(), state['tau'].data_ptr(), self._R(R).data_ptr(), zp, B, n_sub,
+            -1 if max_age is None else int(max_age), -1.0 if target_acceptance is None else float(target_acceptance), int(seed),
+            noise.data_ptr() if noise is not None else None, unif.data_ptr() if unif is not None else None,
+            acc.data_ptr() if return_accept else None, stats if want_stats else None))
+        out = dict(zip(SAMPLER_STAT_KEYS, list(stats))) if want_stats else {}
+        return (out, acc) if return_accept else out
+
+    def exchange_step(self, state, up_idx, down_idx, unif, R=None, return_accept=False):
+        """One opposite-spin exchange step, in place on state {'r','log','sign','age','tau'} (dqmc_exchange_step)."""
+        B = self._check_state(state, ('r', 'log', 'sign', 'age', 'tau'))
+        up = torch.as_tensor(up_idx, device=self.device).to(torch.int32).contiguous()
+        dn = torch.as_tensor(down_idx, device=self.device).to(torch.int32).contiguous()
+        u = self._t(unif)
+        assert up.shape == dn.shape == u.shape == (B,)
+        acc = torch.empty(B, dtype=torch.uint8, device=self.device) if return_accept else None
+        stats = (ctypes.c_double * 7)()
+        self._check(self.lib.dqmc_exchange_step(self._ctx, state['r'].data_ptr(), state['log'].data_ptr(), state['sign'].data_ptr(),
+                                                state['age'].data_ptr(), state['tau'].data_ptr(), self._R(R).data_ptr(), B,
+                                                up.data_ptr(), dn.data_ptr(), u.data_ptr(), acc.data_ptr() if return_accept else None,
+                                                stats))
+        out = dict(zip(SAMPLER_STAT_KEYS, list(stats)))
+        return (out, acc) if return_accept else out
+
     def energy_record(self, e_loc, w=None):
         rec = (ctypes.c_double * 7)()
         self._check(self.lib.dqmc_energy_stats(self._ctx, e_loc.data_ptr(), w.data_ptr() if w is not None else None,

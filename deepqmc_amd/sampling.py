@@ -99,68 +99,24 @@ class MultiElectronicStateSampler:
         return [self.sampler.update(state[s], params[s], R) for s in range(self.n_state)]
 
 
-def clean_force(force, r, R, charges, tau):
-    """sampling/sampling_utils.py:72-101 on device tensors (host-side torch glue; the wave-function
-    work is `Engine.psi_and_grad`)."""
-    z = r[:, :, None, :] - R[None, None, :, :]
-    z2 = (z ** 2).sum(-1)
-    idx = z2.argmin(-1)
-    zn = torch.gather(z, 2, idx[..., None, None].expand(-1, -1, 1, 3)).squeeze(2)
-    z2n = torch.gather(z2, 2, idx[..., None]).squeeze(2)
-    eps = torch.finfo(force.dtype).eps
-    z_unit = zn / torch.linalg.norm(zn, dim=-1, keepdim=True)
-    f_unit = force / torch.clamp(torch.linalg.norm(force, dim=-1, keepdim=True), min=eps)
-    Z2z2 = charges[idx] ** 2 * z2n
-    a = (1 + (f_unit * z_unit).sum(-1)) / 2 + Z2z2 / (10 * (4 + Z2z2))
-    av2tau = a * (force ** 2).sum(-1) * tau
-    factor = 2 / (torch.sqrt(1 + 2 * av2tau) + 1)
-    force = factor[..., None] * force
-    norm_factor = torch.clamp(torch.sqrt(z2n) / (tau * torch.clamp(torch.linalg.norm(force, dim=-1), min=eps)), max=1.0)
-    return force * norm_factor[..., None]
-
-
 class LangevinSampler(MetropolisSampler):
-    """Metropolis-adjusted Langevin sampler (sampling/electron_samplers.py:176-232): drift =
-    cleaned grad log|psi| from one forward-Laplacian pass per proposal, Green's-function ratio in
-    the acceptance.  Propose/accept bookkeeping is torch glue on the device; psi and its gradient
-    come from the HIP engine."""
-
-    def _psi_force(self, eng, r, tau, R=None):
-        sign, log, g = eng.psi_and_grad(r, R)
-        Rt = eng.R if R is None else eng._R(R)
-        Z = torch.as_tensor(self.hamil.mol.charges, dtype=eng.dtype, device=eng.device)
-        return sign, log, clean_force(g, r, Rt, Z, tau)
+    """Metropolis-adjusted Langevin sampler (sampling/electron_samplers.py:176-232): drift = cleaned grad log|psi|
+    (sampling_utils.py:72-101) from one forward-Laplacian pass per proposal, Green's-function ratio in the acceptance.
+    Everything -- drift cleaning, proposal, acceptance, state selection, step-size adaptation -- runs in the HIP
+    library (`dqmc_langevin_update` / `dqmc_langevin_steps`); the state carries the drift as 'force'."""
 
     def update(self, state, params, R=None):
         eng = self.wf.engine(params)
-        sign, log, force = self._psi_force(eng, state['r'], state['tau'], R)
+        sign, log, force = eng.langevin_update(state['r'], state['tau'], self.hamil.mol.charges, R)
         return {**state, 'psi': Psi(sign, log), 'force': force}
 
     def sample(self, rng, state, params, R=None, noise=None, unif=None):
         eng = self.wf.engine(params)
-        r, tau = state['r'], state['tau']
-        gen = torch.Generator(device=eng.device)
-        gen.manual_seed(int(rng))
-        stats = {}
-        for k in range(self.length):
-            xi = torch.randn(r.shape, dtype=eng.dtype, device=eng.device, generator=gen) if noise is None else eng._t(noise[k])
-            u = torch.rand(r.shape[0], dtype=eng.dtype, device=eng.device, generator=gen) if unif is None else eng._t(unif[k])
-            r_prop = r + tau * state['force'] + torch.sqrt(tau) * xi
-            sign_p, log_p, force_p = self._psi_force(eng, r_prop, tau, R)
-            log_G = ((state['force'] + force_p) * ((r - r_prop) + tau / 2 * (state['force'] - force_p))).sum(dim=(1, 2))
-            log_prob = log_G + 2 * (log_p - state['psi'].log)
-            acc = log_prob > torch.log(u)
-            if self.max_age is not None:
-                acc = acc | (state['age'] >= self.max_age)
-            acceptance = acc.to(eng.dtype).mean()
-            if self.target_acceptance is not None:
-                tau = tau / (self.target_acceptance / torch.clamp(acceptance, min=0.05))
-            sel = lambda a, b: torch.where(acc.reshape((-1,) + (1,) * (a.dim() - 1)), a, b)
-            state = {'r': sel(r_prop, r), 'psi': Psi(sel(sign_p, state['psi'].sign), sel(log_p, state['psi'].log)),
-                     'force': sel(force_p, state['force']),
-                     'age': torch.where(acc, torch.zeros_like(state['age']), state['age'] + 1), 'tau': tau}
-            r = state['r']
-            stats = {'sampling/acceptance': float(acceptance), 'sampling/tau': float(tau)}
+        st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
+              'age': state['age'].clone(), 'tau': state['tau'].clone(), 'force': state['force'].clone()}
+        stats = eng.langevin_steps(st, self.length, self.hamil.mol.charges, max_age=self.max_age,
+                                   target_acceptance=self.target_acceptance, seed=int(rng), noise=noise, unif=unif, R=R)
+        state = {'r': st['r'], 'psi': Psi(st['sign'], st['log']), 'age': st['age'], 'tau': st['tau'], 'force': st['force']}
         return state, self.phys_conf(eng.R if R is None else R, state['r']), stats
 
 
@@ -169,9 +125,9 @@ class OppositeSpinExchangeSampler:
     `exchange_step_probability` a step proposes swapping the positions of one random spin-up and one random
     spin-down electron per walker (uniform choice = the reference's default zero logits) and accepts with
     |psi'|^2 / |psi|^2 -- no age override and no step-size adaptation on such steps (:312-321) -- otherwise it
-    is an ordinary step of the wrapped sampler.  The swap bookkeeping is torch glue on the device; psi comes from
-    the HIP engine.  `choices` = (is_exchange: bool, up_idx[B], down_idx[B], unif[B]) overrides the draws
-    (parity tests)."""
+    is an ordinary step of the wrapped sampler.  Swap, psi evaluation, acceptance and state update run in the HIP
+    library (`dqmc_exchange_step`); only the random choices are drawn on the host.  `choices` = (is_exchange: bool,
+    up_idx[B], down_idx[B], unif[B]) overrides the draws (parity tests)."""
 
     def __init__(self, sampler: MetropolisSampler, *, exchange_step_probability: float):
         self.sampler = sampler
@@ -198,23 +154,10 @@ class OppositeSpinExchangeSampler:
             is_ex, up_idx, down_idx, unif = choices
         if not is_ex:
             return self.sampler.sample(rng, state, params, R, **kw)
-        dev = eng.device
-        up_idx, down_idx = torch.as_tensor(up_idx, device=dev).long(), torch.as_tensor(down_idx, device=dev).long() + n_up
-        r = state['r']
-        bi = torch.arange(B, device=dev)
-        r_prop = r.clone()
-        r_prop[bi, up_idx] = r[bi, down_idx]
-        r_prop[bi, down_idx] = r[bi, up_idx]
-        sign_p, log_p = eng.wf_eval(r_prop, R)
-        log_prob = 2 * (log_p - state['psi'].log)                                          # :290-293
-        acc = log_prob > torch.log(torch.as_tensor(unif, dtype=eng.dtype, device=dev))      # _accept without max_age/target
-        new = {**state,
-               'r': torch.where(acc[:, None, None], r_prop, r).contiguous(),
-               'psi': Psi(torch.where(acc, sign_p, state['psi'].sign), torch.where(acc, log_p, state['psi'].log)),
-               'age': torch.where(acc, torch.zeros_like(state['age']), state['age'] + 1)}
-        acceptance = float(acc.to(torch.float64).mean())
-        stats = {'sampling/acceptance': acceptance, 'sampling/tau': float(state['tau'][0]),
-                 'sampling/age/mean': float(new['age'].to(torch.float64).mean()), 'sampling/age/max': float(new['age'].max()),
-                 'sampling/log_psi/mean': float(new['psi'].log.mean()),
-                 'sampling/log_psi/std': float(new['psi'].log.std(unbiased=False))}
+        st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
+              'age': state['age'].clone(), 'tau': state['tau']}
+        stats = eng.exchange_step(st, up_idx, down_idx, unif, R=R)
+        new = {**state, 'r': st['r'], 'psi': Psi(st['sign'], st['log']), 'age': st['age']}
+        if 'force' in state:          # a Langevin state: the drift belongs to the positions
+            new = self.sampler.update(new, params, R)
         return new, self.sampler.phys_conf(eng.R if R is None else R, new['r']), stats

@@ -13,6 +13,8 @@
  *                          hamil.py:156-184, vmapped over walkers at loss/energy.py:50-57
  *   dqmc_mcmc_steps     <- DecorrSampler.sample / MetropolisSampler.sample
  *                          sampling/electron_samplers.py:140-163,347-357
+ *   dqmc_langevin_*     <- LangevinSampler._update / .sample, sampling/electron_samplers.py:176-232
+ *   dqmc_exchange_step  <- OppositeSpinExchangeSampler.sample's exchange branch, electron_samplers.py:235-330
  *   dqmc_energy_stats   <- EnergyMonitor's mean/std/min/max, observable.py:474-479
  *                          (per-rank partial record; ranks merge them after one all-gather)
  *   dqmc_set_weights    <- a new `params` tree after an optimiser step
@@ -185,6 +187,28 @@ int dqmc_mcmc_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t
                     void* tau, const void* R, int B, int n_sub, int max_age,
                     double target_acceptance, uint64_t seed, const void* noise,
                     const void* unif, uint8_t* accept_out, double* stats7_host);
+
+/* Metropolis-adjusted Langevin sampler (reference sampling/electron_samplers.py:176-232; drift cleaning
+ * sampling/sampling_utils.py:72-101).  The sampler state additionally carries the cleaned drift force real[B][N][3].
+ * mol_charges_host: host double[n_nuc], the FULL nuclear charges (mol.charges; the crossover parameter of the
+ * drift cleaning uses them even under an ECP).
+ *   dqmc_langevin_update <- LangevinSampler._update: log|psi|, sign and the drift of the CURRENT positions, cleaned
+ *                           with the step size `tau` (device real[1]) of the previous iteration.
+ *   dqmc_langevin_steps  <- n_sub x LangevinSampler.sample, in place: r' = r + tau F + sqrt(tau) xi, forward-Laplacian
+ *                           pass for psi' and its gradient (no ECP quadrature), Green's-function ratio in the acceptance,
+ *                           age override and step-size adaptation as dqmc_mcmc_steps.  noise / unif / accept_out /
+ *                           stats7_host as there. */
+int dqmc_langevin_update(dqmc_ctx* ctx, const void* r, const void* R, const double* mol_charges_host, int B, const void* tau,
+                         void* logpsi, int32_t* sign, void* force);
+int dqmc_langevin_steps(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, void* force, void* tau, const void* R,
+                        const double* mol_charges_host, int B, int n_sub, int max_age, double target_acceptance, uint64_t seed,
+                        const void* noise, const void* unif, uint8_t* accept_out, double* stats7_host);
+/* One opposite-spin exchange step (sampling/electron_samplers.py:235-330): per walker the positions of spin-up electron
+ * up_idx[b] and spin-down electron n_up + down_idx[b] (device int32[B] each) are swapped, psi re-evaluated (value path),
+ * accepted with 2 (log|psi'| - log|psi|) > log unif[b]; no age override, step size untouched (:312-313).  stats7_host
+ * (may be NULL): the sampler statistics after the step, [0] = acceptance of this step. */
+int dqmc_exchange_step(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int32_t* age, const void* tau, const void* R, int B,
+                       const int32_t* up_idx, const int32_t* down_idx, const void* unif, uint8_t* accept_out, double* stats7_host);
 
 /* Per-rank partial record of the energy reduction: host double[7] =
  * {n, sum_w, sum_wE, sum_E, M2 (sum of squared deviations from this rank's mean), min,

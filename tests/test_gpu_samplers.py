@@ -1,0 +1,143 @@
+"""`-m gpu` tests of the callers either side of the hot path, on the device through the C ABI against the oracle:
+Langevin (MALA) sub-steps and drift cleaning (dqmc_langevin_*), opposite-spin exchange steps (dqmc_exchange_step),
+the batch-level `compute_local_energy [M,S,B]` and the psi-ratio matrix of the overlap penalty."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from deepqmc_amd import MolecularHamiltonian, Molecule, loss
+from deepqmc_amd.sampling import LangevinSampler, MetropolisSampler, OppositeSpinExchangeSampler, synthetic_walkers
+from deepqmc_amd.wf import NeuralNetworkWaveFunction
+from oracle import geom, physics
+from oracle import sampling as osamp
+from oracle import wf as owf
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+def make(molname='LiH', ansatz='paulinet', dtype=torch.float64):
+    h = MolecularHamiltonian(mol=Molecule.from_name(molname))
+    wf = NeuralNetworkWaveFunction(h, ansatz, dtype=dtype, device=DEV, norm_eps=geom.F32_EPS)
+    return h, wf
+
+
+def oracle_psi_force(p, spec, h, R):
+    def f(rb):
+        sg, lg, gr = [], [], []
+        for x in rb:
+            x = x.clone().requires_grad_(True)
+            s, l = owf.wave_function(p, spec, x, R, h.n_up, geom.F32_EPS)
+            g, = torch.autograd.grad(l, x)
+            sg.append(s); lg.append(l.detach()); gr.append(g)
+        return torch.stack(sg), torch.stack(lg), torch.stack(gr)
+    return f
+
+
+@pytest.mark.parametrize('molname,ansatz', [('LiH', 'paulinet'), ('Be', 'ferminet')])
+def test_langevin_steps_match_oracle_f64(molname, ansatz):
+    h, wf = make(molname, ansatz)
+    params = wf.init(3, perturb_envelopes=0.1)
+    B, n = 16, 4
+    smp = LangevinSampler(h, wf, tau=0.1, max_age=3)
+    smp.length = n
+    state = smp.init(5, params, B)
+    rng = np.random.default_rng(0)
+    noise, unif = rng.standard_normal((n, B, h.n_elec, 3)), rng.random((n, B))
+    p, R, Z = owf.to_torch(params), T(h.mol.coords), T(h.mol.charges)
+    psi_force = oracle_psi_force(p, wf.spec, h, R)
+    r0 = state['r'].cpu()
+    s0, l0, g0 = psi_force(r0)
+    ost = {'r': r0.clone(), 'sign': s0, 'log': l0, 'force': osamp.clean_force(g0, r0, R, Z, 0.1),
+           'age': torch.zeros(B, dtype=torch.int64), 'tau': 0.1}
+    np.testing.assert_allclose(state['force'].cpu().numpy(), ost['force'].numpy(), rtol=1e-9, atol=1e-11)
+    state, _, stats = smp.sample(0, state, params, noise=noise, unif=unif)
+    accs = []
+    for k in range(n):
+        ost, acc, a = osamp.langevin_step(psi_force, ost, R, Z, T(noise[k]), T(unif[k]), max_age=3)
+        accs.append(acc)
+    assert torch.stack(accs).any() and not torch.stack(accs).all()
+    np.testing.assert_array_equal(state['age'].cpu().numpy(), ost['age'].numpy())
+    np.testing.assert_allclose(state['r'].cpu().numpy(), ost['r'].numpy(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(state['force'].cpu().numpy(), ost['force'].numpy(), rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(float(state['tau'][0]), ost['tau'], rtol=1e-11)
+    np.testing.assert_allclose(state['psi'].log.cpu().numpy(), ost['log'].numpy(), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(stats['sampling/acceptance'], a, rtol=1e-12)
+
+
+def test_langevin_device_rng_f32():
+    """float32, device Philox noise: the chain stays self-consistent (carried psi / drift = psi / drift of the carried
+    positions) and the acceptance sits in a sane range."""
+    h, wf = make(dtype=torch.float32)
+    params = wf.init(3, perturb_envelopes=0.1)
+    smp = LangevinSampler(h, wf, tau=0.05)
+    smp.length = 10
+    state = smp.init(5, params, 2048)
+    state, pc, stats = smp.sample(7, state, params)
+    assert 0.2 < stats['sampling/acceptance'] <= 1.0
+    chk = smp.update(state, params)
+    np.testing.assert_array_equal(chk['psi'].sign.cpu().numpy(), state['psi'].sign.cpu().numpy())
+    np.testing.assert_allclose(chk['psi'].log.cpu().numpy(), state['psi'].log.cpu().numpy(), rtol=0, atol=1e-4)
+
+
+def test_exchange_step_matches_oracle_f64():
+    h, wf = make()
+    params = wf.init(3, perturb_envelopes=0.1)
+    B = 64
+    smp = OppositeSpinExchangeSampler(MetropolisSampler(h, wf, tau=0.3), exchange_step_probability=0.5)
+    state = smp.init(0, params, B)
+    rng = np.random.default_rng(4)
+    up, dn, u = rng.integers(0, h.n_up, B), rng.integers(0, h.n_down, B), rng.random(B)
+    new, pc, stats = smp.sample(1, state, params, choices=(True, up, dn, u))
+    p = owf.to_torch(params)
+    psi = lambda rr: physics.batch_wave_function(p, wf.spec, rr, T(h.mol.coords), h.n_up, geom.F32_EPS)
+    ost = {'r': state['r'].cpu().clone(), 'sign': state['psi'].sign.cpu().to(torch.float64), 'log': state['psi'].log.cpu().clone(),
+           'age': state['age'].cpu().to(torch.int64), 'tau': 0.3}
+    onew, oacc = osamp.spin_exchange_step(psi, ost, h.n_up, torch.as_tensor(up), torch.as_tensor(dn), T(u))
+    assert oacc.any() and not oacc.all()
+    np.testing.assert_array_equal(new['age'].cpu().numpy(), onew['age'].numpy())
+    np.testing.assert_array_equal(new['r'].cpu().numpy(), onew['r'].numpy())
+    np.testing.assert_allclose(new['psi'].log.cpu().numpy(), onew['log'].numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_array_equal(new['psi'].sign.cpu().numpy(), onew['sign'].numpy().astype(np.int32))
+    np.testing.assert_allclose(stats['sampling/acceptance'], float(oacc.double().mean()), rtol=1e-12)
+    assert float(new['tau'][0]) == 0.3
+
+
+def test_batched_local_energy_and_psi_ratio_three_states():
+    """compute_local_energy [M=1, S=3, B] (loss/energy.py:19-60) and the psi-ratio matrix (loss/overlap.py:40-99) for
+    three electronic states (three parameter sets = three HIP contexts) against the oracle, float64."""
+    h, wf = make()
+    S, B = 3, 8
+    params = [wf.init(s, perturb_envelopes=0.1) for s in range(S)]
+    r = torch.as_tensor(np.stack([synthetic_walkers(h, B, seed=10 + s) for s in range(S)]), device=DEV)[None]      # [1,S,B,N,3]
+    E, stats = loss.compute_local_energy(None, h, wf, params, r)
+    assert E.shape == (1, S, B) and stats['hamil/E_kin'].shape == (1, S)
+    Rt, Zt = T(h.mol.coords), T(h.mol.charges)
+    logs, signs = np.zeros((S, S, B)), np.zeros((S, S, B))
+    for s in range(S):
+        e_ref, st_ref, _ = physics.batch_local_energy(owf.to_torch(params[s]), wf.spec, r[0, s].cpu(), Rt, Zt, h.n_up, geom.F32_EPS)
+        np.testing.assert_allclose(E[0, s].cpu().numpy(), e_ref.numpy(), rtol=1e-8, atol=1e-8)
+        np.testing.assert_allclose(float(stats['hamil/E_kin'][0, s]), float(st_ref['hamil/E_kin'].mean()), rtol=1e-8)
+        for j in range(S):
+            sg, lg = physics.batch_wave_function(owf.to_torch(params[s]), wf.spec, r[0, j].cpu(), Rt, h.n_up, geom.F32_EPS)
+            logs[s, j], signs[s, j] = lg.numpy(), sg.numpy()
+    ratio = loss.compute_psi_ratio(wf, params, r)
+    assert ratio.shape == (1, S, S, B)
+    shifted = logs - logs.mean(axis=(1, 2))[:, None, None]
+    for i in range(S):
+        for j in range(S):
+            ref = signs[i, j] * signs[j, j] * np.exp(shifted[i, j] - shifted[j, j])
+            np.testing.assert_allclose(ratio[0, i, j].cpu().numpy(), ref, rtol=1e-9)
+    w = torch.ones(1, S, B, dtype=torch.float64, device=DEV)
+    pen, info = loss.compute_mean_overlap(ratio, w)
+    mean = np.zeros((S, S))
+    for i in range(S):
+        for j in range(S):
+            mean[i, j] = (signs[i, j] * signs[j, j] * np.exp(shifted[i, j] - shifted[j, j])).mean()
+    sym = np.sign(mean) * np.sqrt(np.clip(mean * mean.T, 0, None))
+    np.testing.assert_allclose(info['overlap/pairwise/mean'][0].cpu().numpy(), sym, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(float(pen), sum(sym[i, j] ** 2 for i in range(S) for j in range(i + 1, S)), rtol=1e-9)
