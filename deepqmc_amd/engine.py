@@ -40,7 +40,10 @@ def nuclear_energy(coords: np.ndarray, charges: np.ndarray) -> float:
 
 class Engine:
     def __init__(self, spec: AnsatzSpec, hamil: MolecularHamiltonian, params, *, dtype=torch.float32,
-                 device='cuda', norm_eps: Optional[float] = None, lib=None):
+                 device='cuda', norm_eps: Optional[float] = None, lib=None, R=None):
+        """`R` [n_nuc,3]: the geometry this context is compiled for (default: the Hamiltonian's).  It matters only
+        for ansatzes with nuclear tokens, whose nuclear stream is folded into the program; every other ansatz
+        takes the geometry per call."""
         self.lib = lib if lib is not None else _lib.load()
         self.spec, self.hamil = spec, hamil
         self.dtype = dtype
@@ -49,8 +52,9 @@ class Engine:
             raise ValueError('dtype must be float32 or float64')
         # eps under the safe norm is the compute dtype's machine eps (reference utils.py:79-85)
         self.norm_eps = norm_eps if norm_eps is not None else (F32_EPS if dtype == torch.float32 else F64_EPS)
+        self.R0 = np.asarray(hamil.mol.coords if R is None else R, np.float64).reshape(hamil.n_nuc, 3)
         self.program: Program = compile_program(spec, params, hamil.n_up, hamil.n_down, hamil.n_nuc,
-                                                R=hamil.mol.coords, eps=self.norm_eps)
+                                                R=self.R0, eps=self.norm_eps)
         self.N = hamil.n_up + hamil.n_down
         sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,
                           0 if dtype == torch.float32 else 1, 0, self.norm_eps, 0.0)
@@ -77,7 +81,7 @@ class Engine:
             dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a.size else None
             self._check(self.lib.dqmc_set_ecp(self._ctx, pot.loc_params.shape[3], dp(pot.loc_params),
                                               pot.nl_params.shape[1], pot.nl_params.shape[3], dp(pot.nl_params)))
-        self.R = torch.as_tensor(hamil.mol.coords, dtype=dtype, device=self.device).contiguous()
+        self.R = torch.as_tensor(self.R0, dtype=dtype, device=self.device).contiguous()
 
     # ------------------------------------------------------------------
     def _check(self, rc: int):
@@ -112,7 +116,7 @@ class Engine:
     def set_params(self, params):
         """New parameter tree after an optimiser step (same structure)."""
         prog = compile_program(self.spec, params, self.hamil.n_up, self.hamil.n_down, self.hamil.n_nuc,
-                               R=self.hamil.mol.coords, eps=self.norm_eps)
+                               R=self.R0, eps=self.norm_eps)
         w = np.ascontiguousarray(prog.weights, np.float64)
         self._check(self.lib.dqmc_set_weights(self._ctx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size))
 

@@ -82,6 +82,7 @@ class MolecularHamiltonian:
         assert ansatz.hamil is self
 
         def loc_ene(rng, params, phys_conf):
-            return ansatz.engine(params).local_energy(phys_conf, rng=rng)
+            R = getattr(phys_conf, 'R', None)
+            return ansatz.engine(params, R).local_energy(phys_conf, rng=rng)
 
         return loc_ene

@@ -1,9 +1,10 @@
 """Batch-level callers of the hot path: `compute_local_energy` (reference
 src/deepqmc/loss/energy.py:19-60) and `compute_psi_ratio` (loss/overlap.py:19-99), with the
 reference's `[molecule, electronic state, walker]` batch axes.  The molecule and state axes are
-host loops over HIP contexts (one per state's parameter set); the walker axis is the GPU batch.
-Only single-geometry batches (M = 1, the `IdleNucleiSampler` case of the BASELINE configs) are
-accepted.
+host loops over HIP contexts (one per state's parameter set; the geometry of a molecule is an argument
+of the call); the walker axis is the GPU batch.  `phys_conf` is either the electron tensor r[M,S,B,N,3]
+(M = 1, the Hamiltonian's geometry) or a `PhysicalConfiguration(R[M,n_nuc,3], r[M,S,B,N,3], mol_idx)` as
+`MultiNuclearGeometrySampler.sample` returns it.
 """
 from __future__ import annotations
 
@@ -14,44 +15,73 @@ import torch
 from .hamil import STAT_KEYS
 
 
-def _check(r):
-    if r.dim() != 5 or r.shape[0] != 1:
-        raise ValueError('expected r[M=1, S, B, N, 3]')
+def _unpack(phys_conf):
+    """-> (r[M,S,B,N,3], [R_m or None per molecule])."""
+    if hasattr(phys_conf, 'r'):
+        r, R = phys_conf.r, phys_conf.R
+    else:
+        r, R = phys_conf, None
+    if r.dim() != 5:
+        raise ValueError('expected r[M, S, B, N, 3]')
+    M = r.shape[0]
+    if R is None:
+        if M != 1:
+            raise ValueError('M > 1 molecules need their geometries: pass a PhysicalConfiguration(R[M,n_nuc,3], r, mol_idx)')
+        return r, [None]
+    R = torch.as_tensor(R)
+    while R.dim() > 3:            # the samplers tile R over the state / walker axes (electron_samplers.py:165-173)
+        R = R[:, 0]
+    if R.dim() == 2:
+        R = R[None]
+    if R.shape[0] != M:
+        raise ValueError('R and r disagree on the number of molecules')
+    return r, [R[m] for m in range(M)]
 
 
 def compute_local_energy(rng, hamil, ansatz, params: Sequence, phys_conf_r: torch.Tensor):
     """loss/energy.py:19-60: returns (E_loc[M,S,B], stats{key: [M,S]} = per-(molecule,state)
     means over the walkers, energy.py:59).  `params` = one parameter tree per state."""
-    _check(phys_conf_r)
-    S = phys_conf_r.shape[1]
+    from .types import PhysicalConfiguration
+    r, Rs = _unpack(phys_conf_r)
+    M, S = r.shape[0], r.shape[1]
     assert len(params) == S
     es, stats = [], {k: [] for k in STAT_KEYS}
-    for s in range(S):
-        e, st = ansatz.engine(params[s]).local_energy(phys_conf_r[0, s].contiguous(), rng=rng)
-        es.append(e)
+    for m in range(M):
+        em, sm = [], {k: [] for k in STAT_KEYS}
+        for s in range(S):
+            rr = r[m, s].contiguous()
+            pc = rr if Rs[m] is None else PhysicalConfiguration(Rs[m], rr, None)
+            e, st = ansatz.engine(params[s], Rs[m]).local_energy(pc, rng=rng)
+            em.append(e)
+            for k in STAT_KEYS:
+                sm[k].append(st[k].mean())
+        es.append(torch.stack(em))
         for k in STAT_KEYS:
-            stats[k].append(st[k].mean())
-    return torch.stack(es)[None], {k: torch.stack(v)[None] for k, v in stats.items()}
+            stats[k].append(torch.stack(sm[k]))
+    return torch.stack(es), {k: torch.stack(v) for k, v in stats.items()}
 
 
 def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
     """loss/overlap.py:77-99 + :40-75: R[m, i, j, b] = psi_i(r_b ~ psi_j^2) / psi_j(r_b ~ psi_j^2),
     computed from log-shifted values (shift = mean log|psi| of each state i over all samples)."""
-    _check(phys_conf_r)
-    S, B = phys_conf_r.shape[1], phys_conf_r.shape[2]
-    sign = torch.empty(S, S, B, dtype=torch.float64, device=phys_conf_r.device)
-    log = torch.empty(S, S, B, dtype=torch.float64, device=phys_conf_r.device)
-    for i in range(S):                       # wave function i ...
-        eng = ansatz.engine(params[i])
-        for j in range(S):                   # ... on the samples of state j
-            sg, lg = eng.wf_eval(phys_conf_r[0, j].contiguous())
-            sign[i, j], log[i, j] = sg.double(), lg.double()
-    mean_log = log.mean(dim=(1, 2))                                   # overlap.py:92-94
-    shifted = log - mean_log[:, None, None]
-    diag = torch.diagonal(shifted, dim1=0, dim2=1).permute(1, 0)     # [S(j), B]
-    log_ratio = shifted - diag[None]
-    sdiag = torch.diagonal(sign, dim1=0, dim2=1).permute(1, 0)
-    return (sign * sdiag[None] * torch.exp(log_ratio))[None]
+    r, Rs = _unpack(phys_conf_r)
+    M, S, B = r.shape[0], r.shape[1], r.shape[2]
+    out = []
+    for m in range(M):
+        sign = torch.empty(S, S, B, dtype=torch.float64, device=r.device)
+        log = torch.empty(S, S, B, dtype=torch.float64, device=r.device)
+        for i in range(S):                       # wave function i ...
+            eng = ansatz.engine(params[i], Rs[m])
+            for j in range(S):                   # ... on the samples of state j
+                sg, lg = eng.wf_eval(r[m, j].contiguous(), Rs[m])
+                sign[i, j], log[i, j] = sg.double(), lg.double()
+        mean_log = log.mean(dim=(1, 2))                                   # overlap.py:92-94
+        shifted = log - mean_log[:, None, None]
+        diag = torch.diagonal(shifted, dim1=0, dim2=1).permute(1, 0)     # [S(j), B]
+        log_ratio = shifted - diag[None]
+        sdiag = torch.diagonal(sign, dim1=0, dim2=1).permute(1, 0)
+        out.append(sign * sdiag[None] * torch.exp(log_ratio))
+    return torch.stack(out)
 
 
 def symmetrize_overlap_with_clipped_geometric_mean(x: torch.Tensor) -> torch.Tensor:

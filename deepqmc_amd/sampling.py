@@ -48,7 +48,7 @@ class MetropolisSampler:
 
     def init(self, rng, params, n: int, R=None):
         """electron_samplers.py:86-100."""
-        eng = self.wf.engine(params)
+        eng = self.wf.engine(params, R)
         r = torch.as_tensor(self.sample_initializer(self.hamil, n, seed=int(rng)), dtype=eng.dtype, device=eng.device)
         state = {'r': r.contiguous(), 'age': torch.zeros(n, dtype=torch.int32, device=eng.device),
                  'tau': torch.full((1,), self.initial_tau, dtype=eng.dtype, device=eng.device)}
@@ -56,7 +56,7 @@ class MetropolisSampler:
 
     def sample(self, rng, state, params, R=None, noise=None, unif=None):
         """electron_samplers.py:140-152 / :347-357.  Returns (state, phys_conf, stats)."""
-        eng = self.wf.engine(params)
+        eng = self.wf.engine(params, R)
         # the reference's samplers are functional (a new state per call); dqmc_mcmc_steps updates its arguments
         # in place, so it gets copies and the caller's previous state stays intact (rollback, multi-state loops)
         st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
@@ -99,6 +99,105 @@ class MultiElectronicStateSampler:
         return [self.sampler.update(state[s], params[s], R) for s in range(self.n_state)]
 
 
+class IdleNucleiSampler:
+    """sampling/nuclei_samplers.py:15-37: keeps the nuclei where they are."""
+
+    def __init__(self, charges=None):
+        pass
+
+    def init(self, nuc_coords, *args, **kw):
+        return {'R': nuc_coords}
+
+    def sample(self, rng, state):
+        return state, torch.zeros_like(torch.as_tensor(state['R'])), {}
+
+
+class MoleculeIdxSampler:
+    """sampling/combined_samplers.py:17-56: cycles through the molecule indices in batches of `batch_size`,
+    optionally shuffled once or at every pass (NumPy permutation stream instead of the JAX one)."""
+
+    def __init__(self, rng, n_mols: int, batch_size: int, shuffle=False):
+        assert shuffle in (False, 'once', 'always')
+        self.rng = np.random.default_rng(int(rng))
+        self.n_mols, self.batch_size, self.shuffle, self.state = n_mols, batch_size, shuffle, 0
+        self._first = self.rng.permutation(n_mols)
+        self.permutation = self.new_permutation()
+
+    def new_permutation(self):
+        if not self.shuffle:
+            return np.arange(self.n_mols)
+        return self._first if self.shuffle == 'once' else self.rng.permutation(self.n_mols)
+
+    def sample(self):
+        idx = np.arange(self.state, min(self.state + self.batch_size, self.n_mols))
+        value = [self.permutation[idx]]
+        if len(idx) < self.batch_size:
+            self.permutation = self.new_permutation()
+            value.append(self.permutation[np.arange(self.batch_size - len(idx))])
+        self.state = (self.state + self.batch_size) % self.n_mols
+        return np.concatenate(value)
+
+
+class MultiNuclearGeometrySampler:
+    """sampling/combined_samplers.py:93-214: electron sampler states for a set of nuclear geometries; `sample` works
+    on the molecules named by `mol_idxs` (gather -> optional nuclear update / electron warp / re-equilibration ->
+    electron sampling -> scatter back) and labels the samples with their molecule index.  The molecule axis is a host
+    loop: the geometry is an argument of every HIP call (ansatzes with nuclear tokens get one context per geometry),
+    the walkers of one (molecule, state) are the GPU batch.  State: {'nuc': [per molecule], 'elec': [per molecule]
+    (whatever `elec_sampler.init` returns), 'update_nuc_counter': int array}."""
+
+    def __init__(self, elec_sampler, nuc_sampler=None, warp_elec_fn=None, update_nuc_period=None,
+                 elec_equilibration_steps=None):
+        self.elec_sampler = elec_sampler
+        self.nuc_sampler = nuc_sampler if nuc_sampler is not None else IdleNucleiSampler()
+        self.warp_elec_fn = warp_elec_fn
+        self.update_nuc_period = update_nuc_period
+        self.elec_equilibration_steps = elec_equilibration_steps
+
+    def init(self, rng, params, electron_batch_size: int, R):
+        R = torch.as_tensor(R)
+        M = R.shape[0]
+        return {'nuc': [self.nuc_sampler.init(R[m]) for m in range(M)],
+                'elec': [self.elec_sampler.init(int(rng) * M + m, params, electron_batch_size, R[m]) for m in range(M)],
+                'update_nuc_counter': np.zeros(M, np.int64)}
+
+    def update_nuc(self, rng, nuc, elec, params):
+        """combined_samplers.py:131-160 for one molecule."""
+        nuc, dR, stats = self.nuc_sampler.sample(int(rng), nuc)
+        if self.warp_elec_fn is not None:
+            elec = self.warp_elec_fn(int(rng) + 1, nuc['R'], dR, elec)
+        elec = self.elec_sampler.update(elec, params, nuc['R'])
+        for i in range(self.elec_equilibration_steps or 0):
+            elec = self.elec_sampler.sample(int(rng) * 1009 + i, elec, params, nuc['R'])[0]
+        return nuc, elec, stats
+
+    def sample(self, rng, smpl_state, params, mol_idxs):
+        mol_idxs = [int(m) for m in np.asarray(mol_idxs).reshape(-1)]
+        counter = smpl_state['update_nuc_counter']
+        nuc, elec = list(smpl_state['nuc']), list(smpl_state['elec'])
+        pcs, stats = [], []
+        for k, m in enumerate(mol_idxs):
+            if self.update_nuc_period is not None:
+                if counter[m] == self.update_nuc_period - 1:
+                    nuc[m], elec[m], _ = self.update_nuc(int(rng) * 7919 + m, nuc[m], elec[m], params)
+                    counter[m] = 0
+                else:
+                    counter[m] += 1
+            elec[m], pc, st = self.elec_sampler.sample(int(rng) * len(nuc) + m, elec[m], params, nuc[m]['R'])
+            pcs.append(pc)
+            stats.append(st)
+        r = torch.stack([pc.r for pc in pcs])                                   # [M_batch, (S,) B, N, 3]
+        Rb = torch.stack([torch.as_tensor(nuc[m]['R'], dtype=r.dtype, device=r.device) for m in mol_idxs])
+        mol_idx = torch.as_tensor(mol_idxs, dtype=torch.int32, device=r.device).reshape((-1,) + (1,) * (r.dim() - 3)).expand(r.shape[:-2])
+        new_state = {'nuc': nuc, 'elec': elec, 'update_nuc_counter': counter}
+        return new_state, PhysicalConfiguration(Rb, r, mol_idx.contiguous()), {k: [st[k] for st in stats] for k in stats[0]}
+
+    def update(self, smpl_state, params):
+        smpl_state = dict(smpl_state)
+        smpl_state['elec'] = [self.elec_sampler.update(e, params, n['R']) for e, n in zip(smpl_state['elec'], smpl_state['nuc'])]
+        return smpl_state
+
+
 class LangevinSampler(MetropolisSampler):
     """Metropolis-adjusted Langevin sampler (sampling/electron_samplers.py:176-232): drift = cleaned grad log|psi|
     (sampling_utils.py:72-101) from one forward-Laplacian pass per proposal, Green's-function ratio in the acceptance.
@@ -106,12 +205,12 @@ class LangevinSampler(MetropolisSampler):
     library (`dqmc_langevin_update` / `dqmc_langevin_steps`); the state carries the drift as 'force'."""
 
     def update(self, state, params, R=None):
-        eng = self.wf.engine(params)
+        eng = self.wf.engine(params, R)
         sign, log, force = eng.langevin_update(state['r'], state['tau'], self.hamil.mol.charges, R)
         return {**state, 'psi': Psi(sign, log), 'force': force}
 
     def sample(self, rng, state, params, R=None, noise=None, unif=None):
-        eng = self.wf.engine(params)
+        eng = self.wf.engine(params, R)
         st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
               'age': state['age'].clone(), 'tau': state['tau'].clone(), 'force': state['force'].clone()}
         stats = eng.langevin_steps(st, self.length, self.hamil.mol.charges, max_age=self.max_age,
@@ -141,7 +240,7 @@ class OppositeSpinExchangeSampler:
         return self.sampler.update(state, params, R)
 
     def sample(self, rng, state, params, R=None, choices=None, **kw):
-        eng = self.wf.engine(params)
+        eng = self.wf.engine(params, R)
         B, n_up, n_down = state['r'].shape[0], self.hamil.n_up, self.hamil.n_down
         gen = torch.Generator(device='cpu')
         gen.manual_seed(int(rng) * 7919 + 13)

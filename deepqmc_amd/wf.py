@@ -40,27 +40,42 @@ class NeuralNetworkWaveFunction:
         h = self.hamil
         return init_params(self.spec, h.n_up, h.n_down, h.n_nuc, seed=int(rng), **kw)
 
-    def engine(self, params) -> Engine:
+    def _geometry_key(self, R):
+        """Ansatzes with nuclear tokens fold the geometry into the program: one context per (tree, geometry).
+        Everything else takes R per call and shares one context across geometries."""
+        if R is None or not self.spec.nuclei_tokens:
+            return None
+        import numpy as np
+        R = np.asarray(R.detach().cpu() if hasattr(R, 'detach') else R, np.float64).reshape(self.hamil.n_nuc, 3)
+        return None if np.array_equal(R, self.hamil.mol.coords) else R.tobytes()
+
+    def engine(self, params, R=None) -> Engine:
         """One HIP context per live parameter tree (e.g. per electronic state, the leading `S` axis of
         the reference's params, wf/base.py:27).  The cache entry keeps the tree alive and is matched by
         identity; once `max_engines` trees are alive the least recently used context is re-targeted
         with `set_params` (no new allocation)."""
-        for k, (tree, eng) in enumerate(self._engines):
-            if tree is params:
+        gkey = self._geometry_key(R)
+        for k, (tree, key, eng) in enumerate(self._engines):
+            if tree is params and key == gkey:
                 self._engines.append(self._engines.pop(k))
                 return eng
-        if len(self._engines) >= self.max_engines:
-            _, eng = self._engines.pop(0)
+        reuse = [k for k, (_, key, _) in enumerate(self._engines) if key == gkey]
+        if len(self._engines) >= self.max_engines and reuse:
+            _, _, eng = self._engines.pop(reuse[0])
             eng.set_params(params)
         else:
+            if len(self._engines) >= self.max_engines:
+                self._engines.pop(0)[2].close()
+            import numpy as np
+            R0 = None if gkey is None else np.frombuffer(gkey, np.float64).reshape(self.hamil.n_nuc, 3)
             eng = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,
-                         norm_eps=self.norm_eps, lib=self._lib)
-        self._engines.append((params, eng))
+                         norm_eps=self.norm_eps, lib=self._lib, R=R0)
+        self._engines.append((params, gkey, eng))
         return eng
 
     def invalidate(self, params=None):
         """Re-upload the weights of `params` (all cached trees if None) after their leaves were changed in place."""
-        for tree, eng in self._engines:
+        for tree, _, eng in self._engines:
             if params is None or tree is params:
                 eng.set_params(tree)
 
@@ -70,7 +85,7 @@ class NeuralNetworkWaveFunction:
             raise NotImplementedError('return_mos is a pretraining hook, outside the hot path')
         r = phys_conf.r if isinstance(phys_conf, PhysicalConfiguration) else phys_conf
         R = phys_conf.R if isinstance(phys_conf, PhysicalConfiguration) else None
-        sign, log = self.engine(params).wf_eval(r, R)
+        sign, log = self.engine(params, R).wf_eval(r, R)
         return Psi(sign, log)
 
     __call__ = apply

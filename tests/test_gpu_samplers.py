@@ -141,3 +141,29 @@ def test_batched_local_energy_and_psi_ratio_three_states():
     sym = np.sign(mean) * np.sqrt(np.clip(mean * mean.T, 0, None))
     np.testing.assert_allclose(info['overlap/pairwise/mean'][0].cpu().numpy(), sym, rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(float(pen), sum(sym[i, j] ** 2 for i in range(S) for j in range(i + 1, S)), rtol=1e-9)
+
+
+def test_multi_geometry_batches_incl_nuclear_tokens():
+    """MultiNuclearGeometrySampler on the device; for the TransPsiformer (nuclear stream folded into the program) the
+    facade builds one context per geometry, for PauliNet the geometry is an argument of each call."""
+    from deepqmc_amd.engine import Engine
+    from deepqmc_amd.sampling import DecorrSampler, MultiElectronicStateSampler, MultiNuclearGeometrySampler
+    from deepqmc_amd.types import PhysicalConfiguration
+    for ansatz in ('paulinet', 'transpsiformer'):
+        h, wf = make('LiH', ansatz)
+        S, B = 2, 16
+        params = [wf.init(s, perturb_envelopes=0.1) for s in range(S)]
+        Rs = torch.as_tensor(np.stack([h.mol.coords, h.mol.coords * 1.25]), device=DEV)
+        ms = MultiNuclearGeometrySampler(MultiElectronicStateSampler(DecorrSampler(h, wf, length=3, tau=0.3), S))
+        state = ms.init(0, params, B, Rs)
+        state, pc, stats = ms.sample(1, state, params, [1, 0])
+        E, st = loss.compute_local_energy(None, h, wf, params, pc)
+        assert E.shape == (2, S, B) and torch.isfinite(E).all()
+        for k, m in enumerate([1, 0]):
+            mol = Molecule(coords=Rs[m].cpu().numpy(), charges=h.mol.charges, charge=h.mol.charge, spin=h.mol.spin)
+            for s in range(S):
+                eng = Engine(wf.spec, MolecularHamiltonian(mol=mol), params[s], dtype=torch.float64, device=DEV, norm_eps=geom.F32_EPS)
+                e_ref, _ = eng.local_energy(pc.r[k, s])
+                np.testing.assert_allclose(E[k, s].cpu().numpy(), e_ref.cpu().numpy(), rtol=1e-11, atol=1e-11)
+                sg, lg = eng.wf_eval(pc.r[k, s])
+                np.testing.assert_allclose(state['elec'][m][s]['psi'].log.cpu().numpy(), lg.cpu().numpy(), rtol=1e-11, atol=1e-11)

@@ -141,3 +141,41 @@ def test_overlap_symmetrisation_known_answers():
     ov, stats = loss.compute_mean_overlap(ratio, weight)
     np.testing.assert_allclose(float(ov), 0.128, rtol=1e-14)
     np.testing.assert_allclose(stats['overlap/pairwise/mean'][0].numpy(), [[1.0, 0.128 ** 0.5], [0.128 ** 0.5, 1.0]], rtol=1e-14)
+
+
+def test_multi_geometry_sampler_and_energies():
+    """MultiNuclearGeometrySampler (combined_samplers.py:93-214) over two LiH bond lengths x two electronic states:
+    only the molecules named by mol_idxs advance, samples carry their molecule index and geometry, and
+    compute_local_energy [M,S,B] on the returned PhysicalConfiguration equals per-geometry engines."""
+    from deepqmc_amd.engine import Engine
+    from deepqmc_amd.sampling import IdleNucleiSampler, MoleculeIdxSampler, MultiNuclearGeometrySampler
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    S, B = 2, 3
+    params = [wf.init(s, perturb_envelopes=0.1) for s in range(S)]
+    Rs = torch.as_tensor(np.stack([h.mol.coords, h.mol.coords * 1.3, h.mol.coords * 0.8]))
+    ms = MultiNuclearGeometrySampler(MultiElectronicStateSampler(DecorrSampler(h, wf, length=2, tau=0.3), S), IdleNucleiSampler())
+    state = ms.init(0, params, B, Rs)
+    before = [[st['r'].clone() for st in mol] for mol in state['elec']]
+    state, pc, stats = ms.sample(1, state, params, [2, 0])
+    assert pc.r.shape == (2, S, B, 4, 3) and pc.R.shape == (2, 2, 3) and pc.mol_idx.shape == (2, S, B)
+    assert pc.mol_idx[0].unique().tolist() == [2] and pc.mol_idx[1].unique().tolist() == [0]
+    assert torch.equal(pc.R[0], Rs[2]) and torch.equal(pc.R[1], Rs[0])
+    for s in range(S):
+        assert torch.equal(state['elec'][1][s]['r'], before[1][s])              # molecule 1 was not sampled
+        assert not torch.equal(state['elec'][2][s]['r'], before[2][s])
+        assert torch.equal(state['elec'][2][s]['r'], pc.r[0, s])
+    E, st = loss.compute_local_energy(None, h, wf, params, pc)
+    assert E.shape == (2, S, B) and st['hamil/V_loc'].shape == (2, S)
+    for k, m in enumerate([2, 0]):
+        mol = Molecule(coords=Rs[m].numpy(), charges=h.mol.charges, charge=h.mol.charge, spin=h.mol.spin)
+        for s in range(S):
+            eng = Engine(wf.spec, MolecularHamiltonian(mol=mol), params[s], dtype=torch.float64, device='cpu', lib=emu_lib(),
+                         norm_eps=geom.F32_EPS)
+            e_ref, _ = eng.local_energy(pc.r[k, s])
+            np.testing.assert_allclose(E[k, s].numpy(), e_ref.numpy(), rtol=1e-12, atol=1e-12)
+    ratio = loss.compute_psi_ratio(wf, params, pc)
+    assert ratio.shape == (2, S, S, B)
+    np.testing.assert_allclose(ratio[:, 0, 0].numpy(), 1.0, rtol=1e-12)
+    idx = MoleculeIdxSampler(0, 3, 2)
+    assert [idx.sample().tolist() for _ in range(3)] == [[0, 1], [2, 0], [1, 2]]
