@@ -261,14 +261,15 @@ struct Engine : dqmc_ctx {
             const int ldw = pad4(i[21]);
             ok = i[18] >= 0 && i[18] + i[20] <= d.rows && i[19] >= 0 && i[19] % 4 == 0 && i[19] + ldw <= d.width &&
                  i[22] >= 0 && i[22] % 4 == 0 && (size_t)i[22] + wrows * ldw <= n_weights &&
-                 (i[23] < 0 || (i[23] % 4 == 0 && (size_t)(i[23] + ldw) <= n_weights)) && i[24] >= 0 && i[24] <= 2;
+                 (i[23] < 0 || (i[23] % 4 == 0 && (size_t)(i[23] + ldw) <= n_weights)) && i[24] >= 0 && i[24] <= 4;
             if (ok && i[25] >= 0)
               ok = okb(i[25]) && bufs[i[25]].width >= i[19] + ldw && i[26] >= 0 && i[26] + i[20] <= bufs[i[25]].rows;
           }
           break;
         }
         case DQMC_OP_SPIN_MEAN: ok = okb(i[0]) && okb(i[1]) && bufs[i[0]].rows == N && bufs[i[1]].rows == 2 && bufs[i[0]].width == bufs[i[1]].width; break;
-        case DQMC_OP_CONV: ok = okb(i[0]) && okb(i[1]) && okb(i[2]) && bufs[i[1]].rows == N && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[6] <= bufs[i[1]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
+        case DQMC_OP_CONST: ok = okb(i[0]) && i[1] >= 0 && (size_t)i[1] + (size_t)bufs[i[0]].rows * bufs[i[0]].width <= n_weights; break;
+        case DQMC_OP_CONV: ok = okb(i[0]) && okb(i[1]) && okb(i[2]) && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[6] <= bufs[i[1]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
         case DQMC_OP_EDGE_SUM: ok = okb(i[0]) && okb(i[2]) && bufs[i[2]].rows == N && i[6] <= bufs[i[0]].width && i[3] + i[6] <= bufs[i[2]].width && (size_t)(i[4] + 2 * N * i[5]) <= n_itable; break;
         case DQMC_OP_ROW_SUM: ok = okb(i[0]) && okb(i[1]) && bufs[i[1]].rows == 1 && bufs[i[0]].width == bufs[i[1]].width; break;
         case DQMC_OP_ORBITALS: {
@@ -291,6 +292,17 @@ struct Engine : dqmc_ctx {
           break;
         default: ok = false;
       }
+      if (ok && op.kind == DQMC_OP_FEAT_EE)          // senders: electron s >= 0, or nucleus -1 - s
+        for (int r = 0; r < i[2] && ok; ++r) {
+          const int rc = h_itable[i[1] + 2 * r], sd = h_itable[i[1] + 2 * r + 1];
+          ok = rc >= 0 && rc < N && sd < N && -1 - sd < sys.n_nuc;
+        }
+      if (ok && op.kind == DQMC_OP_CONV)
+        for (int q = 0; q < N * i[5] && ok; ++q) {
+          const int row = h_itable[i[4] + 2 * q], sd = h_itable[i[4] + 2 * q + 1];
+          if (row < 0) continue;
+          ok = row < bufs[i[0]].rows && (sd >= 0 ? sd : -1 - sd) < bufs[i[1]].rows;
+        }
       if (!ok) return fail(DQMC_E_ARG, "malformed op #" + std::to_string(k) + " kind " + std::to_string(op.kind));
     }
     return DQMC_OK;
@@ -367,7 +379,7 @@ struct Engine : dqmc_ctx {
                 if (row >= 0 && (pair_rs[i[0]][2 * row] != el || pair_rs[i[0]][2 * row + 1] != snd)) ok = false;
               }
           break;
-        case DQMC_OP_FEAT_EN: full_written[i[0]] = 1; break;
+        case DQMC_OP_FEAT_EN: case DQMC_OP_CONST: full_written[i[0]] = 1; break;
         case DQMC_OP_SPIN_MEAN: case DQMC_OP_ROW_SUM: if (compact[i[0]]) ok = false; full_written[i[1]] = 1; break;
         case DQMC_OP_ORBITALS: if (compact[i[0]]) ok = false; full_written[i[1]] = 1; break;
         case DQMC_OP_SLOGDET: if (compact[i[0]]) ok = false; break;
@@ -448,7 +460,7 @@ struct Engine : dqmc_ctx {
     const int32_t* i = op.i;
     rd.clear(); wr.clear();
     switch (op.kind) {
-      case DQMC_OP_FEAT_EN: case DQMC_OP_FEAT_EE: wr.push_back(i[0]); break;
+      case DQMC_OP_FEAT_EN: case DQMC_OP_FEAT_EE: case DQMC_OP_CONST: wr.push_back(i[0]); break;
       case DQMC_OP_LINEAR:
         for (int p = 0; p < i[0]; ++p) rd.push_back(i[1 + 4 * p]);
         if (i[25] >= 0) rd.push_back(i[25]);
@@ -653,6 +665,12 @@ struct Engine : dqmc_ctx {
       if (ops[k].kind == DQMC_OP_ATTENTION || ops[k].kind == DQMC_OP_SLOGDET || ops[k].kind == DQMC_OP_FINAL) return DQMC_OK;
     }
     if (n_f < 0) return DQMC_OK;
+    for (int k = 0; k < n_f; ++k) {       // the LDS-resident kernel implements tanh / silu layers over electron senders only
+      if (ops[k].kind == DQMC_OP_CONST) return DQMC_OK;
+      if (ops[k].kind == DQMC_OP_LINEAR && ops[k].i[24] > 2) return DQMC_OK;
+      if (ops[k].kind == DQMC_OP_FEAT_EE)
+        for (int r = 0; r < ops[k].i[2]; ++r) if (h_itable[ops[k].i[1] + 2 * r + 1] < 0) return DQMC_OK;
+    }
     fused_n_ops = n_f;
     if (fused_sched_mode == 3) {
       // largest per-level budget (= fewest levels) whose packed 4-walker tile leaves room for 4 workgroups per CU
@@ -950,7 +968,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_FEAT_EE:
           t_begin("feat", 0);
-          dqmc::launch_feat_ee<real>(st, r, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
+          dqmc::launch_feat_ee<real>(st, r, R, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
                                      li.TP > 1 && compact[i[0]]);
           t_end();
           break;
@@ -990,7 +1008,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_CONV:
           t_begin("graph", 0);
-          dqmc::launch_conv<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, bptr(i[2]),
+          dqmc::launch_conv<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].rows, bufs[i[1]].width, bptr(i[2]),
                                   bufs[i[2]].width, i[3], d_it + i[4], i[5], i[6], B, li, li.TP > 1 && compact[i[0]]);
           t_end();
           break;
@@ -1017,6 +1035,11 @@ struct Engine : dqmc_ctx {
           if (rc2) return fail(DQMC_E_HIP, "attention launch failed");
           break;
         }
+        case DQMC_OP_CONST:
+          t_begin("feat", 0);
+          dqmc::launch_const_rows<real>(st, d_w + i[1], bptr(i[0]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
+          t_end();
+          break;
         case DQMC_OP_ROW_SUM:
           t_begin("graph", 0);
           dqmc::launch_row_sum<real>(st, bptr(i[0]), bptr(i[1]), B, bufs[i[0]].rows, bufs[i[0]].width, li);

@@ -34,6 +34,18 @@ template <typename real> __device__ __forceinline__ void act_derivs(int act, rea
     y = v * s;
     d1 = s * (1 + v * (1 - s));
     d2 = s * (1 - s) * (2 + v * (1 - 2 * s));
+  } else if (act == 3) {     // shifted softplus log(1 + e^v) + log(1/2) (reference hkext.py:13-19)
+    const real av = v < 0 ? -v : v;
+    const real e = r_exp<real>(-av);
+    const real s = v >= 0 ? 1 / (1 + e) : e / (1 + e);
+    y = (v > 0 ? v : (real)0) + (sizeof(real) == 4 ? (real)log1pf((float)e) : (real)log1p((double)e)) - (real)0.69314718055994530942;
+    d1 = s;
+    d2 = s * (1 - s);
+  } else if (act == 4) {     // multiplicative backflow activation 1 + 2 tanh(v/4) (wf/nn_wave_function.py:17)
+    const real t = r_tanh<real>(v * (real)0.25);
+    y = 1 + 2 * t;
+    d1 = (1 - t * t) * (real)0.5;
+    d2 = -t * (1 - t * t) * (real)0.25;
   } else {
     y = v; d1 = 1; d2 = 0;
   }

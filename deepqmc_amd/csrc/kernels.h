@@ -15,14 +15,16 @@ template <typename real>
 void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B, int n_nuc, int n_up, int width,
                     LaneInfo li, double eps, int log_rescale, int use_spin);
 template <typename real>
-void launch_feat_ee(hipStream_t st, const real* r, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
+void launch_feat_ee(hipStream_t st, const real* r, const real* R, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
                     double eps, int log_rescale, int compact);
+template <typename real>
+void launch_const_rows(hipStream_t st, const real* tab, real* x, int B, int rows, int width, LaneInfo li);
 template <typename real>
 void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li);
 template <typename real>
 void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int width, LaneInfo li);
 template <typename real>
-void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
+void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_rows, int hx_width, real* out,
                  int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li, int compact);
 template <typename real>
 void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,

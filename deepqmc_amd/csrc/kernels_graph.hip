@@ -34,8 +34,10 @@ __global__ void __launch_bounds__(256) k_feat_en(const real* __restrict__ r, con
 }
 
 // Electron-electron edge features, reference gnn/graph.py:23-31 (d = r_recv - r_send).
+// A negative sender s names nucleus -1 - s: d = r_recv - R (the 'ne' edges of the convolution, gnn/graph.py:100-121).
 template <typename real>
-__global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, const int32_t* __restrict__ pairs,
+__global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, const real* __restrict__ R,
+                                                 const int32_t* __restrict__ pairs,
                                                  real* __restrict__ e, int B, int n_rows, LaneInfo li, double eps,
                                                  int log_rescale, int compact) {
   // compact: the destination carries the 8 pair lanes of common.h (Laplacian mode only)
@@ -55,7 +57,7 @@ __global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, con
   } else {
     double d[3];
     for (int c = 0; c < 3; ++c)
-      d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (double)r[((long)b * li.N + sd) * 3 + c];
+      d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (sd >= 0 ? (double)r[((long)b * li.N + sd) * 3 + c] : (double)R[(-1 - sd) * 3 + c]);
     double f[4];
     pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f);
     for (int c = 0; c < 4; ++c) o.v[c] = (real)f[c];
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(256) k_row_sum(const real* __restrict__ x, rea
 // with the product rule across lanes (value, d/dr_c, Laplacian).  tab: int [N][S][2].
 template <typename real>
 __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int we_rows, int we_width,
-                                              const real* __restrict__ hx, int hx_width, real* __restrict__ out,
+                                              const real* __restrict__ hx, int hx_rows, int hx_width, real* __restrict__ out,
                                               int out_width, int col0, const int32_t* __restrict__ tab, int S, int W,
                                               int B, LaneInfo li, int compact) {
   // `compact`: the edge operand carries the 8 pair lanes of common.h; lane t of edge (i, snd) is then lane
@@ -123,7 +125,8 @@ __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int w
   for (int s = 0; s < S; ++s) {
     const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
     if (row < 0) continue;
-    acc0 += we[(((long)b * we_rows + row) * TPe) * we_width + c] * hx[(((long)b * li.N + snd) * li.TP) * hx_width + c];
+    const int hrow = snd >= 0 ? snd : -1 - snd;          // a negative sender is nucleus -1 - snd (row of a nuclear node buffer)
+    acc0 += we[(((long)b * we_rows + row) * TPe) * we_width + c] * hx[(((long)b * hx_rows + hrow) * li.TP) * hx_width + c];
   }
   o[0] = acc0;
   for (int t = 1; t < T; ++t) {
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int w
       const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
       if (row < 0) continue;
       const real* a = we + (((long)b * we_rows + row) * TPe) * we_width + c;
-      const real* h = hx + (((long)b * li.N + snd) * li.TP) * hx_width + c;
+      const real* h = hx + (((long)b * hx_rows + (snd >= 0 ? snd : -1 - snd)) * li.TP) * hx_width + c;
       const int ta = (compact && T > 1) ? pair_lane(t, T, i, snd) : t;
       const real at = ta >= 0 ? a[(long)ta * we_width] : (real)0, ht = h[(long)t * hx_width];
       acc += at * h[0] + a[0] * ht;
@@ -184,11 +187,31 @@ void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B
                      width, li, eps, log_rescale, use_spin);
 }
 template <typename real>
-void launch_feat_ee(hipStream_t st, const real* r, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
+void launch_feat_ee(hipStream_t st, const real* r, const real* R, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
                     double eps, int log_rescale, int compact) {
   const long total = (long)B * n_rows * (compact ? PAIR_LANES : li.TP);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_ee<real>), dim3(nblk(total)), dim3(256), 0, st, r, pairs, e, B, n_rows,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_ee<real>), dim3(nblk(total)), dim3(256), 0, st, r, R, pairs, e, B, n_rows,
                      li, eps, log_rescale, compact);
+}
+// Constant rows (learned embeddings that do not depend on the electron positions: hk.Embed of the electron /
+// nuclear embeddings, gnn/electron_gnn.py:497-503,596-625 with positional_embeddings = false): value lane from the
+// weight table, all derivative lanes zero.
+template <typename real>
+__global__ void __launch_bounds__(256) k_const_rows(const real* __restrict__ tab, real* __restrict__ x, int B, int rows, int width,
+                                                    LaneInfo li) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * rows * li.TP * width;
+  if (idx >= total) return;
+  const int c = (int)(idx % width);
+  long q = idx / width;
+  const int t = (int)(q % li.TP); q /= li.TP;
+  const int row = (int)(q % rows);
+  x[idx] = t == 0 ? tab[(long)row * width + c] : (real)0;
+}
+template <typename real>
+void launch_const_rows(hipStream_t st, const real* tab, real* x, int B, int rows, int width, LaneInfo li) {
+  const long total = (long)B * rows * li.TP * width;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_const_rows<real>), dim3(nblk(total)), dim3(256), 0, st, tab, x, B, rows, width, li);
 }
 template <typename real>
 void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li) {
@@ -201,10 +224,10 @@ void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_sum<real>), dim3(nblk(total)), dim3(256), 0, st, x, s, B, rows, width, li);
 }
 template <typename real>
-void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_width, real* out,
+void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_rows, int hx_width, real* out,
                  int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li, int compact) {
   const long total = (long)B * li.N * W;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx, hx_rows,
                      hx_width, out, out_width, col0, tab, S, W, B, li, compact);
 }
 template <typename real>
@@ -218,11 +241,12 @@ void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, rea
 #define DQMC_INST(real)                                                                                              \
   template void launch_feat_en<real>(hipStream_t, const real*, const real*, real*, int, int, int, int, LaneInfo,     \
                                      double, int, int);                                                              \
-  template void launch_feat_ee<real>(hipStream_t, const real*, const int32_t*, real*, int, int, LaneInfo, double,    \
+  template void launch_feat_ee<real>(hipStream_t, const real*, const real*, const int32_t*, real*, int, int, LaneInfo, double, \
                                      int, int);                                                                      \
+  template void launch_const_rows<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                   \
   template void launch_spin_mean<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                    \
   template void launch_row_sum<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                      \
-  template void launch_conv<real>(hipStream_t, const real*, int, int, const real*, int, real*, int, int,             \
+  template void launch_conv<real>(hipStream_t, const real*, int, int, const real*, int, int, real*, int, int,        \
                                   const int32_t*, int, int, int, LaneInfo, int);                                     \
   template void launch_edge_sum<real>(hipStream_t, const real*, int, int, real*, int, int, const int32_t*, int, int, \
                                       double, int, LaneInfo, int);

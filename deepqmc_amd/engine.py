@@ -40,10 +40,12 @@ def nuclear_energy(coords: np.ndarray, charges: np.ndarray) -> float:
 
 class Engine:
     def __init__(self, spec: AnsatzSpec, hamil: MolecularHamiltonian, params, *, dtype=torch.float32,
-                 device='cuda', norm_eps: Optional[float] = None, lib=None, R=None):
+                 device='cuda', norm_eps: Optional[float] = None, lib=None, R=None, compiler=None):
         """`R` [n_nuc,3]: the geometry this context is compiled for (default: the Hamiltonian's).  It matters only
         for ansatzes with nuclear tokens, whose nuclear stream is folded into the program; every other ansatz
-        takes the geometry per call."""
+        takes the geometry per call.  `compiler(params) -> Program` replaces the default `compile_program(spec, ...)`
+        (e.g. program_featurewise.compile_featurewise for the reference's test ansatz family); `spec` may then be
+        any object with `n_determinants` and `nuclei_tokens`."""
         self.lib = lib if lib is not None else _lib.load()
         self.spec, self.hamil = spec, hamil
         self.dtype = dtype
@@ -53,8 +55,9 @@ class Engine:
         # eps under the safe norm is the compute dtype's machine eps (reference utils.py:79-85)
         self.norm_eps = norm_eps if norm_eps is not None else (F32_EPS if dtype == torch.float32 else F64_EPS)
         self.R0 = np.asarray(hamil.mol.coords if R is None else R, np.float64).reshape(hamil.n_nuc, 3)
-        self.program: Program = compile_program(spec, params, hamil.n_up, hamil.n_down, hamil.n_nuc,
-                                                R=self.R0, eps=self.norm_eps)
+        self._compile = compiler if compiler is not None else (
+            lambda p_: compile_program(spec, p_, hamil.n_up, hamil.n_down, hamil.n_nuc, R=self.R0, eps=self.norm_eps))
+        self.program: Program = self._compile(params)
         self.N = hamil.n_up + hamil.n_down
         sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,
                           0 if dtype == torch.float32 else 1, 0, self.norm_eps, 0.0)
@@ -115,8 +118,7 @@ class Engine:
 
     def set_params(self, params):
         """New parameter tree after an optimiser step (same structure)."""
-        prog = compile_program(self.spec, params, self.hamil.n_up, self.hamil.n_down, self.hamil.n_nuc,
-                               R=self.R0, eps=self.norm_eps)
+        prog = self._compile(params)
         w = np.ascontiguousarray(prog.weights, np.float64)
         self._check(self.lib.dqmc_set_weights(self._ctx, w.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), w.size))
 

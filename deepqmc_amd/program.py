@@ -18,8 +18,8 @@ from .params import attention_feature_name, GNN, OMNI, WF, layer_dims, layer_nam
 from .spec import AnsatzSpec, MLPSpec
 
 OP_FEAT_EN, OP_FEAT_EE, OP_LINEAR, OP_SPIN_MEAN, OP_CONV, OP_EDGE_SUM, OP_ROW_SUM = 1, 2, 3, 4, 5, 6, 7
-OP_ORBITALS, OP_SLOGDET, OP_FINAL, OP_ATTENTION = 8, 9, 10, 11
-ACT = {None: 0, 'tanh': 1, 'silu': 2}
+OP_ORBITALS, OP_SLOGDET, OP_FINAL, OP_ATTENTION, OP_CONST = 8, 9, 10, 11, 12
+ACT = {None: 0, 'tanh': 1, 'silu': 2, 'ssp': 3, 'mult_tanh': 4}
 N_OP_I = 28
 
 

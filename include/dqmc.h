@@ -63,22 +63,24 @@ enum dqmc_op_kind {
    * (gnn/electron_gnn.py:596-625): row i = [|d|,dx,dy,dz] per nucleus (+ spin). */
   DQMC_OP_FEAT_EN = 1,
   /* i: [0]=dst buf [1]=table offset of (recv,send) int pairs [2]=n_edge_rows
-   * [3]=log_rescale.  Electron-electron edge features d = r_recv - r_send
-   * (gnn/graph.py:23-31, gnn/edge_features.py:21-123). */
+   * [3]=log_rescale.  Edge features of d = r_recv - r_send (gnn/graph.py:23-31, gnn/edge_features.py:21-123);
+   * send >= 0: an electron, send < 0: nucleus -1 - send (the 'ne' edges, d = r_recv - R). */
   DQMC_OP_FEAT_EE = 2,
   /* Forward-Laplacian linear layer y = act(concat(pieces) W + b) (+ residual).
    * i: [0]=n_pieces, then per piece p (p<4) at [1+4p..]: src buf, r0, K (unpadded
    * width used), bcast (1: every dst row of a walker reads src row r0);
    * [17]=dst buf [18]=dst r0 [19]=dst col0 [20]=nrows (per walker) [21]=Nout
-   * [22]=W offset [23]=bias offset or -1 [24]=act (0 none,1 tanh,2 silu)
+   * [22]=W offset [23]=bias offset or -1 [24]=act (0 none, 1 tanh, 2 silu, 3 shifted softplus hkext.py:13-19,
+   * 4 the multiplicative backflow activation 1 + 2 tanh(x/4) of wf/nn_wave_function.py:17)
    * [25]=residual buf or -1 [26]=residual r0 [27]=normalize (1: out = (res + y)/sqrt(2),
    * 0: out = res + y; hkext.py:130-137).  W is row-major [sum_p pad4(K_p)][pad4(Nout)]. */
   DQMC_OP_LINEAR = 3,
   /* i: [0]=src buf [1]=dst buf (rows = 2) [2]=n_up.  Mean over up / down electrons
    * (gnn/update_features.py:86-102). */
   DQMC_OP_SPIN_MEAN = 4,
-  /* i: [0]=edge buf (we) [1]=node buf (hx) [2]=dst buf [3]=dst col0 [4]=table offset of
-   * int [N][S][2] (edge row, sender; -1 = none) [5]=S [6]=width.
+  /* i: [0]=edge buf (we) [1]=node buf (hx; rows = electrons, or nuclei for 'ne' edges) [2]=dst buf [3]=dst col0
+   * [4]=table offset of int [N][S][2] (edge row, sender; row -1 = none; sender < 0 = nucleus -1 - sender = row of hx)
+   * [5]=S [6]=width.
    * out[i] = sum_s we[row(i,s)] * hx[send(i,s)] (gnn/graph.py:226-335). */
   DQMC_OP_CONV = 5,
   /* i: as CONV with [1]=divisor instead of a node buf.  out[i] = sum_s e[row(i,s)] / divisor
@@ -108,7 +110,11 @@ enum dqmc_op_kind {
    * [6]=n_const extra key/value rows that do not depend on the electrons (the nuclear tokens of
    * CombinedNodeAttention with elec_to_nuc = false, update_features.py:385-451; they come first
    * in the key order) [7],[8]=weight offsets of their keys / values ([n_const][heads*head_dim]). */
-  DQMC_OP_ATTENTION = 11
+  DQMC_OP_ATTENTION = 11,
+  /* i: [0]=dst buf [1]=weight offset of real[rows][width].  Rows that do not depend on the electron positions
+   * (hk.Embed electron / nuclear embeddings, gnn/electron_gnn.py:497-503,596-625): value lane = the table,
+   * derivative lanes zero. */
+  DQMC_OP_CONST = 12
 };
 
 typedef struct dqmc_op {

@@ -139,8 +139,8 @@ class Interp:
         buf = self.bufs[dst]
         for k in range(n):
             rc, sd = self.it[tab + 2 * k], self.it[tab + 2 * k + 1]
-            d = self.r[:, rc] - self.r[:, sd]
-            buf[:, k] = self._feat4(d, rc, sd, logr)
+            d = self.r[:, rc] - (self.r[:, sd] if sd >= 0 else self.R[-1 - sd])     # sd < 0: nucleus -1 - sd
+            buf[:, k] = self._feat4(d, rc, sd if sd >= 0 else -1, logr)
 
     def op_3(self, op):  # LINEAR
         i = op.i
@@ -168,6 +168,12 @@ class Interp:
             d1 = s * (1 + v * (1 - s))
             d2 = s * (1 - s) * (2 + v * (1 - 2 * s))
             y = self._chain(y, v * s, d1, d2)
+        elif act == 3:        # shifted softplus (hkext.py:13-19)
+            s = 1 / (1 + np.exp(-v))
+            y = self._chain(y, np.logaddexp(0.0, v) - math.log(2.0), s, s * (1 - s))
+        elif act == 4:        # 1 + 2 tanh(x/4) (wf/nn_wave_function.py:17)
+            t = np.tanh(v / 4)
+            y = self._chain(y, 1 + 2 * t, (1 - t * t) / 2, -t * (1 - t * t) / 4)
         y = self._ll(y)
         if res >= 0:
             y = (self.bufs[res][:, rr0:rr0 + nrows, :, dc0:dc0 + nout_p] + y) * (1 / math.sqrt(2.0) if rnorm else 1.0)
@@ -189,7 +195,7 @@ class Interp:
                 if row < 0:
                     continue
                 a = self._ll(self.bufs[we][:, row, :, :W])
-                b_ = self._ll(self.bufs[hx][:, snd, :, :W])
+                b_ = self._ll(self.bufs[hx][:, snd if snd >= 0 else -1 - snd, :, :W])
                 acc += self._prod(a, b_)
             out[:, i, :, c0:c0 + W] = self._ll(acc)
 
@@ -301,6 +307,11 @@ class Interp:
             res.update({'e_loc': e_kin + v_loc + v_el + e_nuc, 'grad': grad.copy(),
                         'stats': np.stack([v_el, e_kin, v_loc, np.zeros(self.B), lap, qf2])})
         return res
+
+    def op_12(self, op):  # CONST rows
+        dst, off = op.i[:2]
+        rows, width = self.p.bufs[dst]
+        self.bufs[dst][:, :, 0, :] = self.w[off:off + rows * width].reshape(rows, width)[None]
 
     def op_11(self, op):  # ATTENTION (forward-Laplacian softmax attention, appendix C)
         qb, kb, vb, dst, H, hd = op.i[:6]
