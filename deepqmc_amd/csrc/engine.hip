@@ -154,6 +154,7 @@ struct Engine : dqmc_ctx {
   const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
+  bool fused2_ma1 = false;       // every unit of the plan has ma == 1
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
   dqmc::FDesc* d_descs = nullptr;
   int32_t* d_wave_begin = nullptr;
@@ -679,7 +680,7 @@ struct Engine : dqmc_ctx {
         fused_sched_budget = (size_t)kb * 1024;
         fused_schedule();
         std::vector<dqmc::FusedBuf> fbt;
-        fit = fused_layout(4, fbt) + 16 + dqmc::fused2_scratch_bytes(4, N, sys.n_det, (int)sizeof(real)) <= fused2_lds_quarter;
+        fit = fused_layout(4, fbt) + 16 + dqmc::fused2_scratch_bytes(4, N, sys.n_det, (int)sizeof(real), (int)n_itable) <= fused2_lds_quarter;
       }
       if (!fit) { fused_sched_mode = 1; fused_schedule(); fused_sched_mode = 3; }   // too big for that: full levels
     } else {
@@ -705,7 +706,7 @@ struct Engine : dqmc_ctx {
     if (fused_n_ops == 0) return DQMC_OK;
     const int cand[] = {16, 8, 4, 2, 1};
     std::vector<dqmc::FusedBuf> fb;
-    auto with_scratch = [&](size_t act, int WT) { return (act + 15) / 16 * 16 + (size_t)dqmc::fused2_scratch_bytes(WT, N, sys.n_det, (int)sizeof(real)); };
+    auto with_scratch = [&](size_t act, int WT) { return (act + 15) / 16 * 16 + (size_t)dqmc::fused2_scratch_bytes(WT, N, sys.n_det, (int)sizeof(real), (int)n_itable); };
     if (fused_wt_req <= 0 && with_scratch(fused_layout(4, fb), 4) <= fused2_lds_quarter) {
       // 4 walkers per tile and 4 tiles per CU: for the batch sizes of the north star (4096 walkers = 1024 tiles =
       // 256 CUs x 4) the whole batch is ONE round of co-resident workgroups (measured fastest)
@@ -792,17 +793,28 @@ struct Engine : dqmc_ctx {
       }
       if (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) flush_level();
     }
-    plan_lists = lists;
+    fused2_ma1 = true;
+    for (auto& l : lists) for (auto& dd : l) if (dd.kind == 1 && dd.ma != 1) fused2_ma1 = false;
     std::vector<dqmc::FDesc> flat;
-    int32_t begin[4];
+    int32_t begin[8];
+    // (plan_lists is recorded after the chaining below)
     for (int w = 0; w < n_waves; ++w) {
       begin[w] = (int32_t)flat.size();
+      begin[4 + w] = -1;
+      int last_unit = -1;                          // chain the units of the list: each prefetches the next one's first weights
+      for (size_t k = 0; k < lists[w].size(); ++k) {
+        if (lists[w][k].kind != 1) continue;
+        if (last_unit < 0) begin[4 + w] = begin[w] + (int32_t)k;
+        else lists[w][last_unit].next_unit = (int32_t)k - last_unit;
+        last_unit = (int)k;
+      }
       flat.insert(flat.end(), lists[w].begin(), lists[w].end());
       dqmc::FDesc e{}; e.kind = 0; flat.push_back(e);
     }
+    plan_lists = lists;
     if (d_descs) { HIP_TRY(hipFree(d_descs)); d_descs = nullptr; }
     HIP_TRY(hipMalloc((void**)&d_descs, sizeof(dqmc::FDesc) * flat.size()));
-    if (!d_wave_begin) HIP_TRY(hipMalloc((void**)&d_wave_begin, sizeof(int32_t) * 4));
+    if (!d_wave_begin) HIP_TRY(hipMalloc((void**)&d_wave_begin, sizeof(int32_t) * 8));
     if (!d_fbufs2) HIP_TRY(hipMalloc((void**)&d_fbufs2, sizeof(dqmc::FusedBuf) * bufs.size()));
     HIP_TRY(hipMemcpy(d_descs, flat.data(), sizeof(dqmc::FDesc) * flat.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_wave_begin, begin, sizeof(begin), hipMemcpyHostToDevice));
@@ -820,7 +832,7 @@ struct Engine : dqmc_ctx {
     const dqmc::FusedBuf& bfb = fbufs2_h[ops[orb].i[0]];
     const size_t need = (size_t)fused2_WT * sys.n_det * N * N;
     const size_t bf_len = (size_t)fused2_WT * bfb.rows * bfb.stride;
-    const size_t act_end = (fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real))) / sizeof(real);
+    const size_t act_end = (fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real), (int)n_itable)) / sizeof(real);
     if (bfb.is_global) return -1;
     if ((size_t)bfb.off >= need) return 0;
     if ((size_t)bfb.off + bf_len + need <= act_end) return (int)((size_t)bfb.off + bf_len);
@@ -835,7 +847,10 @@ struct Engine : dqmc_ctx {
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
     a.B = B; a.WT = fused2_WT; a.wt_shift = fused2_shift; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det;
     a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
-    a.scratch_off = (int)((fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real))) / sizeof(real));
+    a.scratch_off = (int)((fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real), (int)n_itable)) / sizeof(real));
+    a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));
+    a.n_it = (int)n_itable;
+    a.ma1 = fused2_ma1 ? 1 : 0;
     if (mc) a.mc = *mc;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)

@@ -29,6 +29,11 @@
 
 namespace dqmc {
 
+// four consecutive reals as a register vector (the prefetched B quads travel between units in these)
+template <typename real> struct RVec4;
+template <> struct RVec4<float> { typedef f32x4 type; };
+template <> struct RVec4<double> { typedef f64x4 type; };
+
 typedef const DQMC_UNIFORM FDesc* DescPtr;
 typedef const DQMC_UNIFORM FusedBuf* BufPtr;
 typedef const DQMC_UNIFORM ::dqmc_op* OpPtr;
@@ -40,8 +45,12 @@ template <typename real> __device__ __forceinline__ real act2_value(int act, rea
 }
 
 // One unit: MA row blocks x 2 column blocks of y = act(concat(pieces) W + b) (+ residual) on the tile.
+// `pre`: the first quad of B fragments of THIS unit, requested by the previous unit of the wave before its epilogue
+// (so the L2 round trip overlaps that epilogue, the LDS stores and the level barrier); on return it holds the first
+// quad of the wave's next unit (FDesc::next_unit).
 template <typename real, int MA>
-__device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d) {
+__device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d, typename RVec4<real>::type& pre0,
+                                            typename RVec4<real>::type& pre1) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   typedef typename Mfma<real>::acc_t acc_t;
@@ -83,8 +92,14 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
     const Vec4<real>* wq0 = wbase + (long)q0 * qstride;
     const Vec4<real>* wq1 = wq0 + cb1;
     Vec4<real> ring[D][NRW];
+    if (p == 0) {
 #pragma unroll
-    for (int dd = 0; dd < D; ++dd) {
+      for (int kk = 0; kk < 4; ++kk) { ring[0][0].v[kk] = pre0[kk]; ring[0][1].v[kk] = pre1[kk]; }
+    } else {
+      ring[0][0] = wq0[0]; ring[0][1] = wq1[0];
+    }
+#pragma unroll
+    for (int dd = 1; dd < D; ++dd) {
       if (dd < NQ) {                               // wave-uniform; short layers load only what they use
         ring[dd][0] = wq0[(long)dd * qstride];
         ring[dd][1] = wq1[(long)dd * qstride];
@@ -130,6 +145,15 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
       }
     }
     q0 += NQ;
+  }
+  {
+    const int nu = d->next_unit;                   // request the next unit's first B quad now
+    if (nu > 0) {
+      const DescPtr nd = d + nu;
+      const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + nd->w_off + lane;
+      pre0 = nb[0];
+      pre1 = nb[nd->w_cb1];
+    }
   }
   // ---- epilogue: bias + activation + residual, store to LDS (or HBM for buffers later kernels read) ----
   const int flags = d->flags, act = flags & 3;
@@ -233,6 +257,72 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
   }
 }
 
+// Slater-matrix entries A[(wl, k)][el][mu] = envelope(el; k, mu) * backflow(el; k, mu) for the tile (the arithmetic of
+// k_orbitals, value lane).  One thread per (electron, orbital k*N + mu): the envelope weights pi / zeta of that pair are
+// read ONCE (they do not depend on the walker) and the exponentials of the WT walkers are independent instructions --
+// the earlier one-thread-per-(walker, electron, orbital) loop spent its time in dependent table loads.
+// store(wl, kd, el, mu, value) places the entry (LDS matrices of the sub-step tail, or the HBM orbital buffer).
+template <typename real, typename Store>
+__device__ __forceinline__ void fused2_slater_entries(const Fused2Args<real>& a, OpPtr op, int nw, const real* rs, Store store) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  const real* smem = reinterpret_cast<const real*>(smem_raw);
+  const int tid = threadIdx.x, nthr = blockDim.x, WT = a.WT, N = a.li.N, K = a.K, n_up = a.n_up, n_nuc = a.n_nuc, KN = K * N;
+  const BufPtr bf = (BufPtr)a.fbufs + op->i[0];
+  const int bo = bf->off, bs = bf->stride;
+  const int n_env = op->i[6] > 0 ? op->i[6] : 1;
+  const int o_pu = op->i[2], o_pd = op->i[3], o_zu = op->i[4], o_zd = op->i[5];
+  constexpr int WCH = 4;
+  for (int q = tid; q < N * KN; q += nthr) {
+    const int el = q / KN, kmu = q - el * KN;
+    const int kd = kmu / N, mu = kmu - kd * N;
+    const real* pi = a.w + (el < n_up ? o_pu : o_pd) + kmu * n_nuc * n_env;
+    const real* ze = a.w + (el < n_up ? o_zu : o_zd) + kmu * n_nuc * n_env;
+    if (sizeof(real) == 4) {      // float32 build: exponentials on the f32 unit (as k_orbitals, T = 1)
+      for (int w0 = 0; w0 < nw; w0 += WCH) {       // WCH walkers at a time (their exponentials are independent)
+        float acc[WCH], px[WCH], py[WCH], pz[WCH];
+#pragma unroll
+        for (int j = 0; j < WCH; ++j) {
+          const int wl = (w0 + j < WT) ? w0 + j : w0;
+          const real* rp = rs + (wl * N + el) * 3;
+          px[j] = (float)rp[0]; py[j] = (float)rp[1]; pz[j] = (float)rp[2];
+          acc[j] = 0.f;
+        }
+        for (int n = 0; n < n_nuc; ++n) {
+          const float Rx = (float)a.R[n * 3], Ry = (float)a.R[n * 3 + 1], Rz = (float)a.R[n * 3 + 2];
+          float rho[WCH];
+#pragma unroll
+          for (int j = 0; j < WCH; ++j) {
+            const float dx = px[j] - Rx, dy = py[j] - Ry, dz = pz[j] - Rz;
+            float d2 = (float)a.eps;
+            d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
+            rho[j] = sqrtf(d2);
+          }
+          for (int ev = 0; ev < n_env; ++ev) {
+            const float p = (float)pi[n * n_env + ev], z = fabsf((float)ze[n * n_env + ev]);
+#pragma unroll
+            for (int j = 0; j < WCH; ++j) acc[j] += p * expf(-z * rho[j]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < WCH; ++j)
+          if (w0 + j < nw) store(w0 + j, kd, el, mu, (real)(acc[j] * (float)smem[bo + (el * WT + w0 + j) * bs + kmu]));
+      }
+    } else {
+      for (int wl = 0; wl < nw; ++wl) {
+        const real* rp = rs + (wl * N + el) * 3;
+        double e0 = 0;
+        for (int n = 0; n < n_nuc; ++n) {
+          double d2 = a.eps;
+          for (int c = 0; c < 3; ++c) { const double dx = (double)rp[c] - (double)a.R[n * 3 + c]; d2 += dx * dx; }
+          const double rho = sqrt(d2);
+          for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
+        }
+        store(wl, kd, el, mu, (real)(e0 * (double)smem[bo + (el * WT + wl) * bs + kmu]));
+      }
+    }
+  }
+}
+
 // Structured ops (pair features, spin means, convolutions, sums, envelopes): all threads of the
 // workgroup, element-parallel.  Tile element (wl, row, col) of buffer b: off + (row*WT + wl)*stride + col.
 template <typename real>
@@ -246,6 +336,9 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
   const BufPtr fbs = (BufPtr)a.fbufs;
   const int kind = op->kind;
   LaneInfo li = a.li;   // T = TP = 1
+  // the int table (edge pairs, per-receiver sender lists) was staged into LDS by the prologue: its reads sit on the
+  // dependent path of every structured op (row index -> activation address)
+  const int32_t* itab = reinterpret_cast<const int32_t*>(smem_raw + a.it_off);
   // Elements are enumerated walker-fastest (e = rest*WT + wl) so neighbouring threads touch neighbouring
   // LDS rows of the same column; walkers beyond the batch (wl >= nw) are skipped.
   switch (kind) {
@@ -272,7 +365,7 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
     case DQMC_OP_FEAT_EE: {
       const BufPtr eb = fbs + op->i[0];
       const int eo = eb->off, es = eb->stride, n_rows = op->i[2], lr = op->i[3];
-      const int32_t* pairs = a.itable + op->i[1];
+      const int32_t* pairs = itab + op->i[1];
       for (int e = tid; e < n_rows * WT; e += nthr) {
         const int wl = e & wtm1, kr = e >> sh;
         if (wl >= nw) continue;
@@ -307,7 +400,7 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
       const BufPtr hx = conv ? fbs + op->i[1] : we;
       const int wo = we->off, ws_ = we->stride, ho = hx->off, hs = hx->stride, oo = out->off, os = out->stride;
       const real scale = conv ? (real)1 : (real)(1.0 / (double)(op->i[1] > 0 ? op->i[1] : 1));
-      const int32_t* tab = a.itable + op->i[4];
+      const int32_t* tab = itab + op->i[4];
       const int S = op->i[5], W = op->i[6], col0 = op->i[3];
       for (int e = tid; e < N * W * WT; e += nthr) {
         const int wl = e & wtm1, q = e >> sh;
@@ -337,43 +430,12 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
     }
     case DQMC_OP_ORBITALS: {
       if (a.mc.enabled) break;                     // sub-step mode: the tail builds the Slater matrices itself
-      const BufPtr bf = fbs + op->i[0];
       const BufPtr orb = fbs + op->i[1];
-      const int bo = bf->off, bs = bf->stride, ow = orb->width;
-      real* orb_g = reinterpret_cast<real*>(a.ws + orb->goff) + (long)blockIdx.x * WT * orb->rows * ow;
-      const int KN = K * N;
-      const int n_env = op->i[6] > 0 ? op->i[6] : 1;          // envelopes per nucleus (kernels_head.hip: k_orbitals)
-      const int o_pu = op->i[2], o_pd = op->i[3], o_zu = op->i[4], o_zd = op->i[5];
-      for (int e = tid; e < N * KN * WT; e += nthr) {
-        const int wl = e & wtm1, q = e >> sh;
-        const int el = q / KN, kmu = q - el * KN;
-        if (wl >= nw) continue;
-        const int kd = kmu / N, mu = kmu - kd * N;
-        const real* pi = a.w + (el < n_up ? o_pu : o_pd) + kmu * n_nuc * n_env;
-        const real* ze = a.w + (el < n_up ? o_zu : o_zd) + kmu * n_nuc * n_env;
-        const real b0 = smem[bo + (el * WT + wl) * bs + kmu];
-        real res;
-        if (sizeof(real) == 4) {        // float32 build: exponentials on the f32 unit (as k_orbitals, T = 1)
-          float acc = 0.f;
-          for (int n = 0; n < n_nuc; ++n) {
-            float d2 = (float)a.eps;
-            for (int c = 0; c < 3; ++c) { const float dx = (float)r[(wl * N + el) * 3 + c] - (float)a.R[n * 3 + c]; d2 += dx * dx; }
-            const float rho = sqrtf(d2);
-            for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[n * n_env + ev] * expf(-fabsf((float)ze[n * n_env + ev]) * rho);
-          }
-          res = (real)(acc * (float)b0);
-        } else {
-          double e0 = 0;
-          for (int n = 0; n < n_nuc; ++n) {
-            double d2 = a.eps;
-            for (int c = 0; c < 3; ++c) { const double dx = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += dx * dx; }
-            const double rho = sqrt(d2);
-            for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
-          }
-          res = (real)(e0 * (double)b0);
-        }
-        orb_g[(wl * K + kd) * ow + el * N + mu] = res;
-      }
+      const int ow = orb->width, orows = orb->rows;
+      real* orb_g = reinterpret_cast<real*>(a.ws + orb->goff) + (long)blockIdx.x * WT * orows * ow;
+      fused2_slater_entries<real>(a, op, nw, r, [&](int wl, int kd, int el, int mu, real v) {
+        orb_g[(wl * K + kd) * ow + el * N + mu] = v;
+      });
       break;
     }
     default:
@@ -436,7 +498,7 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int tid = threadIdx.x, nthr = blockDim.x, WT = a.WT, N = a.li.N, K = a.K, wtm1 = WT - 1, sh = a.wt_shift;
-  const int n_up = a.n_up, n_nuc = a.n_nuc, NN = N * N, KN = K * N;
+  const int n_up = a.n_up, NN = N * N;
   real* rs = smem + a.scratch_off;
   real* jas = rs + WT * N * 3;
   char* after = smem_raw + (size_t)a.scratch_off * sizeof(real) + ((WT * (N * 3 + 4) * (int)sizeof(real) + 15) / 16 * 16);
@@ -454,41 +516,10 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
     age_b = a.mc.age[b];
   }
   const OpPtr op = (OpPtr)a.ops + a.mc.orb_op;
-  const BufPtr bf = (BufPtr)a.fbufs + op->i[0];
-  const int bo = bf->off, bs = bf->stride;
-  const int n_env = op->i[6] > 0 ? op->i[6] : 1;
-  const int o_pu = op->i[2], o_pd = op->i[3], o_zu = op->i[4], o_zd = op->i[5];
   // Slater matrix entries = envelope * backflow, exactly as the ORBITALS op computes them
-  for (int e = tid; e < N * KN * WT; e += nthr) {
-    const int wl = e & wtm1, q = e >> sh;
-    const int el = q / KN, kmu = q - el * KN;
-    if (wl >= nw) continue;
-    const int kd = kmu / N, mu = kmu - kd * N;
-    const real* pi = a.w + (el < n_up ? o_pu : o_pd) + kmu * n_nuc * n_env;
-    const real* ze = a.w + (el < n_up ? o_zu : o_zd) + kmu * n_nuc * n_env;
-    const real b0 = smem[bo + (el * WT + wl) * bs + kmu];
-    real res;
-    if (sizeof(real) == 4) {
-      float acc = 0.f;
-      for (int n = 0; n < n_nuc; ++n) {
-        float d2 = (float)a.eps;
-        for (int c = 0; c < 3; ++c) { const float dx = (float)rs[(wl * N + el) * 3 + c] - (float)a.R[n * 3 + c]; d2 += dx * dx; }
-        const float rho = sqrtf(d2);
-        for (int ev = 0; ev < n_env; ++ev) acc += (float)pi[n * n_env + ev] * expf(-fabsf((float)ze[n * n_env + ev]) * rho);
-      }
-      res = (real)(acc * (float)b0);
-    } else {
-      double e0 = 0;
-      for (int n = 0; n < n_nuc; ++n) {
-        double d2 = a.eps;
-        for (int c = 0; c < 3; ++c) { const double dx = (double)rs[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c]; d2 += dx * dx; }
-        const double rho = sqrt(d2);
-        for (int ev = 0; ev < n_env; ++ev) e0 += (double)pi[n * n_env + ev] * exp(-fabs((double)ze[n * n_env + ev]) * rho);
-      }
-      res = (real)(e0 * (double)b0);
-    }
-    mats[(wl * K + kd) * NN + el * N + mu] = res;
-  }
+  fused2_slater_entries<real>(a, op, nw, rs, [&](int wl, int kd, int el, int mu, real v) {
+    mats[(wl * K + kd) * NN + el * N + mu] = v;
+  });
   __syncthreads();
   for (int e = tid; e < K * WT; e += nthr) {
     const int wl = e & wtm1, kd = e >> sh;
@@ -572,7 +603,10 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   }
 }
 
-template <typename real>
+// MA1: every unit of the plan is one row block high (tiles of <= 16 MFMA rows per layer segment, e.g. 4-electron
+// systems with 4-walker tiles): the taller unit bodies are not instantiated, which takes the kernel from 128
+// registers with scratch spills to < 100 without any.
+template <typename real, bool MA1>
 __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
@@ -588,6 +622,10 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     real* rs = smem + a.scratch_off;
     const int n = nw * a.li.N * 3;
     const long g0 = (long)w0 * a.li.N * 3;
+    {
+      int32_t* itab = reinterpret_cast<int32_t*>(smem_raw + a.it_off);
+      for (int e = threadIdx.x; e < a.n_it; e += blockDim.x) itab[e] = a.itable[e];
+    }
     if (a.mc.enabled) {
       // step size of this sub-step from the previous one's acceptance (the arithmetic of k_tau_update)
       real tau;
@@ -614,6 +652,16 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     __syncthreads();
   }
   DescPtr d = (DescPtr)a.descs + ((const DQMC_UNIFORM int32_t*)a.wave_begin)[wave];
+  typename RVec4<real>::type pre0 = {0, 0, 0, 0}, pre1 = {0, 0, 0, 0};
+  {
+    const int fu = ((const DQMC_UNIFORM int32_t*)a.wave_begin)[4 + wave];      // first unit of this wave's list, or -1
+    if (fu >= 0) {
+      const DescPtr nd = (DescPtr)a.descs + fu;
+      const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + nd->w_off + (threadIdx.x & 63);
+      pre0 = nb[0];
+      pre1 = nb[nd->w_cb1];
+    }
+  }
   const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
   int n_d = 0;
   if (stamp) a.prof[wave * 256] = clock64();
@@ -623,11 +671,15 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     if (kind == 2) {
       __syncthreads();
     } else if (kind == 1) {
-      const int ma = d->ma;
-      if (ma == 1) fused2_unit<real, 1>(a, d);
-      else if (ma == 2) fused2_unit<real, 2>(a, d);
-      else if (ma == 3) fused2_unit<real, 3>(a, d);
-      else fused2_unit<real, 4>(a, d);
+      if (MA1) {
+        fused2_unit<real, 1>(a, d, pre0, pre1);
+      } else {
+        const int ma = d->ma;
+        if (ma == 1) fused2_unit<real, 1>(a, d, pre0, pre1);
+        else if (ma == 2) fused2_unit<real, 2>(a, d, pre0, pre1);
+        else if (ma == 3) fused2_unit<real, 3>(a, d, pre0, pre1);
+        else fused2_unit<real, 4>(a, d, pre0, pre1);
+      }
     } else {
       fused2_generic<real>(a, (OpPtr)a.ops + d->op, nw);
     }
@@ -637,20 +689,25 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
 }
 
 // OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.
-template <typename real, int OCC>
-__global__ void __launch_bounds__(256, OCC) k_fused2_value(const Fused2Args<real> a) { fused2_body<real>(a); }
+template <typename real, int OCC, bool MA1>
+__global__ void __launch_bounds__(256, OCC) k_fused2_value(const Fused2Args<real> a) { fused2_body<real, MA1>(a); }
 
-template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ) {
+template <typename real, bool MA1> static void launch_fused2_ma(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ) {
   const dim3 g((unsigned)n_blocks), b(256);
   if (sizeof(real) == 8) occ = 2;     // the float64 (parity) build needs the full register file
-  if (occ >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 4>), g, b, lds_bytes, st, a);
-  else if (occ == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 3>), g, b, lds_bytes, st, a);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 2>), g, b, lds_bytes, st, a);
+  if (occ >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 4, MA1>), g, b, lds_bytes, st, a);
+  else if (occ == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 3, MA1>), g, b, lds_bytes, st, a);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fused2_value<real, 2, MA1>), g, b, lds_bytes, st, a);
+}
+template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ) {
+  if (a.ma1) launch_fused2_ma<real, true>(st, a, n_blocks, lds_bytes, occ);
+  else launch_fused2_ma<real, false>(st, a, n_blocks, lds_bytes, occ);
 }
 template <typename real> int fused2_set_lds_limit(size_t lds_bytes) {
-  int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  int rc = 0;
+#define DQMC_SET(OCC, M) rc |= (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused2_value<real, OCC, M>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  DQMC_SET(2, true) DQMC_SET(3, true) DQMC_SET(4, true) DQMC_SET(2, false) DQMC_SET(3, false) DQMC_SET(4, false)
+#undef DQMC_SET
   return rc;
 }
 

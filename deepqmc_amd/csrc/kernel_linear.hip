@@ -334,8 +334,22 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
       else launch_nr<real, 1, 0>(st, a);
       break;
     }
-    case 8: launch_nr<real, 4, -1>(st, a); break;
-    case 16: launch_nr<real, 4, 4>(st, a); break;
+    // Laplacian-mode batches of a few hundred walkers (the float64 refinement pass, small evaluation batches) would
+    // occupy a fraction of the 256 CUs with the 16-groups-per-workgroup tiles: shrink the tile until >= 512 workgroups
+    case 8: {
+      const long wg4 = ((long)a.B * a.nrows + 31) / 32 * ((a.ldw + 63) / 64);
+      if (wg4 >= 512) launch_nr<real, 4, -1>(st, a);
+      else if (wg4 >= 256) launch_nr<real, 2, -1>(st, a);
+      else launch_nr<real, 1, -1>(st, a);
+      break;
+    }
+    case 16: {
+      const long wg4 = ((long)a.B * a.nrows + 15) / 16 * ((a.ldw + 63) / 64);
+      if (wg4 >= 512) launch_nr<real, 4, 4>(st, a);
+      else if (wg4 >= 256) launch_nr<real, 2, 2>(st, a);
+      else launch_nr<real, 1, 1>(st, a);
+      break;
+    }
     case 32: launch_nr<real, 4, 2>(st, a); break;
     case 48: launch_nr<real, 3, 1>(st, a); break;
     case 64: launch_nr<real, 4, 1>(st, a); break;

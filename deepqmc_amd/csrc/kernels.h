@@ -89,7 +89,8 @@ struct FDesc {
   int32_t res_stride;
   int32_t flags;        // bits 0-1 activation, bit 2 scale by 1/sqrt(2), bit 3 destination in HBM, bit 4 no partial row/column block
   int32_t g_r0, g_col0; // HBM destination: first row / column
-  int32_t pad[4];
+  int32_t next_unit;    // distance (in descriptors) to the next kind-1 descriptor of this wave's list, 0 = none
+  int32_t pad[3];
 };
 static_assert(sizeof(FDesc) == 160, "FDesc is 40 dwords");
 // Metropolis sub-step folded into the fused kernel (N <= 4): propose r' = r + tau xi in the prologue, the K
@@ -122,7 +123,7 @@ struct FusedMc {
 };
 template <typename real> struct Fused2Args {
   const FDesc* descs;       // device: the four wave lists, concatenated
-  const int32_t* wave_begin; // device int[4]: first descriptor of each wave
+  const int32_t* wave_begin; // device int[8]: first descriptor of each wave, then the first kind-1 descriptor of each wave (-1: none)
   const ::dqmc_op* ops;     // device: the scheduled ops (structured ops read their fields from here)
   const FusedBuf* fbufs;    // device: LDS offset / stride (tile layout [row][WT]) or HBM offset per buffer
   const real* w;
@@ -133,14 +134,20 @@ template <typename real> struct Fused2Args {
   const real* R;
   int B, WT, wt_shift, n_up, n_nuc, K;
   int scratch_off;          // LDS offset (in reals) of the per-tile scratch: positions, Jastrow, log|det|, det signs
+  int it_off, n_it;         // LDS byte offset and length of the staged int table
+  int ma1;                  // every unit is one row block high: launch the specialised kernel
   FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
   LaneInfo li;
   double eps;
 };
-// bytes of that scratch area: r tile [WT][N][3], Jastrow [WT][4], log|det| double[WT][K], sign int[WT][K], CI shift double[WT]
-__host__ __device__ inline int fused2_scratch_bytes(int WT, int N, int K, int real_size) {
+// bytes of that scratch area: r tile [WT][N][3], Jastrow [WT][4], log|det| double[WT][K], sign int[WT][K], CI shift double[WT],
+// then the staged int table (n_it ints, 16-byte aligned)
+__host__ __device__ inline int fused2_scratch_core(int WT, int N, int K, int real_size) {
   return ((WT * (N * 3 + 4) * real_size + 15) / 16 * 16) + WT * K * 12 + WT * 8;
+}
+__host__ __device__ inline int fused2_scratch_bytes(int WT, int N, int K, int real_size, int n_it = 0) {
+  return (fused2_scratch_core(WT, N, K, real_size) + 15) / 16 * 16 + (4 * n_it + 15) / 16 * 16;
 }
 template <typename real> void launch_fused2_value(hipStream_t st, const Fused2Args<real>& a, int n_blocks, size_t lds_bytes, int occ);
 template <typename real> int fused2_set_lds_limit(size_t lds_bytes);

@@ -19,7 +19,7 @@ for cfg in "--molecule N2 --ansatz ferminet --n-sub 10 --steps 3 --warmup 1" \
 done
 cd /tmp && export TMPDIR=/tmp
 rm -rf "$ROOT/gpurun_out/prof"
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o r02 -- python "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$ROOT/gpurun_out/prof.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof" -o r02 -- python "$ROOT/bench.py" --steps 3 --warmup 1 --repeats 1 --no-cpu-baseline > "$ROOT/gpurun_out/prof.log" 2>&1
 echo "prof rc=$?" >> "$ROOT/gpurun_out/prof.log"
 cd "$ROOT"
 tail -3 gpurun_out/smoke.log; tail -5 gpurun_out/pytest_gpu.log; tail -2 gpurun_out/bench.log | cut -c1-600; wc -l gpurun_out/other_configs.log; tail -5 gpurun_out/traffic.log

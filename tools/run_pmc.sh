@@ -10,7 +10,7 @@ P3="SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_FLAT SQ_
 k=1
 for P in "$P1" "$P2" "$P3"; do
   rm -rf "$ROOT/gpurun_out/pmc$k"
-  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$ROOT/gpurun_out/pmc$k" -o p$k -- python "$ROOT/bench.py" --steps 1 --warmup 1 --no-cpu-baseline "$@" > "$ROOT/gpurun_out/pmc$k.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d "$ROOT/gpurun_out/pmc$k" -o p$k -- python "$ROOT/bench.py" --steps 1 --warmup 1 --repeats 1 --no-cpu-baseline "$@" > "$ROOT/gpurun_out/pmc$k.log" 2>&1
   k=$((k+1))
 done
 cd "$ROOT"
