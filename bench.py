@@ -192,6 +192,11 @@ def main():
     ap.add_argument('--fused-occ', type=int, default=0, help='register budget of the fused kernel: workgroups per CU (2..4)')
     ap.add_argument('--fused-lds-kb', type=int, default=0, help='LDS budget (KiB) for the automatic tile choice')
     ap.add_argument('--fused-sched', type=int, default=-1, help='0: keep program order; 1 (library default): reorder ops into full dependency levels (more LDS)')
+    ap.add_argument('--states', type=int, default=1, help='electronic states (BASELINE configs[4]: 3): one parameter set and one '
+                    'Markov-chain ensemble per state, local energy of every state, the S x S psi-ratio matrix (S^2 value-only '
+                    'psi evaluations per walker, loss/overlap.py:40-99) and the overlap penalty with its all-reduce')
+    ap.add_argument('--refine', type=int, default=-1, help='float64 refinement of ill-conditioned walkers: 0 off, 1 flagged walkers '
+                    '(library default), 2 whole E_loc pass in float64')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state time the timed blocks must cover')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
@@ -290,6 +295,19 @@ def main():
     sampler = DecorrSampler(hamil, wf, length=args.n_sub, sample_initializer=shard_initializer)
     state = sampler.init(1000, params, B)
     loc_ene = hamil.local_energy(wf)
+    if args.refine >= 0:
+        eng.set_option('refine', args.refine)
+    S = args.states
+    if S > 1:
+        from deepqmc_amd import loss
+        from deepqmc_amd.sampling import MultiElectronicStateSampler
+        params_s = [params] + [wf.init(s, perturb_envelopes=0.05) for s in range(1, S)]
+        ms_sampler = MultiElectronicStateSampler(sampler, S)
+        ms_state = ms_sampler.init(1000, params_s, B)
+        if args.refine >= 0:
+            for p_ in params_s:
+                wf.engine(p_).set_option('refine', args.refine)
+        ones = torch.ones(1, S, B, dtype=torch.float64, device=device)
     n_ranks_seen = len(parallel.all_gather_records(np.zeros(7), device if not args.emulated else 'cpu'))   # one real collective
     if world > 1:
         assert n_ranks_seen == torch.distributed.get_world_size() == world
@@ -300,7 +318,20 @@ def main():
             torch.distributed.barrier()
         sync()
 
+    def vmc_step_states(step, state):
+        """Multi-state step: sample every state, E_loc[1,S,B], psi ratios [1,S,S,B], overlap penalty (one all-reduce)."""
+        state, pc, _ = ms_sampler.sample(step * world + rank, state, params_s)
+        r = pc.r[None]
+        E, _ = loss.compute_local_energy(step, hamil, wf, params_s, r)
+        ratio = loss.compute_psi_ratio(wf, params_s, r)
+        pen, info = loss.compute_mean_overlap(ratio, ones)
+        stats = parallel.energy_stats(eng, E[0, 0].contiguous())
+        stats['overlap/penalty'] = float(pen)
+        return state, stats
+
     def vmc_step(step, state):
+        if S > 1:
+            return vmc_step_states(step, state)
         if args.n_sub > 0:
             state, pc, _ = sampler.sample(step * world + rank, state, params)
             r = state['r']
@@ -339,6 +370,9 @@ def main():
             return pipe['stats']
 
     step_fn = vmc_step_pipelined if args.overlap else vmc_step
+    if S > 1:
+        assert not args.overlap, '--overlap is a single-state arrangement'
+        state = ms_state
     stats = None
     for s in range(args.warmup):
         state, stats = step_fn(s, state)
@@ -374,12 +408,12 @@ def main():
     log(f'{len(blocks)} timed blocks done')
     elapsed = float(np.median(blocks))
     ms_per_step = 1e3 * elapsed / args.steps
-    value = B * world / (elapsed / args.steps)
+    value = S * B * world / (elapsed / args.steps)        # every state's walkers get a local energy per step
 
     eloc_only, roofline = None, None
     if not args.emulated:       # (the emulated test harness only exercises launch / shard / reduce)
         # ---- pure E_loc throughput (n_sub = 0), not the headline ----
-        r = state['r']
+        r = state['r'] if S == 1 else state[0]['r']
         for _ in range(2):
             loc_ene(0, params, r)
         sync()
@@ -428,9 +462,13 @@ def main():
             'ms_per_step_min': 1e3 * float(np.min(blocks)) / args.steps, 'ms_per_step_max': 1e3 * float(np.max(blocks)) / args.steps,
             'n_ranks_seen': n_ranks_seen,
             'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
-            'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, {B} walkers/GPU, '
-                                   f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats',
-                       'walkers_per_gpu': B, 'n_sub': args.n_sub, 'parallelism': f'walker-dp{world}'},
+            'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, '
+                                   + (f'{S} electronic states x ' if S > 1 else '') + f'{B} walkers/GPU, '
+                                   f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats'
+                                   + (f' + {S}x{S} psi-ratio matrix + overlap penalty' if S > 1 else ''),
+                       'walkers_per_gpu': B, 'n_sub': args.n_sub, 'states': S, 'parallelism': f'walker-dp{world}',
+                       'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers)', 0: 'off', 1: 'flagged walkers',
+                                  2: 'whole E_loc pass in float64'}[args.refine]},
             'eloc_only_evals_per_s': eloc_only,
             'energy': stats,
             'flops_per_eloc': (3 * hamil.n_elec + 2) * eng.program.flops_per_walker,

@@ -142,7 +142,8 @@ struct Engine : dqmc_ctx {
   long long* d_prof = nullptr;
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
-  size_t ws_budget = (size_t)64 << 30;   // activation workspace per evaluation chunk (option "ws_budget_mb")
+  size_t ws_budget = (size_t)32 << 30;   // activation workspace per evaluation chunk (option "ws_budget_mb"); several contexts
+                                         // (electronic states, float64 twins) share the 288 GB of one GPU
   bool lane_compact = true;
   int attention_mfma = 1;      // 1: where profitable (N > 16), 2: wherever supported, 0: never
   int slogdet_mfma = 1;        // 1: where profitable (N > 16), 2: from N > 8 on, 0: never
@@ -175,6 +176,7 @@ struct Engine : dqmc_ctx {
   int refine = 1;
   double refine_thresh = 16.0;
   bool flag_on = false;
+  int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
   std::vector<double> w64_h, ecp_loc_h;
   int ecp_loc_nt_h = 0;
   dqmc_ctx* twin = nullptr;
@@ -1133,7 +1135,11 @@ struct Engine : dqmc_ctx {
       }
       int rc = DQMC_OK;
       int32_t n = 0;
-      if (refine >= 2) {           // the whole forward-Laplacian pass in float64 (float32 stays the sampling dtype)
+      // mode 1 on a system where (nearly) every walker gets flagged (ill-conditioned Slater matrices, e.g. a random-init
+      // TransPsiformer): the float32 pass would be wasted, so the following 15 calls go to float64 directly, then re-probe
+      const bool direct = refine >= 2 || (refine == 1 && refine_all_calls > 0 && twin);
+      if (refine == 1 && refine_all_calls > 0) --refine_all_calls;
+      if (direct) {                // the whole forward-Laplacian pass in float64 (float32 stays the sampling dtype)
         std::vector<int32_t> iota((size_t)B + 1);
         iota[0] = B;
         for (int k = 0; k < B; ++k) iota[k + 1] = k;
@@ -1150,6 +1156,7 @@ struct Engine : dqmc_ctx {
         HIP_TRY(hipStreamSynchronize(st));
         if (n <= 0) return DQMC_OK;
         if (n > B) n = B;
+        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
       }
       if (!twin) {
         auto* t = new Engine<double>();
@@ -1167,7 +1174,7 @@ struct Engine : dqmc_ctx {
           return DQMC_OK;
         }
         if (rc) { delete t; return rc; }
-        t->ws_budget = ws_budget;
+        t->ws_budget = ws_budget / 2;
         twin = t;
       }
       const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;

@@ -112,17 +112,18 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     wf64 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     params = wf32.init(5, perturb_envelopes=0.1)
     e32, e64 = wf32.engine(params), wf64.engine(params)
-    B = 12
+    B = 6
     r = torch.as_tensor(synthetic_walkers(h, B, seed=11).astype(np.float32))
     e32.set_option('refine', 0)
     e_plain, st_plain, g_plain = e32.local_energy(r, return_grad=True)
     assert e32.last_refined() == 0
+    ratio = ((st_plain['hamil/lap'].abs() + st_plain['hamil/quantum_force']) / e_plain.abs().clamp(min=1.0)).numpy()
+    thr = max(1, int(np.median(ratio)))            # a threshold that splits these walkers
     e32.set_option('refine', 1)
-    e32.set_option('refine_thresh', 3)            # low threshold: several of the 12 walkers qualify
+    e32.set_option('refine_thresh', thr)
     e_ref, st_ref, g_ref = e32.local_energy(r, return_grad=True)
     n = e32.last_refined()
-    ratio = ((st_plain['hamil/lap'].abs() + st_plain['hamil/quantum_force']) / e_plain.abs().clamp(min=1.0)).numpy()
-    flagged = ratio > 3
+    flagged = ratio > thr
     assert n == int(flagged.sum()) and 0 < n < B
     R32 = torch.as_tensor(h.mol.coords, dtype=torch.float32).double()      # the twin sees the float32 context's geometry
     e_d, st_d, g_d = e64.local_energy(PhysicalConfiguration(R32, r.double(), None), return_grad=True)
@@ -137,6 +138,6 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     e32.set_params(p2)
     e2, _ = e32.local_energy(r)
     fresh = Engine(wf32.spec, h, p2, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-    fresh.set_option('refine_thresh', 3)
+    fresh.set_option('refine_thresh', thr)
     e3, _ = fresh.local_energy(r)
     np.testing.assert_array_equal(e2.numpy(), e3.numpy())

@@ -113,16 +113,16 @@ def test_emu_metropolis_bit_exact_and_stats(substep):
 def test_emu_rng_moments():
     """Philox4x32-10 + Box-Muller: mean/variance of the device noise (emulated)."""
     import ctypes
-    spec, mol, h, eng, r0, it = _setup(paulinet, 'LiH', torch.float32, 512)
+    spec, mol, h, eng, r0, it = _setup(paulinet, 'LiH', torch.float32, 96)
     r0 = r0.astype(np.float32)
     sign0, log0 = eng.wf_eval(torch.as_tensor(r0))
     st = {'r': torch.as_tensor(r0).clone(), 'log': log0.clone(), 'sign': sign0.clone(),
-          'age': torch.zeros(512, dtype=torch.int32), 'tau': torch.full((1,), 1.0, dtype=torch.float32)}
+          'age': torch.zeros(96, dtype=torch.int32), 'tau': torch.full((1,), 1.0, dtype=torch.float32)}
     # target_acceptance None keeps tau = 1, so r' - r of accepted walkers is the raw noise
     stats, acc = eng.mcmc_steps(st, 1, target_acceptance=None, seed=42, return_accept=True)
     moved = (st['r'].numpy() - r0)[acc.numpy()[0].astype(bool)].reshape(-1)
-    assert moved.size > 300
-    assert abs(moved.mean()) < 0.15 and 0.5 < moved.std() < 1.3
+    assert moved.size > 100
+    assert abs(moved.mean()) < 0.3 and 0.5 < moved.std() < 1.3
 
 
 def test_emu_value_slogdet_lu_n2():
