@@ -35,6 +35,7 @@ SIGNATURES = [
     ('dqmc_set_ecp', c_int, [c_void_p, c_int, POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     ('dqmc_ecp_rotation', c_int, [c_void_p, c_uint64, c_void_p]),
     ('dqmc_energy_stats', c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_double)]),
+    ('dqmc_energy_stats_allgather', c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_double)]),
     ('dqmc_merge_energy_stats', c_int, [POINTER(c_double), c_int, POINTER(c_double)]),
     ('dqmc_debug_read', c_int, [c_void_p, c_int, POINTER(c_double), c_size_t]),
     ('dqmc_debug_lanes', c_int, [c_void_p]),

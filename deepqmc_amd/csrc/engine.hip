@@ -3,6 +3,8 @@
 // kernel_linear.hip / kernels_graph.hip / kernels_head.hip / kernels_mcmc.hip.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -42,7 +44,7 @@ struct TimingRec {
 }  // namespace
 
 struct dqmc_ctx {
-  virtual ~dqmc_ctx() {}
+  virtual ~dqmc_ctx() { if (d_gather) (void)hipFree(d_gather); }
   virtual int set_weights(const double* w, size_t n) = 0;
   virtual int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) = 0;
   virtual int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
@@ -61,11 +63,14 @@ struct dqmc_ctx {
   virtual int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) = 0;
   virtual int ecp_rotation(uint64_t seed, const void* phi) = 0;
   virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
+  virtual int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   int device = 0;           // every entry point makes this the calling thread's current device
+  double* d_gather = nullptr;   // all-gathered energy records (dqmc_energy_stats_allgather)
+  size_t gather_cap = 0;
   // timing
   bool timing = false;
   std::map<std::string, TimingRec> trec;
@@ -1498,6 +1503,13 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
+  int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) override {
+    if (B < 1) return fail(DQMC_E_ARG, "B must be positive");
+    dqmc::launch_energy_stats<real>(st, (const real*)e, (const real*)w, B, d_acc + 8);
+    *rec_dev = d_acc + 8;
+    return DQMC_OK;
+  }
+
   int debug_read(int buf, double* out, size_t n) override {
     if (last_B == 0) return fail(DQMC_E_ARG, "no evaluation has run yet");
     HIP_TRY(hipStreamSynchronize(st));
@@ -1656,6 +1668,39 @@ int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, do
   if (!ctx || !e_loc || !out7_host) return fail(DQMC_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return ctx->energy_stats(e_loc, w, B, out7_host);
+}
+
+// The ONE collective of a VMC step inside the library: per-rank record -> ncclAllGather over the caller's RCCL
+// communicator on the context's stream -> Chan merge.  librccl is resolved at the first call (dlopen), so the
+// library itself carries no link-time dependency on it.
+int dqmc_energy_stats_allgather(dqmc_ctx* ctx, void* rccl_comm, int n_ranks, const void* e_loc, const void* w, int B,
+                                double* out5_host) {
+  if (!ctx || !rccl_comm || !e_loc || !out5_host || n_ranks < 1 || n_ranks > 4096) return fail(DQMC_E_ARG, "null / bad argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  typedef int (*allgather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+  static allgather_fn nccl_all_gather = nullptr;
+  if (!nccl_all_gather) {
+    void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(DQMC_E_UNSUPPORTED, std::string("librccl.so not found: ") + dlerror());
+    nccl_all_gather = (allgather_fn)dlsym(h, "ncclAllGather");
+    if (!nccl_all_gather) return fail(DQMC_E_UNSUPPORTED, "ncclAllGather not found in librccl.so");
+  }
+  double* rec = nullptr;
+  int rc = ctx->energy_stats_dev(e_loc, w, B, &rec);
+  if (rc) return rc;
+  if ((size_t)n_ranks * 7 > ctx->gather_cap) {
+    if (ctx->d_gather) HIP_TRY(hipFree(ctx->d_gather));
+    HIP_TRY(hipMalloc((void**)&ctx->d_gather, sizeof(double) * 7 * (size_t)n_ranks));
+    ctx->gather_cap = (size_t)n_ranks * 7;
+  }
+  const int nrc = nccl_all_gather(rec, ctx->d_gather, 7, /* ncclFloat64 */ 8, rccl_comm, ctx->st);
+  if (nrc != 0) return fail(DQMC_E_HIP, "ncclAllGather failed with code " + std::to_string(nrc));
+  std::vector<double> host((size_t)n_ranks * 7);
+  HIP_TRY(hipMemcpyAsync(host.data(), ctx->d_gather, sizeof(double) * host.size(), hipMemcpyDeviceToHost, ctx->st));
+  HIP_TRY(hipStreamSynchronize(ctx->st));
+  return dqmc_merge_energy_stats(host.data(), n_ranks, out5_host);
 }
 
 int dqmc_merge_energy_stats(const double* rec, int n_ranks, double* out5) {

@@ -35,3 +35,50 @@ def energy_stats(engine, e_loc, w=None):
     rec = engine.energy_record(e_loc, w)
     dev = e_loc.device if (dist.is_initialized() and dist.get_backend() == 'nccl') else 'cpu'
     return engine.merge_energy_records(all_gather_records(rec, dev))
+
+
+class RcclCommunicator:
+    """An RCCL communicator of the library's own (`ncclCommInitRank` through ctypes) for
+    `dqmc_energy_stats_allgather`: the unique id is created on rank 0 and distributed with one torch.distributed
+    broadcast (or used directly for a single rank).  One process per GPU, as everywhere in this package."""
+
+    def __init__(self, rank: int = 0, world: int = 1, device=None):
+        import ctypes
+        self._ct = ctypes
+        self.rccl = ctypes.CDLL('librccl.so')
+        self.rank, self.world = rank, world
+        uid = (ctypes.c_char * 128)()
+        if rank == 0:
+            rc = self.rccl.ncclGetUniqueId(ctypes.byref(uid))
+            if rc:
+                raise RuntimeError(f'ncclGetUniqueId failed: {rc}')
+        if world > 1:
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device)
+            dist.broadcast(t, 0)
+            uid = (ctypes.c_char * 128).from_buffer_copy(bytes(t.cpu().tolist()))
+
+        class _Uid(ctypes.Structure):
+            _fields_ = [('internal', ctypes.c_char * 128)]
+        u = _Uid()
+        ctypes.memmove(ctypes.byref(u), uid, 128)
+        self.comm = ctypes.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _Uid, ctypes.c_int]
+        rc = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), world, u, rank)
+        if rc:
+            raise RuntimeError(f'ncclCommInitRank failed: {rc}')
+
+    def close(self):
+        if self.comm:
+            self.rccl.ncclCommDestroy.argtypes = [self._ct.c_void_p]
+            self.rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def energy_stats_inlib(engine, e_loc, comm: RcclCommunicator, w=None):
+    """`energy_stats` with the collective inside the HIP library (one ncclAllGather on the context's stream)."""
+    import ctypes
+    out = (ctypes.c_double * 5)()
+    engine._check(engine.lib.dqmc_energy_stats_allgather(engine._ctx, comm.comm, comm.world, e_loc.data_ptr(),
+                                                         w.data_ptr() if w is not None else None, e_loc.shape[0], out))
+    return dict(zip(('local_energy/mean', 'local_energy/std', 'local_energy/min', 'local_energy/max',
+                     'local_energy/weighted_mean'), list(out)))

@@ -221,6 +221,12 @@ int dqmc_exchange_step(dqmc_ctx* ctx, void* r, void* logpsi, int32_t* sign, int3
  * max}.  w may be NULL (all ones).  Ranks all-gather the 56-byte records (RCCL) and
  * merge them with dqmc_merge_energy_stats. */
 int dqmc_energy_stats(dqmc_ctx* ctx, const void* e_loc, const void* w, int B, double* out7_host);
+/* The whole cross-GPU energy reduction in one call: this rank's record, ONE ncclAllGather of the 56-byte records over
+ * the caller's RCCL communicator (`rccl_comm` = an ncclComm_t of `n_ranks` ranks; the call is enqueued on the context's
+ * stream), Chan merge -> host double[5] as dqmc_merge_energy_stats.  Replaces the reference's five pmean / pmin / pmax
+ * calls (parallel.py:175-225).  librccl.so is loaded at the first call; DQMC_E_UNSUPPORTED if it is absent. */
+int dqmc_energy_stats_allgather(dqmc_ctx* ctx, void* rccl_comm, int n_ranks, const void* e_loc, const void* w, int B,
+                                double* out5_host);
 /* Chan merge of n_ranks records -> host double[5] = mean, std (population), min, max,
  * weighted mean.  Pure host arithmetic. */
 int dqmc_merge_energy_stats(const double* records_host, int n_ranks, double* out5_host);

@@ -167,3 +167,24 @@ def test_multi_geometry_batches_incl_nuclear_tokens():
                 np.testing.assert_allclose(E[k, s].cpu().numpy(), e_ref.cpu().numpy(), rtol=1e-11, atol=1e-11)
                 sg, lg = eng.wf_eval(pc.r[k, s])
                 np.testing.assert_allclose(state['elec'][m][s]['psi'].log.cpu().numpy(), lg.cpu().numpy(), rtol=1e-11, atol=1e-11)
+
+
+def test_inlib_rccl_allgather_single_rank():
+    """dqmc_energy_stats_allgather: the per-rank record, ONE ncclAllGather over an RCCL communicator and the Chan merge
+    inside the library (here a 1-rank communicator created with ncclCommInitRank; the multi-rank protocol is the same
+    call) against the host-side path and NumPy."""
+    from deepqmc_amd import parallel
+    h, wf = make(dtype=torch.float32)
+    eng = wf.engine(wf.init(0))
+    comm = parallel.RcclCommunicator(0, 1)
+    try:
+        e = torch.randn(4096, dtype=torch.float32, device=DEV) * 3 - 7
+        out = parallel.energy_stats_inlib(eng, e, comm)
+        ref = parallel.energy_stats(eng, e)
+        x = e.double().cpu().numpy()
+        for k in ref:
+            np.testing.assert_allclose(out[k], ref[k], rtol=1e-14)
+        np.testing.assert_allclose(out['local_energy/mean'], x.mean(), rtol=1e-12)
+        np.testing.assert_allclose(out['local_energy/std'], x.std(), rtol=1e-10)
+    finally:
+        comm.close()
