@@ -157,7 +157,7 @@ struct Engine : dqmc_ctx {
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
   size_t fused_sched_budget = 36 * 1024;   // bytes live per level the list scheduler (mode 3) aims for
-  const size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 workgroups per CU
+  size_t fused2_lds_quarter = 160 * 1024 / 4;   // LDS per workgroup for 4 (option "fused_wg_per_cu": 5) workgroups per CU
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
@@ -433,6 +433,11 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "fused_wg_per_cu") {
+      if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
+      fused2_lds_quarter = (size_t)160 * 1024 / value;
+      return build_fused_plan();
+    }
     if (s == "refine") { refine = value; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }

@@ -38,8 +38,24 @@ typedef const DQMC_UNIFORM FDesc* DescPtr;
 typedef const DQMC_UNIFORM FusedBuf* BufPtr;
 typedef const DQMC_UNIFORM ::dqmc_op* OpPtr;
 
+// tanh of the value path (Metropolis sub-steps, psi ratios): 1 - 2 / (1 + e^{2x}) on the hardware exp2 / rcp units --
+// 5 VALU instructions instead of the ~25 of r_tanh (whose polynomial branch keeps RELATIVE accuracy near 0 for the
+// derivative lanes of the Laplacian pass).  Absolute error <= ~1.5e-7 everywhere (saturates correctly: e -> inf gives 1,
+// e -> 0 gives -1); the epilogues were 30 % of this kernel's VALU instructions, its most contended pipe.
+template <typename real> __device__ __forceinline__ real fast_tanh(real x);
+template <> __device__ __forceinline__ float fast_tanh<float>(float x) {
+#if defined(__HIPCC__)
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);       // e^{2x}
+  return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
+#else
+  const float e = exp2f(x * 2.8853900817779268f);
+  return fmaf(-2.0f, 1.0f / (e + 1.0f), 1.0f);
+#endif
+}
+template <> __device__ __forceinline__ double fast_tanh<double>(double x) { return tanh(x); }
+
 template <typename real> __device__ __forceinline__ real act2_value(int act, real v) {
-  if (act == 1) return r_tanh<real>(v);
+  if (act == 1) return fast_tanh<real>(v);
   if (act == 2) return v / (1 + r_exp<real>(-v));
   return v;
 }
@@ -191,7 +207,7 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
 #pragma unroll
       for (int rgi = 0; rgi < 4; ++rgi)
 #pragma unroll
-        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = r_tanh<real>(ov[x][rgi][y]);
+        for (int y = 0; y < NRW; ++y) ov[x][rgi][y] = fast_tanh<real>(ov[x][rgi][y]);
   } else if (act == 2) {
 #pragma unroll
     for (int x = 0; x < MA; ++x)
@@ -349,11 +365,13 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
         const int wl = e & wtm1, q = e >> sh;
         const int el = q / n_nuc, n = q - el * n_nuc;
         if (wl >= nw) continue;
-        double dd[3], f[4];
-        for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c];
-        pair_feature_lane(dd, a.eps, el, -1, 0, li, lr != 0, f);
         const int row = xo + (el * WT + wl) * xs;
-        for (int c = 0; c < 4; ++c) smem[row + 4 * n + c] = (real)f[c];
+        {
+          double dd[3], f[4];
+          for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + el) * 3 + c] - (double)a.R[n * 3 + c];
+          pair_feature_lane(dd, a.eps, el, -1, 0, li, lr != 0, f);
+          for (int c = 0; c < 4; ++c) smem[row + 4 * n + c] = (real)f[c];
+        }
         if (n == 0) {
           int c = 4 * n_nuc;
           if (sp) smem[row + c++] = (real)(el < n_up ? 1.0 : -1.0);
@@ -370,11 +388,13 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
         const int wl = e & wtm1, kr = e >> sh;
         if (wl >= nw) continue;
         const int rc = pairs[2 * kr], sd = pairs[2 * kr + 1];
-        double dd[3], f[4];
-        for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + rc) * 3 + c] - (double)r[(wl * N + sd) * 3 + c];
-        pair_feature_lane(dd, a.eps, rc, sd, 0, li, lr != 0, f);
         const int row = eo + (kr * WT + wl) * es;
-        for (int c = 0; c < 4; ++c) smem[row + c] = (real)f[c];
+        {
+          double dd[3], f[4];
+          for (int c = 0; c < 3; ++c) dd[c] = (double)r[(wl * N + rc) * 3 + c] - (double)r[(wl * N + sd) * 3 + c];
+          pair_feature_lane(dd, a.eps, rc, sd, 0, li, lr != 0, f);
+          for (int c = 0; c < 4; ++c) smem[row + c] = (real)f[c];
+        }
       }
       break;
     }
@@ -402,9 +422,11 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
       const real scale = conv ? (real)1 : (real)(1.0 / (double)(op->i[1] > 0 ? op->i[1] : 1));
       const int32_t* tab = itab + op->i[4];
       const int S = op->i[5], W = op->i[6], col0 = op->i[3];
+      const bool w_pow2 = (W & (W - 1)) == 0;
+      const int w_sh = 31 - __builtin_clz((unsigned)(W > 0 ? W : 1));
       for (int e = tid; e < N * W * WT; e += nthr) {
         const int wl = e & wtm1, q = e >> sh;
-        const int el = q / W, c = q - el * W;
+        const int el = w_pow2 ? (q >> w_sh) : q / W, c = q - el * W;      // (no integer division on the common widths)
         real acc = 0;
         for (int s = 0; s < S; ++s) {
           const int row = tab[2 * (el * S + s)], snd = tab[2 * (el * S + s) + 1];
