@@ -96,7 +96,8 @@ enum dqmc_op_kind {
    * n_env = 3 with pi = 1: the SimplifiedNucleusDependentEnvelopes of env.py:110-226). */
   DQMC_OP_ORBITALS = 8,
   /* i: [0]=orbital buf.  sign/log|det| of the K matrices and their forward-Laplacian
-   * lanes, kept in double inside the context (wf/nn_wave_function.py:36-39). */
+   * lanes, kept in double inside the context (wf/nn_wave_function.py:36-39).  At most 44 electrons (the
+   * largest LDS-resident Gauss-Jordan instance); programs with more are rejected at creation (DQMC_E_ARG). */
   DQMC_OP_SLOGDET = 9,
   /* i: [0]=jastrow buf or -1 [1]=conf_coeff weight offset or -1 (SumPool) [2]=cusp kind
    * (0 none,1 deepqmc,2 psiformer) [3]=weight offset of {same_alpha, anti_alpha}.
