@@ -516,7 +516,7 @@ __device__ __forceinline__ void fused2_det(const real* m, double& logabs, int& s
 // -> psi of the proposal -> accept / reject -> sampler state, acceptance count; the last workgroup to finish
 // adapts tau (electron_samplers.py:106-138).  The matrices reuse LDS of activations that are dead by now.
 template <typename real>
-__device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw) {
+__device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw, long long* prof) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   const int tid = threadIdx.x, nthr = blockDim.x, WT = a.WT, N = a.li.N, K = a.K, wtm1 = WT - 1, sh = a.wt_shift;
@@ -542,6 +542,7 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   fused2_slater_entries<real>(a, op, nw, rs, [&](int wl, int kd, int el, int mu, real v) {
     mats[(wl * K + kd) * NN + el * N + mu] = v;
   });
+  if (prof) prof[0] = clock64();
   __syncthreads();
   for (int e = tid; e < K * WT; e += nthr) {
     const int wl = e & wtm1, kd = e >> sh;
@@ -556,6 +557,7 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
     ld[wl * K + kd] = la;
     sg[wl * K + kd] = sn;
   }
+  if (prof) prof[1] = clock64();
   __syncthreads();
   // exp-normalised CI terms (wf/nn_wave_function.py:152-160), one thread per (walker, determinant)
   const real* cc = a.mc.cc_off >= 0 ? a.w + a.mc.cc_off : nullptr;
@@ -617,6 +619,7 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
     }
     if (a.mc.accept_out) a.mc.accept_out[b] = acc ? 1 : 0;
   }
+  if (prof) prof[2] = clock64();
   if (tid < 64) {                                   // WT <= 16 < 64: the walkers of the tile sit in wave 0
     for (int m = 1; m < 64; m <<= 1) n_acc += __shfl_xor(n_acc, m, 64);
     // acceptance count: a fire-and-forget atomic (no return value, no fence); the NEXT sub-step's prologue
@@ -707,7 +710,9 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     }
     if (stamp && n_d < 254) a.prof[wave * 256 + (++n_d)] = clock64();
   }
-  if (a.mc.enabled) fused2_mc_tail<real>(a, nw);     // every wave list ends with a barrier
+  if (a.mc.enabled) {
+    fused2_mc_tail<real>(a, nw, stamp ? a.prof + wave * 256 + n_d + 1 : nullptr);     // every wave list ends with a barrier
+  }
 }
 
 // OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.

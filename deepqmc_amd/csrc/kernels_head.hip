@@ -524,12 +524,25 @@ __global__ void __launch_bounds__(256) k_slogdet_small(const real* __restrict__ 
   for (int t = li.T; t < li.TP; ++t) logdet[bk * li.TP + t] = 0.0;
 }
 
-// CI sum, cusps, Jastrow, and (Laplacian mode) the local energy.  One thread per walker;
-// double arithmetic (the cancellation Delta + |grad|^2 is the sensitive spot).
+// CI sum, cusps, Jastrow, and (Laplacian mode) the local energy.  SIXTEEN lanes per walker (the one-thread-per-walker
+// version was a 100 us serial chain even for 32 walkers): determinants, derivative lanes and particle pairs are dealt
+// to the lanes of a group and combined with xor-shuffles inside the group; double arithmetic (the cancellation
+// Delta + |grad|^2 is the sensitive spot).
+__device__ __forceinline__ double grp16_sum(double v) {
+  for (int m = 1; m < 16; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double grp16_max(double v) {
+  for (int m = 1; m < 16; m <<= 1) v = fmax(v, __shfl_xor(v, m, 64));
+  return v;
+}
 template <typename real>
-__global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= a.B) return;
+__global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
+  const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = threadIdx.x & 15;
+  const int b_raw = gtid >> 4;
+  const bool live = b_raw < a.B;
+  const int b = live ? b_raw : a.B - 1;            // idle groups shadow the last walker (all lanes stay in the shuffles)
   const int N = a.li.N, T = a.li.T, TP = a.li.TP, K = a.K;
   const real* r = reinterpret_cast<const real*>(a.r) + (long)b * N * 3;
   const real* R = reinterpret_cast<const real*>(a.R);
@@ -538,43 +551,69 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
   const real* cc = reinterpret_cast<const real*>(a.conf_coeff);
   // exp-normalised CI sum, reference wf/nn_wave_function.py:152-160
   double shift = -INFINITY;
-  for (int k = 0; k < K; ++k) shift = fmax(shift, x[(long)k * TP]);
+  for (int k = l; k < K; k += 16) shift = fmax(shift, x[(long)k * TP]);
+  shift = grp16_max(shift);
   if (isinf(shift)) shift = 0.0;
   double psi = 0.0;
-  for (int k = 0; k < K; ++k) psi += (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift);
+  for (int k = l; k < K; k += 16) psi += (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift);
+  psi = grp16_sum(psi);
   double logpsi = log(fabs(psi)) + shift;
   const int sign = (psi > 0) - (psi < 0);
-  // cusps (value), reference wf/cusp.py:5-26,68-78
+  // pair terms: cusp value (wf/cusp.py:5-26,68-78), its Laplacian, and the electron-electron repulsion
   const real* al = reinterpret_cast<const real*>(a.alphas);
-  double cusp = 0.0;
-  if (a.cusp_kind) {
-    for (int i = 0; i < N; ++i)
-      for (int j = i + 1; j < N; ++j) {
-        double d2 = a.eps;
-        for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
-        const double rho = sqrt(d2);
+  const int n_pairs = N * (N - 1) / 2;
+  double cusp = 0.0, cusp_lap = 0.0, v_el = 0.0;
+  {
+    int i = 0, j = 1, p0 = 0;                        // pair p <-> (i, j), i < j, row-major
+    for (int p = l; p < n_pairs; p += 16) {
+      while (p - p0 >= N - 1 - i) { p0 += N - 1 - i; ++i; }
+      j = i + 1 + (p - p0);
+      double d2 = 0.0;
+      for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
+      const double rho = sqrt(a.eps + d2);
+      v_el += 1.0 / rho;                                    // reference physics.py:119-121 (safe norm)
+      if (a.cusp_kind) {
         const bool same = (i < a.n_up) == (j < a.n_up);
         const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
-        cusp += a.cusp_kind == 1 ? -sc / (alp * (1 + alp * rho)) : -sc * alp * alp / (alp + rho);
+        double g1, g2;
+        if (a.cusp_kind == 1) {
+          const double u = 1 + alp * rho;
+          cusp += -sc / (alp * u);
+          g1 = sc / (u * u); g2 = -2 * sc * alp / (u * u * u);
+        } else {
+          const double u = alp + rho;
+          cusp += -sc * alp * alp / u;
+          g1 = sc * alp * alp / (u * u); g2 = -2 * sc * alp * alp / (u * u * u);
+        }
+        // both electrons: 2 * (g'' |grad rho|^2 + g' Lap rho)
+        cusp_lap += 2.0 * (g2 * d2 / (rho * rho) + g1 * (3.0 / rho - d2 / (rho * rho * rho)));
       }
+    }
   }
+  cusp = grp16_sum(cusp);
   const real* jas = reinterpret_cast<const real*>(a.jastrow);
   const real* jrow = jas ? jas + (long)b * TP * a.jas_width : nullptr;
   logpsi += cusp + (jrow ? (double)jrow[0] : 0.0);
-  if (a.logpsi) reinterpret_cast<real*>(a.logpsi)[b] = (real)logpsi;
-  if (a.sign) a.sign[b] = sign;
+  if (live && l == 0) {
+    if (a.logpsi) reinterpret_cast<real*>(a.logpsi)[b] = (real)logpsi;
+    if (a.sign) a.sign[b] = sign;
+  }
   if (T == 1) return;
 
   // ---- gradient and Laplacian of log|psi| ----
-  double lap = 0.0, qf2 = 0.0, sumJ2 = 0.0;
-  for (int k = 0; k < K; ++k) {
+  // per determinant (lanes over k): p_k and p_k (L_k + sum_t J_kt^2)
+  double lap = 0.0;
+  for (int k = l; k < K; k += 16) {
     const double pk = (cc ? (double)cc[k] : 1.0) * sk[k] * exp(x[(long)k * TP] - shift) / psi;
     double s2 = 0.0;
     for (int t = 1; t < T - 1; ++t) { const double j = x[(long)k * TP + t]; s2 += j * j; }
     lap += pk * (x[(long)k * TP + T - 1] + s2);
   }
+  lap = grp16_sum(lap);
+  // per derivative lane (lanes over t): g_t = sum_k p_k J_kt (+ Jastrow + cusp gradients)
   real* grad = reinterpret_cast<real*>(a.grad);
-  for (int t = 1; t < T - 1; ++t) {
+  double sumJ2 = 0.0, qf2 = 0.0;
+  for (int t = 1 + l; t < T - 1; t += 16) {
     const int c = t - 1, e = c / 3, xyz = c - 3 * e;
     double g = 0.0;
     for (int k = 0; k < K; ++k) {
@@ -597,48 +636,31 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
       }
     }
     qf2 += g * g;
-    if (grad) grad[(long)b * (3 * N) + c] = (real)g;
+    if (live && grad) grad[(long)b * (3 * N) + c] = (real)g;
   }
-  lap -= sumJ2;
+  sumJ2 = grp16_sum(sumJ2);
+  qf2 = grp16_sum(qf2);
+  cusp_lap = grp16_sum(cusp_lap);
+  v_el = grp16_sum(v_el);
+  lap += cusp_lap - sumJ2;
   if (jrow) lap += (double)jrow[(long)(T - 1) * a.jas_width];
-  double v_el = 0.0;
-  for (int i = 0; i < N; ++i)
-    for (int j = i + 1; j < N; ++j) {
-      double d2 = 0.0;
-      for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
-      const double rho = sqrt(a.eps + d2);
-      v_el += 1.0 / rho;                                    // reference physics.py:119-121 (safe norm)
-      if (a.cusp_kind) {
-        const bool same = (i < a.n_up) == (j < a.n_up);
-        const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
-        double g1, g2;
-        if (a.cusp_kind == 1) {
-          const double u = 1 + alp * rho;
-          g1 = sc / (u * u); g2 = -2 * sc * alp / (u * u * u);
-        } else {
-          const double u = alp + rho;
-          g1 = sc * alp * alp / (u * u); g2 = -2 * sc * alp * alp / (u * u * u);
-        }
-        // both electrons: 2 * (g'' |grad rho|^2 + g' Lap rho)
-        lap += 2.0 * (g2 * d2 / (rho * rho) + g1 * (3.0 / rho - d2 / (rho * rho * rho)));
-      }
-    }
   double v_loc = 0.0;
-  for (int i = 0; i < N; ++i)
-    for (int n = 0; n < a.n_nuc; ++n) {
-      double d2 = 0.0;
-      for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)R[n * 3 + c]; d2 += d * d; }
-      const double rn = sqrt(d2);
-      v_loc -= a.charges[n] / rn;                           // reference physics.py:131-133 (plain norm)
-      if (a.ecp_loc) {                                      // ecp/gaussian_type_ecp.py:127-159: r^-1, r^0, r^1 Gaussians
-        const double* p = a.ecp_loc + (long)n * 6 * a.ecp_nt;
-        for (int t = 0; t < a.ecp_nt; ++t) {
-          v_loc += p[1 * a.ecp_nt + t] / rn * exp(-p[0 * a.ecp_nt + t] * d2);
-          v_loc += p[3 * a.ecp_nt + t] * exp(-p[2 * a.ecp_nt + t] * d2);
-          v_loc += p[5 * a.ecp_nt + t] * rn * exp(-p[4 * a.ecp_nt + t] * d2);
-        }
+  for (int q = l; q < N * a.n_nuc; q += 16) {
+    const int i = q / a.n_nuc, n = q - i * a.n_nuc;
+    double d2 = 0.0;
+    for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)R[n * 3 + c]; d2 += d * d; }
+    const double rn = sqrt(d2);
+    v_loc -= a.charges[n] / rn;                           // reference physics.py:131-133 (plain norm)
+    if (a.ecp_loc) {                                      // ecp/gaussian_type_ecp.py:127-159: r^-1, r^0, r^1 Gaussians
+      const double* p = a.ecp_loc + (long)n * 6 * a.ecp_nt;
+      for (int t = 0; t < a.ecp_nt; ++t) {
+        v_loc += p[1 * a.ecp_nt + t] / rn * exp(-p[0 * a.ecp_nt + t] * d2);
+        v_loc += p[3 * a.ecp_nt + t] * exp(-p[2 * a.ecp_nt + t] * d2);
+        v_loc += p[5 * a.ecp_nt + t] * rn * exp(-p[4 * a.ecp_nt + t] * d2);
       }
     }
+  }
+  v_loc = grp16_sum(v_loc);
   // nuclear repulsion of the geometry of THIS call (reference physics.py:112-116: recomputed from phys_conf.R)
   double e_nuc = 0.0;
   for (int n = 0; n < a.n_nuc; ++n)
@@ -649,6 +671,7 @@ __global__ void __launch_bounds__(64) k_final(const FinalArgs a) {
     }
   const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
   const double e_loc = e_kin + v_loc + v_el + e_nuc;        // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
+  if (!live || l != 0) return;
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.flag_idx) {      // float32 build: hand ill-conditioned walkers to the float64 refinement pass
     const double ratio = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc));
@@ -711,7 +734,7 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
 }
 
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<real>), dim3((unsigned)((a.B + 63) / 64)), dim3(64), 0, st, a);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_final<real>), dim3((unsigned)((a.B + 15) / 16)), dim3(256), 0, st, a);
 }
 
 #define DQMC_INST(real)                                                                                              \

@@ -8,7 +8,7 @@ from deepqmc_amd.sampling import synthetic_walkers
 from deepqmc_amd.wf import NeuralNetworkWaveFunction
 
 ap = argparse.ArgumentParser(); ap.add_argument('--wt', type=int, default=0); ap.add_argument('--walkers', type=int, default=4096)
-ap.add_argument('--sched', type=int, default=-1)
+ap.add_argument('--sched', type=int, default=-1); ap.add_argument('--substep', type=int, default=0)
 args = ap.parse_args()
 h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
 wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cuda:0')
@@ -21,7 +21,12 @@ if args.wt:
 eng.set_option('fused_dbg', 1)
 eng.set_option('fused_print', 2)
 r = torch.as_tensor(synthetic_walkers(h, args.walkers).astype(np.float32), device='cuda:0')
-for _ in range(3):
+if args.substep:       # whole Metropolis sub-steps: the last three stamps of each wave are the tail (matrices, determinants, accept)
+    sg, lg = eng.wf_eval(r)
+    st = {'r': r.clone(), 'log': lg, 'sign': sg, 'age': torch.zeros(args.walkers, dtype=torch.int32, device='cuda:0'),
+          'tau': torch.full((1,), 0.3, dtype=torch.float32, device='cuda:0')}
+    eng.mcmc_steps(st, 3, seed=1)
+for _ in range(0 if args.substep else 3):
     eng.wf_eval(r)
 torch.cuda.synchronize()
 out = np.zeros(1024)
