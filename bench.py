@@ -410,6 +410,14 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     value = S * B * world / (elapsed / args.steps)        # every state's walkers get a local energy per step
 
+    # ---- the same loop with the float64 refinement switched off (secondary figure; plain float32 arithmetic) ----
+    ms_refine_off = None
+    if not args.emulated and args.refine < 0 and args.dtype == 'f32' and S == 1 and not args.overlap:
+        eng.set_option('refine', 0)
+        timed_block(10_000)
+        off = [timed_block(10_000 + (k + 1) * args.steps) for k in range(max(3, min(len(blocks), 10)))]
+        ms_refine_off = 1e3 * float(np.median(off)) / args.steps
+        eng.set_option('refine', 1)
     eloc_only, roofline = None, None
     if not args.emulated:       # (the emulated test harness only exercises launch / shard / reduce)
         # ---- pure E_loc throughput (n_sub = 0), not the headline ----
@@ -460,7 +468,7 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'timed_blocks': len(blocks), 'timed_seconds': float(np.sum(blocks)),
             'ms_per_step_min': 1e3 * float(np.min(blocks)) / args.steps, 'ms_per_step_max': 1e3 * float(np.max(blocks)) / args.steps,
-            'n_ranks_seen': n_ranks_seen,
+            'n_ranks_seen': n_ranks_seen, 'ms_per_step_refine_off': ms_refine_off,
             'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
             'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, '
                                    + (f'{S} electronic states x ' if S > 1 else '') + f'{B} walkers/GPU, '

@@ -69,34 +69,49 @@ __global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, con
 template <typename real>
 __global__ void __launch_bounds__(256) k_spin_mean(const real* __restrict__ x, real* __restrict__ m, int B, int n_up,
                                                    int width, LaneInfo li) {
+  // four consecutive features per thread (widths are multiples of 4): 16-byte loads and stores
+  const int w4 = width >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * 2 * li.TP * width;
+  const long total = (long)B * 2 * li.TP * w4;
   if (idx >= total) return;
-  const int c = (int)(idx % width);
-  long q = idx / width;
+  const int c = (int)(idx % w4) << 2;
+  long q = idx / w4;
   const int t = (int)(q % li.TP); q /= li.TP;
   const int which = (int)(q % 2);
   const int b = (int)(q / 2);
   const int i0 = which ? n_up : 0, i1 = which ? li.N : n_up;
-  real acc = 0;
-  for (int i = i0; i < i1; ++i) acc += x[(((long)b * li.N + i) * li.TP + t) * width + c];
-  m[idx] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
+  Vec4<real> acc{{0, 0, 0, 0}};
+  for (int i = i0; i < i1; ++i) {
+    const Vec4<real> v = *reinterpret_cast<const Vec4<real>*>(x + (((long)b * li.N + i) * li.TP + t) * width + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j];
+  }
+  const real inv = (i1 > i0) ? (real)1 / (real)(i1 - i0) : (real)0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc.v[j] = (i1 > i0) ? acc.v[j] / (real)(i1 - i0) : (real)0;
+  (void)inv;
+  *reinterpret_cast<Vec4<real>*>(m + (((long)b * 2 + which) * li.TP + t) * width + c) = acc;
 }
 
 // Sum over all rows of a walker (Jastrow sum_first, wf/omni.py:35-40).
 template <typename real>
 __global__ void __launch_bounds__(256) k_row_sum(const real* __restrict__ x, real* __restrict__ s, int B, int rows,
                                                  int width, LaneInfo li) {
+  const int w4 = width >> 2;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * li.TP * width;
+  const long total = (long)B * li.TP * w4;
   if (idx >= total) return;
-  const int c = (int)(idx % width);
-  long q = idx / width;
+  const int c = (int)(idx % w4) << 2;
+  long q = idx / w4;
   const int t = (int)(q % li.TP);
   const int b = (int)(q / li.TP);
-  real acc = 0;
-  for (int i = 0; i < rows; ++i) acc += x[(((long)b * rows + i) * li.TP + t) * width + c];
-  s[idx] = acc;
+  Vec4<real> acc{{0, 0, 0, 0}};
+  for (int i = 0; i < rows; ++i) {
+    const Vec4<real> v = *reinterpret_cast<const Vec4<real>*>(x + (((long)b * rows + i) * li.TP + t) * width + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j];
+  }
+  *reinterpret_cast<Vec4<real>*>(s + ((long)b * li.TP + t) * width + c) = acc;
 }
 
 // Convolution feature, reference gnn/graph.py:226-335: out[i] = sum_s we[row(i,s)] * hx[send(i,s)]
@@ -215,12 +230,12 @@ void launch_const_rows(hipStream_t st, const real* tab, real* x, int B, int rows
 }
 template <typename real>
 void launch_spin_mean(hipStream_t st, const real* x, real* m, int B, int n_up, int width, LaneInfo li) {
-  const long total = (long)B * 2 * li.TP * width;
+  const long total = (long)B * 2 * li.TP * (width / 4);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spin_mean<real>), dim3(nblk(total)), dim3(256), 0, st, x, m, B, n_up, width, li);
 }
 template <typename real>
 void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int width, LaneInfo li) {
-  const long total = (long)B * li.TP * width;
+  const long total = (long)B * li.TP * (width / 4);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_sum<real>), dim3(nblk(total)), dim3(256), 0, st, x, s, B, rows, width, li);
 }
 template <typename real>
