@@ -14,6 +14,8 @@
 // queries additionally attend to n_const key / value rows that do not depend on the electrons (folded on
 // the host, deepqmc_amd/nuclear_stream.py).  They come first in the key order -- as in the reference's
 // concatenate([nuclei, electrons]) -- and their derivative lanes are zero.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -23,14 +25,19 @@ template <typename real>
 __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, const real* __restrict__ k,
                                                    const real* __restrict__ v, real* __restrict__ out, int width,
                                                    int H, int hd, LaneInfo li, int n_const,
-                                                   const real* __restrict__ k_const, const real* __restrict__ v_const) {
+                                                   const real* __restrict__ k_const, const real* __restrict__ v_const,
+                                                   int NQ) {
+  // blockIdx.y selects a block of NQ queries (the rows of the attention matrix are independent given all keys): the
+  // query-indexed tiles shrink accordingly, which is what lets 42 electrons x 64 features fit the LDS in float64
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* sm = reinterpret_cast<real*>(smem_raw);
-  const int N = li.N, T = li.T, TP = li.TP;
+  const int NE = li.N, T = li.T, TP = li.TP;           // NE electrons = keys; N = queries of this workgroup
+  const int i_lo = blockIdx.y * NQ;
+  const int N = (NE - i_lo) < NQ ? (NE - i_lo) : NQ;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int S = hd + 1;              // padded row stride of the [rows][hd] tiles
-  const int M = n_const + N;         // keys: constant rows first, then the electrons
+  const int M = n_const + NE;        // keys: constant rows first, then the electrons
   const int NN = N * M, NH = N * S, MH = M * S;
   real* q0 = sm;            real* k0 = q0 + NH;       real* v0 = k0 + MH;
   real* qc = v0 + MH;       real* kc = qc + NH;       real* vc = kc + MH;
@@ -39,13 +46,14 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
   real* A1 = dP + NN;       real* QK = A1 + NN;       // [N][M] accumulators
   real* mrow = QK + NN;     real* A2 = mrow + N;      // [N]
   const real sc = (real)(1.0 / sqrt((double)hd));
-  const long row0 = (long)b * N * TP;                 // row of (b, i=0, t=0)
+  const long row0 = (long)b * NE * TP;                // row of (b, i=0, t=0)
+  const long qrow0 = row0 + (long)i_lo * TP;          // row of this workgroup's first query
   const int col0 = h * hd;
 
   auto load_tile = [&](const real* src, int t, real* dst) {
     for (int e = tid; e < N * hd; e += nthr) {
       const int i = e / hd, d = e - i * hd;
-      dst[i * S + d] = src[(row0 + (long)i * TP + t) * width + col0 + d];
+      dst[i * S + d] = src[(qrow0 + (long)i * TP + t) * width + col0 + d];
     }
   };
   auto load_kv = [&](const real* src, const real* cst, int t, real* dst) {   // [M][hd]: constants, then electrons
@@ -84,7 +92,7 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
     const int i = e / hd, d = e - i * hd;
     real o = 0;
     for (int j = 0; j < M; ++j) o += P[i * M + j] * v0[j * S + d];
-    out[(row0 + (long)i * TP) * width + col0 + d] = o;
+    out[(qrow0 + (long)i * TP) * width + col0 + d] = o;
   }
   if (T == 1) return;
 
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
           ol += dp * vc[j * S + d];
         }
         OL[i * S + d] += 2 * ol;
-        out[(row0 + (long)i * TP + t) * width + col0 + d] = o;
+        out[(qrow0 + (long)i * TP + t) * width + col0 + d] = o;
       }
     } else {
       // L_P = A1 + P*(L_S - rowsum(P*L_S) - A2);  out_L = L_P v0 + P v_L + 2 sum_c dP_c v_c
@@ -146,35 +154,55 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
         const int i = e / hd, d = e - i * hd;
         real o = OL[i * S + d];
         for (int j = 0; j < M; ++j) o += dP[i * M + j] * v0[j * S + d] + P[i * M + j] * vc[j * S + d];
-        out[(row0 + (long)i * TP + t) * width + col0 + d] = o;
+        out[(qrow0 + (long)i * TP + t) * width + col0 + d] = o;
       }
     }
   }
   for (int t = T; t < TP; ++t)
     for (int e = tid; e < N * hd; e += nthr) {
       const int i = e / hd, d = e - i * hd;
-      out[(row0 + (long)i * TP + t) * width + col0 + d] = 0;
+      out[(qrow0 + (long)i * TP + t) * width + col0 + d] = 0;
     }
 }
 
-template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const) {
+// LDS bytes with the queries split into blocks of NQ (NQ = N: one workgroup per (walker, head))
+template <typename real> static size_t attention_lds_split(int N, int hd, int n_const, int NQ) {
   const size_t M = (size_t)N + n_const;
-  return sizeof(real) * (((size_t)3 * N + 4 * M) * (hd + 1) + (size_t)5 * N * M + 2 * N);
+  return sizeof(real) * (((size_t)3 * NQ + 4 * M) * (hd + 1) + (size_t)5 * NQ * M + 2 * NQ);
+}
+// smallest number of query blocks whose tile set fits the 160 KiB LDS (0: none does)
+template <typename real> static int attention_query_blocks(int N, int hd, int n_const) {
+  for (int qs = 1; qs <= N; ++qs) {
+    const int NQ = (N + qs - 1) / qs;
+    if (attention_lds_split<real>(N, hd, n_const, NQ) <= (size_t)160 * 1024) return qs;
+  }
+  return 0;
+}
+template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const) {
+  const int qs = attention_query_blocks<real>(N, hd, n_const);
+  if (qs == 0) return (size_t)1 << 30;
+  return attention_lds_split<real>(N, hd, n_const, (N + qs - 1) / qs);
 }
 
 template <typename real>
 int launch_attention(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd,
                      int B, LaneInfo li, int n_const, const real* k_const, const real* v_const) {
-  const size_t lds = attention_lds_bytes<real>(li.N, hd, n_const);
-  if (lds > 160 * 1024) return -1;
+  int qs = attention_query_blocks<real>(li.N, hd, n_const);
+  if (qs == 0) return -1;
+  if (const char* f = getenv("DQMC_ATTN_QSPLIT")) {      // test hook: force at least this many query blocks
+    const int want = atoi(f);
+    if (want > qs && want <= li.N) qs = want;
+  }
+  const int NQ = (li.N + qs - 1) / qs;
+  const size_t lds = attention_lds_split<real>(li.N, hd, n_const, NQ);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return -2;
   // few electrons: one wave per (walker, head) instead of four mostly idle ones (measured: N = 4 10.4 -> 7.0 ms
   // per step; N = 14 is faster with four waves)
   const unsigned nthr = li.N <= 8 ? 64u : 256u;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<real>), dim3((unsigned)(B * H)), dim3(nthr), lds, st, q, k, v, out,
-                     width, H, hd, li, n_const, k_const, v_const);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention<real>), dim3((unsigned)(B * H), (unsigned)qs), dim3(nthr), lds, st, q, k, v, out,
+                     width, H, hd, li, n_const, k_const, v_const, NQ);
   return 0;
 }
 

@@ -107,3 +107,26 @@ def test_attention_mfma_f32(ansatz):
     it = Interp(eng.program, mol.charges, geom.F32_EPS)
     ref = it.run(r.astype(np.float64), mol.coords.astype(np.float32).astype(np.float64), laplacian=True)
     np.testing.assert_allclose(out[1][0], ref['e_loc'], rtol=5e-4, atol=5e-4)
+
+
+def test_attention_query_blocks_are_independent():
+    """The scalar attention kernel splits the queries over workgroups when its tile set would not fit the LDS (float64,
+    42 electrons); forcing the split on a small system must not change a single bit (rows of the attention matrix are
+    independent given all keys)."""
+    import os
+    from deepqmc_amd.engine import Engine
+    from deepqmc_amd.sampling import synthetic_walkers
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    spec = psiformer()
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=3, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    r = torch.as_tensor(synthetic_walkers(h, 2, seed=3))
+    e0, st0, g0 = eng.local_energy(r, return_grad=True)
+    os.environ['DQMC_ATTN_QSPLIT'] = '3'
+    try:
+        e1, st1, g1 = eng.local_energy(r, return_grad=True)
+    finally:
+        del os.environ['DQMC_ATTN_QSPLIT']
+    np.testing.assert_array_equal(e0.numpy(), e1.numpy())
+    np.testing.assert_array_equal(g0.numpy(), g1.numpy())
