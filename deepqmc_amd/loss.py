@@ -97,8 +97,9 @@ def compute_mean_overlap(psi_ratio: torch.Tensor, weight: torch.Tensor):
     s = (weight[:, None, :, :] * psi_ratio).sum(-1)
     n = torch.tensor(float(psi_ratio.shape[-1]), dtype=s.dtype, device=s.device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(s)
-        dist.all_reduce(n)
+        packed = torch.cat([s.reshape(-1), n.reshape(1)])          # sums and walker count in ONE all-reduce
+        dist.all_reduce(packed)
+        s, n = packed[:-1].reshape(s.shape), packed[-1]
     symm = symmetrize_overlap_with_clipped_geometric_mean(s / n)
     S = symm.shape[-1]
     iu = torch.triu_indices(S, S, offset=1, device=symm.device)
