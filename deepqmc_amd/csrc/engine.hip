@@ -161,6 +161,8 @@ struct Engine : dqmc_ctx {
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
+  int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
+  std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
   dqmc::FDesc* d_descs = nullptr;
   int32_t* d_wave_begin = nullptr;
@@ -433,6 +435,7 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
       fused2_lds_quarter = (size_t)160 * 1024 / value;
@@ -604,8 +607,44 @@ struct Engine : dqmc_ctx {
       }
       lvl = alap;
     }
+    // Row-wise two-layer MLPs (edge MLPs w / u, node MLP h): the second layer of a row block needs only the hidden rows
+    // of the SAME row block, so a wave that computed them can go on without a workgroup barrier.  Such a child op is
+    // pulled into its parent's level (its units follow the parent's in the same wave behind a wave-local LDS fence,
+    // build_fused2_plan); levels that become empty disappear.
+    chain_parent.assign(ops.size(), -1);
+    if (fused_chain) {
+      std::vector<std::vector<int>> writers(nb), readers(nb);
+      for (int k = 0; k < (int)ops.size(); ++k) { op_io(ops[k], rd, wr); for (int b : wr) writers[b].push_back(k); for (int b : rd) readers[b].push_back(k); }
+      std::vector<char> has_child(ops.size(), 0);
+      for (int k = 0; k < no; ++k) {
+        const int32_t* c = ops[k].i;
+        if (ops[k].kind != DQMC_OP_LINEAR || c[0] != 1 || c[4]) continue;          // one non-broadcast piece
+        const int sb = c[1];
+        if (writers[sb].size() != 1 || readers[sb].size() != 1) continue;            // a private hidden buffer
+        const int p = writers[sb][0];
+        if (p >= no || ops[p].kind != DQMC_OP_LINEAR || chain_parent[p] >= 0 || has_child[p]) continue;
+        const int32_t* pi = ops[p].i;
+        if (pi[18] != c[2] || pi[20] != c[20] || pi[19] != 0 || pad4(c[3]) > pad4(pi[21])) continue;   // same rows, whole width
+        if (lvl[k] != lvl[p] + 1) continue;
+        bool ok = true;
+        if (c[25] >= 0) for (int w : writers[c[25]]) ok = ok && w < no && lvl[w] < lvl[p];   // residual input complete before the level
+        for (int b2 : {c[17]}) for (int r2 : readers[b2]) ok = ok && (r2 >= no || lvl[r2] > lvl[k]);
+        if (!ok) continue;
+        lvl[k] = lvl[p];
+        chain_parent[k] = p;
+        has_child[p] = 1;
+      }
+      // drop empty levels
+      int L = 0;
+      for (int k = 0; k < no; ++k) L = lvl[k] + 1 > L ? lvl[k] + 1 : L;
+      std::vector<int> used(L, 0), remap(L, 0);
+      for (int k = 0; k < no; ++k) used[lvl[k]] = 1;
+      for (int l = 0, nl = 0; l < L; ++l) { remap[l] = nl; nl += used[l]; }
+      for (int k = 0; k < no; ++k) lvl[k] = remap[lvl[k]];
+    }
     f_order.resize(no);
     for (int k = 0; k < no; ++k) f_order[k] = k;
+    // a chained child sorts right behind ... its own level; within a level the program order is kept (parents first)
     std::stable_sort(f_order.begin(), f_order.end(), [&](int x, int y) { return lvl[x] < lvl[y]; });
     f_level.assign(no, 0);
     for (int j = 0; j < no; ++j) f_level[j] = lvl[f_order[j]];
@@ -737,17 +776,41 @@ struct Engine : dqmc_ctx {
     std::vector<int32_t> words(2 * (size_t)fused_n_ops);
     HIP_TRY(hipMemcpy(words.data(), d_wpk_off, sizeof(int32_t) * words.size(), hipMemcpyDeviceToHost));
     std::vector<std::vector<dqmc::FDesc>> lists(n_waves);
-    struct Unit { dqmc::FDesc d; long cost; };
+    struct Unit { dqmc::FDesc d; long cost; int opidx; };
     std::vector<Unit> level_units;
     std::vector<int> level_generic;
     auto flush_level = [&]() {
-      std::stable_sort(level_units.begin(), level_units.end(), [](const Unit& x, const Unit& y) { return x.cost > y.cost; });
+      // jobs: a unit, or -- for a chained MLP -- all units of one row block of the parent layer, a wave-local fence,
+      // and the child layer's units of that row block; jobs go longest first onto the least loaded wave
+      struct Job { std::vector<dqmc::FDesc> d; long cost; };
+      std::vector<Job> jobs;
+      std::vector<char> taken(level_units.size(), 0);
+      for (size_t a = 0; a < level_units.size(); ++a) {
+        if (taken[a]) continue;
+        const int op_a = level_units[a].opidx;
+        if (chain_parent[op_a] >= 0) continue;                    // placed with its parent's job
+        int child = -1;
+        for (size_t c = 0; c < level_units.size(); ++c) if (chain_parent[level_units[c].opidx] == op_a) child = level_units[c].opidx;
+        Job jb{{}, 0};
+        if (child < 0) {
+          jb.d.push_back(level_units[a].d); jb.cost = level_units[a].cost; taken[a] = 1;
+        } else {
+          const int row0 = level_units[a].d.row0;
+          for (size_t c = 0; c < level_units.size(); ++c)
+            if (!taken[c] && level_units[c].opidx == op_a && level_units[c].d.row0 == row0) { jb.d.push_back(level_units[c].d); jb.cost += level_units[c].cost; taken[c] = 1; }
+          dqmc::FDesc f{}; f.kind = 4; jb.d.push_back(f);
+          for (size_t c = 0; c < level_units.size(); ++c)
+            if (!taken[c] && level_units[c].opidx == child && level_units[c].d.row0 == row0) { jb.d.push_back(level_units[c].d); jb.cost += level_units[c].cost; taken[c] = 1; }
+        }
+        jobs.push_back(jb);
+      }
+      std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.cost > y.cost; });
       long load[4] = {0, 0, 0, 0};
-      for (const Unit& u : level_units) {
+      for (const Job& jb : jobs) {
         int best = 0;
         for (int w = 1; w < n_waves; ++w) if (load[w] < load[best]) best = w;
-        lists[best].push_back(u.d);
-        load[best] += u.cost;
+        lists[best].insert(lists[best].end(), jb.d.begin(), jb.d.end());
+        load[best] += jb.cost;
       }
       for (int j : level_generic)
         for (int w = 0; w < n_waves; ++w) { dqmc::FDesc g{}; g.kind = 3; g.op = j; lists[w].push_back(g); }
@@ -764,6 +827,12 @@ struct Engine : dqmc_ctx {
         const int NRB = (Rtot + 15) / 16, NCB = (ldw + 15) / 16, n_cg = (NCB + 1) / 2;
         int rpu = NRB * n_cg / n_waves;
         rpu = rpu < 1 ? 1 : (rpu > 4 ? 4 : rpu);
+        {   // chained layers are cut into single row blocks (parent and child units must cover the same rows)
+          const int me = f_order[j];
+          bool chained = chain_parent[me] >= 0;
+          for (int k2 = 0; k2 < fused_n_ops && !chained; ++k2) chained = chain_parent[k2] == me;
+          if (chained) rpu = 1;
+        }
         dqmc::FDesc t{};
         t.kind = 1; t.op = j; t.n_pieces = i[0]; t.rtot = Rtot; t.ldw = ldw;
         long kq = 0;
@@ -792,7 +861,7 @@ struct Engine : dqmc_ctx {
         }
         for (int rb0 = 0; rb0 < NRB; rb0 += rpu)
           for (int cg = 0; cg < n_cg; ++cg) {
-            Unit u{t, 0};
+            Unit u{t, 0, f_order[j]};
             u.d.ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
             u.d.row0 = rb0 * 16;
             u.d.col0 = cg * 32;

@@ -695,6 +695,8 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     if (kind == 0) break;
     if (kind == 2) {
       __syncthreads();
+    } else if (kind == 4) {
+      wave_lds_fence();          // chained MLP layer: the rows this wave just stored are the rows it reads next
     } else if (kind == 1) {
       if (MA1) {
         fused2_unit<real, 1>(a, d, pre0, pre1);
