@@ -161,6 +161,7 @@ struct Engine : dqmc_ctx {
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
+  int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
   int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
   std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
@@ -436,6 +437,7 @@ struct Engine : dqmc_ctx {
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
+    if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
       fused2_lds_quarter = (size_t)160 * 1024 / value;
@@ -868,6 +870,8 @@ struct Engine : dqmc_ctx {
             u.d.w_off = words[2 * j] / 4 + (cg * 2) * 64;
             u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
             if ((rb0 + u.d.ma) * 16 <= Rtot && cg * 32 + 32 <= ldw) u.d.flags |= 16;
+            // small layers take the lean unit body (kernel_fused2.hip: fused2_unit_lean)
+            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= 4 && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
             u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
             level_units.push_back(u);
           }
@@ -875,7 +879,7 @@ struct Engine : dqmc_ctx {
       if (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) flush_level();
     }
     fused2_ma1 = true;
-    for (auto& l : lists) for (auto& dd : l) if (dd.kind == 1 && dd.ma != 1) fused2_ma1 = false;
+    for (auto& l : lists) for (auto& dd : l) if ((dd.kind == 1 || dd.kind == 5) && dd.ma != 1) fused2_ma1 = false;
     std::vector<dqmc::FDesc> flat;
     int32_t begin[8];
     // (plan_lists is recorded after the chaining below)
@@ -884,7 +888,7 @@ struct Engine : dqmc_ctx {
       begin[4 + w] = -1;
       int last_unit = -1;                          // chain the units of the list: each prefetches the next one's first weights
       for (size_t k = 0; k < lists[w].size(); ++k) {
-        if (lists[w][k].kind != 1) continue;
+        if (lists[w][k].kind != 1 && lists[w][k].kind != 5) continue;
         if (last_unit < 0) begin[4 + w] = begin[w] + (int32_t)k;
         else lists[w][last_unit].next_unit = (int32_t)k - last_unit;
         last_unit = (int)k;

@@ -273,6 +273,101 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
   }
 }
 
+// Lean unit for the many SMALL layers (edge MLPs, second layers of the node MLPs): one piece, one row block, at most
+// 4 quads of k-steps (K <= 64), LDS destination, tanh or no activation.  The general unit executes ~700 instructions for
+// such a layer (piece loop, weight ring, double-buffered A fragments, descriptor fields it never needs) around 2-32
+// MFMAs, and with four waves per SIMD sharing the issue slots that instruction count IS its latency; this straight-line
+// version loads every B quad up front (quad 0 arrived with the previous unit) and keeps everything else in registers.
+template <typename real>
+__device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, DescPtr d, typename RVec4<real>::type& pre0,
+                                                 typename RVec4<real>::type& pre1) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  typedef typename Mfma<real>::acc_t acc_t;
+  typedef typename RVec4<real>::type rv4;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
+  const int KS = d->a_ks[0], NQ = d->a_nq[0];
+  const int bias_off = d->bias_off;
+  const int col0v = col_u + l15, col1v = col_u + 16 + l15;
+  const bool c0 = col0v < ldw, c1 = col1v < ldw;
+  const real bias0 = (bias_off >= 0 && c0) ? a.w[bias_off + col0v] : (real)0;
+  const real bias1 = (bias_off >= 0 && c1) ? a.w[bias_off + col1v] : (real)0;
+  const rv4* wq = reinterpret_cast<const rv4*>(a.wpk) + d->w_off + lane;
+  const int cb1 = d->w_cb1, qstride = d->qstride;
+  rv4 b0[4], b1[4];
+  b0[0] = pre0; b1[0] = pre1;
+#pragma unroll
+  for (int dd = 1; dd < 4; ++dd)
+    if (dd < NQ) { b0[dd] = wq[dd * qstride]; b1[dd] = wq[dd * qstride + cb1]; }
+  const int m = row0 + l15;
+  const int ao = d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + l4;
+  acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    if (dd < NQ) {                                 // wave-uniform
+      real fa[4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int ks = dd * 4 + kk;
+        fa[kk] = smem[ao + (ks < KS ? ks : KS - 1) * 4];      // clamped past the end: those weights are zero
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        acc0 = Mfma<real>::run(fa[kk], b0[dd][kk], acc0);
+        acc1 = Mfma<real>::run(fa[kk], b1[dd][kk], acc1);
+      }
+    }
+  }
+  {
+    const int nu = d->next_unit;                   // request the next unit's first B quad now
+    if (nu > 0) {
+      const DescPtr nd = d + nu;
+      const rv4* nb = reinterpret_cast<const rv4*>(a.wpk) + nd->w_off + lane;
+      pre0 = nb[0];
+      pre1 = nb[nd->w_cb1];
+    }
+  }
+  const int flags = d->flags;
+  real o0[4], o1[4];
+#pragma unroll
+  for (int rgi = 0; rgi < 4; ++rgi) { o0[rgi] = acc0[rgi] + bias0; o1[rgi] = acc1[rgi] + bias1; }
+  if ((flags & 3) == 1) {
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) { o0[rgi] = fast_tanh<real>(o0[rgi]); o1[rgi] = fast_tanh<real>(o1[rgi]); }
+  }
+  int me[4];
+  bool rk[4];
+#pragma unroll
+  for (int rgi = 0; rgi < 4; ++rgi) {
+    const int mm = row0 + Mfma<real>::row_of(lane, rgi);
+    rk[rgi] = mm < rtot;
+    me[rgi] = rk[rgi] ? mm : row0;
+  }
+  const int cc0 = c0 ? col0v : col_u, cc1 = c1 ? col1v : col_u;
+  const int res_base = d->res_base;
+  if (res_base >= 0) {
+    const int rs = d->res_stride;
+    const real res_scale = (flags & 4) ? (real)0.70710678118654752440 : (real)1;
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) {
+      o0[rgi] = (smem[res_base + me[rgi] * rs + cc0] + o0[rgi]) * res_scale;
+      o1[rgi] = (smem[res_base + me[rgi] * rs + cc1] + o1[rgi]) * res_scale;
+    }
+  }
+  const int db = d->dst_base, ds = d->dst_stride;
+  if (flags & 16) {
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) { smem[db + me[rgi] * ds + cc0] = o0[rgi]; smem[db + me[rgi] * ds + cc1] = o1[rgi]; }
+  } else {
+#pragma unroll
+    for (int rgi = 0; rgi < 4; ++rgi) {
+      if (rk[rgi] && c0) smem[db + me[rgi] * ds + cc0] = o0[rgi];
+      if (rk[rgi] && c1) smem[db + me[rgi] * ds + cc1] = o1[rgi];
+    }
+  }
+}
+
 // Slater-matrix entries A[(wl, k)][el][mu] = envelope(el; k, mu) * backflow(el; k, mu) for the tile (the arithmetic of
 // k_orbitals, value lane).  One thread per (electron, orbital k*N + mu): the envelope weights pi / zeta of that pair are
 // read ONCE (they do not depend on the walker) and the exponentials of the WT walkers are independent instructions --
@@ -697,6 +792,8 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
       __syncthreads();
     } else if (kind == 4) {
       wave_lds_fence();          // chained MLP layer: the rows this wave just stored are the rows it reads next
+    } else if (kind == 5) {
+      fused2_unit_lean<real>(a, d, pre0, pre1);
     } else if (kind == 1) {
       if (MA1) {
         fused2_unit<real, 1>(a, d, pre0, pre1);
