@@ -871,7 +871,7 @@ struct Engine : dqmc_ctx {
             u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
             if ((rb0 + u.d.ma) * 16 <= Rtot && cg * 32 + 32 <= ldw) u.d.flags |= 16;
             // small layers take the lean unit body (kernel_fused2.hip: fused2_unit_lean)
-            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= 4 && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
+            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= 8 && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
             u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
             level_units.push_back(u);
           }

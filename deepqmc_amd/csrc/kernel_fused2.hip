@@ -274,7 +274,7 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
 }
 
 // Lean unit for the many SMALL layers (edge MLPs, second layers of the node MLPs): one piece, one row block, at most
-// 4 quads of k-steps (K <= 64), LDS destination, tanh or no activation.  The general unit executes ~700 instructions for
+// 8 quads of k-steps (K <= 128), LDS destination, tanh or no activation.  The general unit executes ~700 instructions for
 // such a layer (piece loop, weight ring, double-buffered A fragments, descriptor fields it never needs) around 2-32
 // MFMAs, and with four waves per SIMD sharing the issue slots that instruction count IS its latency; this straight-line
 // version loads every B quad up front (quad 0 arrived with the previous unit) and keeps everything else in registers.
@@ -303,20 +303,33 @@ __device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, Desc
   const int m = row0 + l15;
   const int ao = d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + l4;
   acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
+  for (int qb = 0; qb < NQ; qb += 4) {             // batches of 4 quads (NQ <= 8: at most two)
+    rv4 n0[4], n1[4];
+    const bool more = qb + 4 < NQ;
+    if (more) {                                    // request the next batch before this one is multiplied
 #pragma unroll
-  for (int dd = 0; dd < 4; ++dd) {
-    if (dd < NQ) {                                 // wave-uniform
-      real fa[4];
+      for (int dd = 0; dd < 4; ++dd)
+        if (qb + 4 + dd < NQ) { n0[dd] = wq[(qb + 4 + dd) * qstride]; n1[dd] = wq[(qb + 4 + dd) * qstride + cb1]; }
+    }
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const int ks = dd * 4 + kk;
-        fa[kk] = smem[ao + (ks < KS ? ks : KS - 1) * 4];      // clamped past the end: those weights are zero
+    for (int dd = 0; dd < 4; ++dd) {
+      if (qb + dd < NQ) {                          // wave-uniform
+        real fa[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          const int ks = (qb + dd) * 4 + kk;
+          fa[kk] = smem[ao + (ks < KS ? ks : KS - 1) * 4];    // clamped past the end: those weights are zero
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          acc0 = Mfma<real>::run(fa[kk], b0[dd][kk], acc0);
+          acc1 = Mfma<real>::run(fa[kk], b1[dd][kk], acc1);
+        }
       }
+    }
+    if (more) {
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        acc0 = Mfma<real>::run(fa[kk], b0[dd][kk], acc0);
-        acc1 = Mfma<real>::run(fa[kk], b1[dd][kk], acc1);
-      }
+      for (int dd = 0; dd < 4; ++dd) { b0[dd] = n0[dd]; b1[dd] = n1[dd]; }
     }
   }
   {
@@ -497,13 +510,14 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
       const BufPtr x = fbs + op->i[0];
       const BufPtr m = fbs + op->i[1];
       const int xo = x->off, xs = x->stride, W = x->width, mo = m->off, ms = m->stride;
+      const real inv_up = n_up > 0 ? (real)1 / (real)n_up : (real)0, inv_dn = N > n_up ? (real)1 / (real)(N - n_up) : (real)0;
       for (int e = tid; e < W * 2 * WT; e += nthr) {
         const int wl = e & wtm1, q = e >> sh;
         const int which = q & 1, c = q >> 1;
         const int i0 = which ? n_up : 0, i1 = which ? N : n_up;
         real acc = 0;
         for (int el = i0; el < i1; ++el) acc += smem[xo + (el * WT + wl) * xs + c];
-        smem[mo + (which * WT + wl) * ms + c] = (i1 > i0) ? acc / (real)(i1 - i0) : (real)0;
+        smem[mo + (which * WT + wl) * ms + c] = acc * (which ? inv_dn : inv_up);
       }
       break;
     }

@@ -66,7 +66,7 @@ struct FusedBuf {
 };
 // One entry of a wave's work list; built on the host (engine.hip: build_fused2_plan), read through scalar loads.
 struct FDesc {
-  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, K <= 64, LDS destination)
+  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, K <= 128, LDS destination)
   int32_t op;           // scheduled op index (FusedArgs::ops)
   int32_t ma;           // row blocks of the unit (1..4); column blocks are always 2
   int32_t n_pieces;
