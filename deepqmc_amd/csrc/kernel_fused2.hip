@@ -638,10 +638,11 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   double* shv = reinterpret_cast<double*>(after + (size_t)WT * K * 12);      // CI shift per walker
   real* mats = smem + a.mc.mat_off;                           // [WT*K][N*N]
   // sampler state of this thread's walker: requested now, used after the determinants
+  // (the accept step works with 16 lanes per walker, four walkers at a time on wave 0: lane group g <-> walker g)
   real lp_old = 0, u_b = 1;
   int age_b = 0;
-  if (tid < nw) {
-    const long b = (long)blockIdx.x * WT + tid;
+  if (tid < 64 && (tid >> 4) < nw) {
+    const long b = (long)blockIdx.x * WT + (tid >> 4);
     lp_old = reinterpret_cast<const real*>(a.mc.logpsi)[b];
     u_b = reinterpret_cast<const real*>(a.mc.unif)[b];
     age_b = a.mc.age[b];
@@ -686,19 +687,32 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
   if (e_own >= 0) ld[(e_own & wtm1) * K + (e_own >> sh)] = term;     // log|det| -> CI term, in place
   __syncthreads();
   int n_acc = 0;
-  if (tid < nw) {
-    const int wl = tid;
-    const long b = (long)blockIdx.x * WT + wl;
-    double psi = 0.0;
-    for (int k = 0; k < K; ++k) psi += ld[wl * K + k];
-    double logpsi = log(fabs(psi)) + shv[wl];
-    const int sign_p = (psi > 0) - (psi < 0);
-    const real* r = rs + wl * N * 3;
+  if (tid < 64) {
+    const int l = tid & 15;
     const real* al = a.w + a.mc.al_off;
-    double cusp = 0.0;
-    if (a.mc.cusp_kind) {     // wf/cusp.py:5-26,68-78 (value)
-      for (int i = 0; i < N; ++i)
-        for (int j = i + 1; j < N; ++j) {
+    const int n_pairs = N * (N - 1) / 2;
+    for (int w0 = 0; w0 < nw; w0 += 4) {             // four walkers per pass, 16 lanes each
+      const int wl_raw = w0 + (tid >> 4);
+      const bool live = wl_raw < nw;
+      const int wl = live ? wl_raw : nw - 1;         // idle groups shadow a valid walker (all lanes stay in the shuffles)
+      const long b = (long)blockIdx.x * WT + wl;
+      if (w0 > 0 && live) {                          // later passes: their state was not preloaded
+        lp_old = reinterpret_cast<const real*>(a.mc.logpsi)[b];
+        u_b = reinterpret_cast<const real*>(a.mc.unif)[b];
+        age_b = a.mc.age[b];
+      }
+      double psi = 0.0;
+      for (int k = l; k < K; k += 16) psi += ld[wl * K + k];
+      for (int m = 1; m < 16; m <<= 1) psi += __shfl_xor(psi, m, 64);
+      double logpsi = log(fabs(psi)) + shv[wl];
+      const int sign_p = (psi > 0) - (psi < 0);
+      const real* r = rs + wl * N * 3;
+      double cusp = 0.0;
+      if (a.mc.cusp_kind) {     // wf/cusp.py:5-26,68-78 (value); pair p <-> (i, j), i < j, row-major
+        int i = 0, p0 = 0;
+        for (int p = l; p < n_pairs; p += 16) {
+          while (p - p0 >= N - 1 - i) { p0 += N - 1 - i; ++i; }
+          const int j = i + 1 + (p - p0);
           double d2 = a.eps;
           for (int c = 0; c < 3; ++c) { const double d = (double)r[i * 3 + c] - (double)r[j * 3 + c]; d2 += d * d; }
           const double rho = sqrt(d2);
@@ -706,27 +720,33 @@ __device__ __forceinline__ void fused2_mc_tail(const Fused2Args<real>& a, int nw
           const double sc = same ? a.mc.same_scale : a.mc.anti_scale, alp = (double)al[same ? 0 : 1];
           cusp += a.mc.cusp_kind == 1 ? -sc / (alp * (1 + alp * rho)) : -sc * alp * alp / (alp + rho);
         }
+        for (int m = 1; m < 16; m <<= 1) cusp += __shfl_xor(cusp, m, 64);
+      }
+      logpsi += cusp + (a.mc.jas_width > 0 ? (double)jas[wl * 4] : 0.0);
+      const real lp_prop = (real)logpsi;
+      // accept = 2 (log|psi'| - log|psi|) > log u  [| age >= max_age]   (k_accept); identical in all lanes of the group
+      const real log_prob = 2 * (lp_prop - lp_old);
+      const real lu = sizeof(real) == 4 ? (real)logf((float)u_b) : (real)log((double)u_b);
+      bool acc = log_prob > lu;
+      if (a.mc.max_age >= 0) acc = acc || (age_b >= a.mc.max_age);
+      if (live) {
+        if (acc) {
+          real* rg = reinterpret_cast<real*>(a.mc.r) + b * 3 * N;
+          for (int k = l; k < 3 * N; k += 16) rg[k] = r[k];
+        }
+        if (l == 0) {
+          if (acc) {
+            reinterpret_cast<real*>(a.mc.logpsi)[b] = lp_prop;
+            a.mc.sign[b] = sign_p;
+            a.mc.age[b] = 0;
+            n_acc += 1;
+          } else {
+            a.mc.age[b] = age_b + 1;
+          }
+          if (a.mc.accept_out) a.mc.accept_out[b] = acc ? 1 : 0;
+        }
+      }
     }
-    logpsi += cusp + (a.mc.jas_width > 0 ? (double)jas[wl * 4] : 0.0);
-    const real lp_prop = (real)logpsi;
-    // accept = 2 (log|psi'| - log|psi|) > log u  [| age >= max_age]   (k_accept)
-    real* lp_state = reinterpret_cast<real*>(a.mc.logpsi);
-    const real log_prob = 2 * (lp_prop - lp_old);
-    const real lu = sizeof(real) == 4 ? (real)logf((float)u_b) : (real)log((double)u_b);
-    bool acc = log_prob > lu;
-    const int age = age_b;
-    if (a.mc.max_age >= 0) acc = acc || (age >= a.mc.max_age);
-    if (acc) {
-      real* rg = reinterpret_cast<real*>(a.mc.r) + b * 3 * N;
-      for (int k = 0; k < 3 * N; ++k) rg[k] = r[k];
-      lp_state[b] = lp_prop;
-      a.mc.sign[b] = sign_p;
-      a.mc.age[b] = 0;
-      n_acc = 1;
-    } else {
-      a.mc.age[b] = age + 1;
-    }
-    if (a.mc.accept_out) a.mc.accept_out[b] = acc ? 1 : 0;
   }
   if (prof) prof[2] = clock64();
   if (tid < 64) {                                   // WT <= 16 < 64: the walkers of the tile sit in wave 0
