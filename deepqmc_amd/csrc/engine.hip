@@ -85,15 +85,17 @@ struct dqmc_ctx {
     (void)hipEventCreate(&e);
     return e;
   }
-  void t_begin(const char* name, double flops) {
+  hipStream_t t_stream = nullptr;      // stream of the launch being timed (the context's, or its edge-stream companion)
+  void t_begin(const char* name, double flops, hipStream_t s = nullptr) {
     if (!timing) return;
+    t_stream = s ? s : st;
     Pending p{name, get_event(), get_event(), flops};
-    (void)hipEventRecord(p.a, st);
+    (void)hipEventRecord(p.a, t_stream);
     pending.push_back(p);
   }
   void t_end() {
     if (!timing) return;
-    (void)hipEventRecord(pending.back().b, st);
+    (void)hipEventRecord(pending.back().b, t_stream);
   }
   void t_collect() {
     if (pending.empty()) return;
@@ -161,6 +163,14 @@ struct Engine : dqmc_ctx {
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
+  // Laplacian pass on two HIP streams: the two-particle (edge) stream does not depend on the node stream (reference
+  // gnn/electron_gnn.py:160-276: edges are updated from edges), its launches are HBM bound while the node layers are
+  // MFMA bound, so they run on a companion stream and the node stream waits (event) only where a convolution or an
+  // edge sum consumes an edge buffer.  Option "dual_stream" (1).
+  int dual_stream = 1;
+  hipStream_t st2 = nullptr;
+  std::vector<hipEvent_t> buf_ev;      // per buffer: last write on the companion stream (nullptr: none pending)
+  hipEvent_t ev_fork = nullptr;
   int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
   int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
   std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
@@ -195,6 +205,9 @@ struct Engine : dqmc_ctx {
 
   ~Engine() override {
     delete twin;
+    if (st2) (void)hipStreamDestroy(st2);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto e : buf_ev) if (e) (void)hipEventDestroy(e);
     if (d_molz) (void)hipFree(d_molz);
     if (d_flag) (void)hipFree(d_flag);
     if (d_ref) (void)hipFree(d_ref);
@@ -436,6 +449,7 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
@@ -1051,6 +1065,38 @@ struct Engine : dqmc_ctx {
     if (!lanes_supported(li.TP)) return fail(DQMC_E_UNSUPPORTED, "no kernel instance for " + std::to_string(li.TP) + " lanes");
     int rc = plan(B, li.TP);
     if (rc) return rc;
+    // edge-stream ops (destination carries pair-compact lanes) go to the companion stream in Laplacian mode
+    const bool dual = laplacian && dual_stream && !timing_serial() && std::any_of(compact.begin(), compact.end(), [](char c) { return c != 0; });
+    std::vector<char> pending_ev(bufs.size(), 0);
+    if (dual) {
+      if (!st2) HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+      if (!ev_fork) HIP_TRY(hipEventCreate(&ev_fork));
+      if (buf_ev.size() != bufs.size()) buf_ev.assign(bufs.size(), nullptr);
+      HIP_TRY(hipEventRecord(ev_fork, st));            // inputs ready, the previous evaluation's readers done
+      HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+    }
+    auto stream_of = [&](const dqmc_op& o) -> hipStream_t {
+      if (!dual) return st;
+      const bool edge = (o.kind == DQMC_OP_FEAT_EE && compact[o.i[0]]) || (o.kind == DQMC_OP_LINEAR && compact[o.i[17]]);
+      return edge ? st2 : st;
+    };
+    std::vector<int> rd_b, wr_b;
+    auto before = [&](const dqmc_op& o, hipStream_t s) -> int {     // the main stream waits for edge buffers it is about to read
+      if (!dual || s != st) return DQMC_OK;
+      op_io(o, rd_b, wr_b);
+      for (int b : rd_b) if (pending_ev[b]) { HIP_TRY(hipStreamWaitEvent(st, buf_ev[b], 0)); pending_ev[b] = 0; }
+      return DQMC_OK;
+    };
+    auto after = [&](const dqmc_op& o, hipStream_t s) -> int {
+      if (!dual || s != st2) return DQMC_OK;
+      op_io(o, rd_b, wr_b);
+      for (int b : wr_b) {
+        if (!buf_ev[b]) HIP_TRY(hipEventCreate(&buf_ev[b]));
+        HIP_TRY(hipEventRecord(buf_ev[b], st2));
+        pending_ev[b] = 1;
+      }
+      return DQMC_OK;
+    };
     size_t first_op = 0;
     if (!laplacian && fused_enabled && fused_n_ops > 0 && fused2_WT > 0) {
       rc = run_fused2(r, R, B, li);
@@ -1060,6 +1106,8 @@ struct Engine : dqmc_ctx {
     for (size_t opi = first_op; opi < ops.size(); ++opi) {
       const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
+      const hipStream_t so = stream_of(op);
+      { const int rcb = before(op, so); if (rcb) return rcb; }
       switch (op.kind) {
         case DQMC_OP_FEAT_EN:
           t_begin("feat", 0);
@@ -1067,8 +1115,8 @@ struct Engine : dqmc_ctx {
           t_end();
           break;
         case DQMC_OP_FEAT_EE:
-          t_begin("feat", 0);
-          dqmc::launch_feat_ee<real>(st, r, R, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
+          t_begin("feat", 0, so);
+          dqmc::launch_feat_ee<real>(so, r, R, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
                                      li.TP > 1 && compact[i[0]]);
           t_end();
           break;
@@ -1096,8 +1144,8 @@ struct Engine : dqmc_ctx {
           a.res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
           a.act = i[24]; a.nrows = i[20]; a.B = B; a.T = li.T; a.TP = li.TP;
           if (li.TP > 1 && compact[i[17]]) { a.T = dqmc::PAIR_LANES; a.TP = dqmc::PAIR_LANES; }   // row-wise op on edge rows
-          t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21]);
-          dqmc::launch_linear<real>(st, a);
+          t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
+          dqmc::launch_linear<real>(so, a);
           t_end();
           break;
         }
@@ -1182,10 +1230,14 @@ struct Engine : dqmc_ctx {
         default:
           return fail(DQMC_E_UNSUPPORTED, "op kind " + std::to_string(op.kind));
       }
+      { const int rca = after(op, so); if (rca) return rca; }
     }
+    if (dual)        // join: nothing of this evaluation may still run on the companion stream when the caller goes on
+      for (size_t b = 0; b < bufs.size(); ++b) if (pending_ev[b]) { HIP_TRY(hipStreamWaitEvent(st, buf_ev[b], 0)); pending_ev[b] = 0; }
     HIP_TRY(hipGetLastError());
     return DQMC_OK;
   }
+  bool timing_serial() const { return false; }
 
   int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) override {
     return run((const real*)r, (const real*)R, B, false, (real*)logpsi, sign, nullptr, nullptr, nullptr);
