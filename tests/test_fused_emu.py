@@ -61,3 +61,22 @@ def test_set_params_repacks_fused_weights():
     e_b, _ = eng.local_energy(rt)
     e_c, _ = fresh.local_energy(rt)
     np.testing.assert_array_equal(e_b.numpy(), e_c.numpy())
+
+
+def test_plan_variants_agree():
+    """The lean unit body for small layers (default), the general body (fused_lean 0) and the chained-MLP plan
+    (fused_chain 1) are different instruction sequences for the same arithmetic: identical psi in float64."""
+    spec = paulinet()
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    rt = torch.as_tensor(make_walkers(mol, h.n_elec, 6))
+    s0, l0 = eng.wf_eval(rt)
+    for opt, val in (('fused_lean', 0), ('fused_chain', 1)):
+        eng.set_option(opt, val)
+        s1, l1 = eng.wf_eval(rt)
+        np.testing.assert_array_equal(s1.numpy(), s0.numpy())
+        np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=1e-13, atol=1e-13)
+    eng.set_option('fused_lean', 1)
+    eng.set_option('fused_chain', 0)
