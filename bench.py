@@ -197,6 +197,7 @@ def main():
                     'psi evaluations per walker, loss/overlap.py:40-99) and the overlap penalty with its all-reduce')
     ap.add_argument('--refine', type=int, default=-1, help='float64 refinement of ill-conditioned walkers: 0 off, 1 flagged walkers '
                     '(library default), 2 whole E_loc pass in float64')
+    ap.add_argument('--opt', action='append', default=[], help='library option name=value (dqmc_set_option), repeatable')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
     ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state time the timed blocks must cover')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
@@ -297,6 +298,8 @@ def main():
     loc_ene = hamil.local_energy(wf)
     if args.refine >= 0:
         eng.set_option('refine', args.refine)
+    for kv in args.opt:
+        eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
     S = args.states
     if S > 1:
         from deepqmc_amd import loss

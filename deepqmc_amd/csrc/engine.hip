@@ -163,6 +163,8 @@ struct Engine : dqmc_ctx {
   size_t fused2_lds = 0, fused2_lds_budget = 80 * 1024;
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
+  bool fbufs2_uploaded = false;
+  int fused_always_upload = 0;   // experiment: re-upload the table before every launch (what round 1 did)
   // Laplacian pass on two HIP streams: the two-particle (edge) stream does not depend on the node stream (reference
   // gnn/electron_gnn.py:160-276: edges are updated from edges), its launches are HBM bound while the node layers are
   // MFMA bound, so they run on a companion stream and the node stream waits (event) only where a convolution or an
@@ -171,6 +173,7 @@ struct Engine : dqmc_ctx {
   hipStream_t st2 = nullptr;
   std::vector<hipEvent_t> buf_ev;      // per buffer: last write on the companion stream (nullptr: none pending)
   hipEvent_t ev_fork = nullptr;
+  int fused_stagger_div = 256;
   int fused_stagger = 0;         // option "fused_stagger": start delay between the co-resident workgroups of a CU (x 8128 cycles)
   int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
   int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
@@ -452,7 +455,9 @@ struct Engine : dqmc_ctx {
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
+    if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
     if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
+    if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
@@ -920,6 +925,7 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipMemcpy(d_descs, flat.data(), sizeof(dqmc::FDesc) * flat.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_wave_begin, begin, sizeof(begin), hipMemcpyHostToDevice));
     fbufs2_h = fb;
+    fbufs2_uploaded = false;
     if (dqmc::fused2_set_lds_limit<real>(fused2_lds) != 0) { fused2_WT = 0; return DQMC_OK; }
     return DQMC_OK;
   }
@@ -941,8 +947,16 @@ struct Engine : dqmc_ctx {
   }
 
   int run_fused2(const real* r, const real* R, int B, dqmc::LaneInfo li, const dqmc::FusedMc* mc = nullptr) {
-    for (size_t b = 0; b < bufs.size(); ++b) fbufs2_h[b].goff = (long)buf_off[b];
-    HIP_TRY(hipMemcpyAsync(d_fbufs2, fbufs2_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
+    bool changed = !fbufs2_uploaded || fused_always_upload;       // the buffer table goes to the device only when an offset moved (not once per sub-step)
+    for (size_t b = 0; b < bufs.size(); ++b) {
+      if (fbufs2_h[b].goff != (long)buf_off[b]) changed = true;
+      fbufs2_h[b].goff = (long)buf_off[b];
+    }
+    if (changed) {
+      HIP_TRY(hipMemcpyAsync(d_fbufs2, fbufs2_h.data(), sizeof(dqmc::FusedBuf) * bufs.size(), hipMemcpyHostToDevice, st));
+      if (!fbufs2_uploaded) HIP_TRY(hipStreamSynchronize(st));   // (the host vector may change before an asynchronous copy from pageable memory ran)
+      fbufs2_uploaded = true;
+    }
     dqmc::Fused2Args<real> a{};
     a.descs = d_descs; a.wave_begin = d_wave_begin; a.ops = d_ops; a.fbufs = d_fbufs2;
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
@@ -952,7 +966,7 @@ struct Engine : dqmc_ctx {
     a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));
     a.n_it = (int)n_itable;
     a.ma1 = fused2_ma1 ? 1 : 0;
-    a.stagger = fused_stagger; a.stagger_div = 256;
+    a.stagger = fused_stagger; a.stagger_div = fused_stagger_div;
     if (mc) a.mc = *mc;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)
