@@ -129,7 +129,8 @@ struct Engine : dqmc_ctx {
   char* d_ws = nullptr;
   size_t ws_bytes = 0;
   std::vector<size_t> buf_off;  // byte offsets for the current (B, TP)
-  size_t off_logdet = 0, off_signk = 0;
+  size_t off_logdet = 0, off_signk = 0, off_z = 0;
+  int split_bcast = 1;           // option "split_bcast": per-walker pieces of a linear layer multiplied once per walker
   int last_B = 0;
   // mcmc scratch
   char* d_mc = nullptr;
@@ -453,6 +454,7 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
     if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
@@ -1033,6 +1035,11 @@ struct Engine : dqmc_ctx {
     auto bump = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     for (size_t k = 0; k < bufs.size(); ++k)
       buf_off[k] = bump(sizeof(real) * (size_t)B * bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width);
+    {
+      int max_ldw = 4;
+      for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && pad4(o.i[21]) > max_ldw) max_ldw = pad4(o.i[21]);
+      off_z = bump(sizeof(real) * (size_t)B * TP * max_ldw);       // per-walker pre-activation rows of the split linear layers
+    }
     off_logdet = bump(sizeof(double) * (size_t)B * sys.n_det * TP);
     off_signk = bump(sizeof(int32_t) * (size_t)B * sys.n_det);
     if (off > ws_bytes) {
@@ -1050,7 +1057,9 @@ struct Engine : dqmc_ctx {
   size_t ws_bytes_per_walker(int TP) const {
     size_t b = 0;
     for (size_t k = 0; k < bufs.size(); ++k) b += sizeof(real) * (size_t)bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width;
-    return b + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det;
+    size_t zrow = 4;
+    for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && (size_t)pad4(o.i[21]) > zrow) zrow = (size_t)pad4(o.i[21]);
+    return b + sizeof(real) * zrow * TP + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det;
   }
 
   // Execute the layer program on B walkers, in chunks if the activation workspace of the whole batch would exceed
@@ -1140,7 +1149,7 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_LINEAR: {
           dqmc::LinArgs<real> a{};
           a.n_pieces = i[0];
-          int ktot = 0;
+          int ktot = 0, w_row = 0, n_bc = 0;
           for (int p = 0; p < i[0]; ++p) {
             const int sb = i[1 + 4 * p];
             a.piece[p].src = bptr(sb);
@@ -1149,6 +1158,9 @@ struct Engine : dqmc_ctx {
             a.piece[p].r0 = i[2 + 4 * p];
             a.piece[p].K = pad4(i[3 + 4 * p]);
             a.piece[p].bcast = i[4 + 4 * p];
+            a.piece[p].w_row = w_row;
+            w_row += pad4(i[3 + 4 * p]);
+            n_bc += i[4 + 4 * p] ? 1 : 0;
             ktot += i[3 + 4 * p];
           }
           a.W = d_w + i[22];
@@ -1161,6 +1173,30 @@ struct Engine : dqmc_ctx {
           a.res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
           a.act = i[24]; a.nrows = i[20]; a.B = B; a.T = li.T; a.TP = li.TP;
           if (li.TP > 1 && compact[i[17]]) { a.T = dqmc::PAIR_LANES; a.TP = dqmc::PAIR_LANES; }   // row-wise op on edge rows
+          if (split_bcast && n_bc > 0 && n_bc < i[0] && i[20] > 1 && !(li.TP > 1 && compact[i[17]])) {
+            // Per-walker (broadcast) pieces -- the spin means of the node update, reference gnn/update_features.py:64-106 --
+            // contribute the same row to every electron of a walker: their product with W is computed ONCE per walker into
+            // a scratch row and enters the main launch as an addend of the pre-activation (for LiH 57 %, for N2 62 % of the
+            // K range of the g layers; the dense path multiplied it once per electron).
+            dqmc::LinArgs<real> z = a;
+            dqmc::LinArgs<real> m = a;
+            z.n_pieces = m.n_pieces = 0;
+            for (int p = 0; p < i[0]; ++p) {
+              if (a.piece[p].bcast) z.piece[z.n_pieces++] = a.piece[p];
+              else m.piece[m.n_pieces++] = a.piece[p];
+            }
+            real* zb = reinterpret_cast<real*>(d_ws + off_z);
+            z.bias = nullptr; z.act = 0; z.res = nullptr; z.pre = nullptr;
+            z.dst = zb; z.ld_dst = a.ldw; z.rpw_dst = 1; z.r0_dst = 0; z.col0_dst = 0; z.nrows = 1;
+            m.pre = zb; m.ld_pre = a.ldw;
+            t_begin("linear", 0, so);
+            dqmc::launch_linear<real>(so, z);
+            t_end();
+            t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
+            dqmc::launch_linear<real>(so, m);
+            t_end();
+            break;
+          }
           t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
           dqmc::launch_linear<real>(so, a);
           t_end();

@@ -109,9 +109,9 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
-  int w_row0 = 0;  // first W row of the current piece
   for (int p = 0; p < a.n_pieces; ++p) {
     const LinPiece<real> pc = a.piece[p];
+    const int w_row0 = pc.w_row;   // first W row of the current piece
     const real* a_src[APT];
 #pragma unroll
     for (int j = 0; j < APT; ++j) {
@@ -176,7 +176,6 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
           for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
       }
     }
-    w_row0 += (pc.K + 3) / 4 * 4;
   }
 
   // ---- epilogue ----
@@ -243,6 +242,21 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
       const int b = g / a.nrows, rr = g - b * a.nrows;
       const long drow0 = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
       const long rrow0 = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
+      if (a.pre != nullptr) {        // per-walker part of the pre-activation (all lanes: the layer is linear in them)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_w0 + n * 16 + cl;
+          if (col < a.ldw) {
+#pragma unroll
+            for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
+                acc[gj * GB + tb][n][rg] += a.pre[((long)b * a.TP + t) * a.ld_pre + col];
+              }
+          }
+        }
+      }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         const int col = col_w0 + n * 16 + cl;
@@ -294,6 +308,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
           const int col = col_w0 + n * 16 + cl;
           if (col >= a.ldw) continue;
           real v = acc[i][n][rg];
+          if (a.pre != nullptr) v += a.pre[(long)b * a.ld_pre + col];
           if (a.bias != nullptr) v += a.bias[col];
           real y, d1, d2;
           act_derivs<real>(a.act, v, y, d1, d2);

@@ -36,6 +36,7 @@ void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, rea
 template <typename real> struct LinPiece {
   const real* src;
   int ld, rpw, r0, K, bcast;
+  int w_row;          // first row of this piece's block in W
 };
 template <typename real> struct LinArgs {
   int n_pieces;
@@ -45,6 +46,8 @@ template <typename real> struct LinArgs {
   const real* bias;   // [ldw] or nullptr (value lane only)
   real* dst;
   int ld_dst, rpw_dst, r0_dst, col0_dst;
+  const real* pre;    // per-walker addend to the pre-activation, real[B][TP][ld_pre], or nullptr: the product of the
+  int ld_pre;         //   per-walker (broadcast) pieces, computed once per walker by a separate launch
   const real* res;    // residual input or nullptr: out = (res + y) * res_scale
   int ld_res, rpw_res, r0_res;
   real res_scale;
