@@ -168,16 +168,38 @@ __global__ void __launch_bounds__(256) k_edge_sum(const real* __restrict__ e, in
                                                   real* __restrict__ out, int out_width, int col0,
                                                   const int32_t* __restrict__ tab, int S, int W, real scale, int B,
                                                   LaneInfo li, int compact) {
+  // four consecutive features per thread when the width allows (16-byte loads / stores, 4x fewer index computations)
+  const bool v4 = (W & 3) == 0 && (col0 & 3) == 0;
+  const int Wv = v4 ? W >> 2 : W;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * li.N * li.TP * W;
+  const long total = (long)B * li.N * li.TP * Wv;
   if (idx >= total) return;
-  const int c = (int)(idx % W);
-  long q = idx / W;
+  const int c = (int)(idx % Wv) * (v4 ? 4 : 1);
+  long q = idx / Wv;
   const int t = (int)(q % li.TP); q /= li.TP;
   const int i = (int)(q % li.N);
   const int b = (int)(q / li.N);
   const bool cp = compact && li.T > 1;
   const int TPe = cp ? PAIR_LANES : li.TP;
+  real* o = out + (((long)b * li.N + i) * li.TP + t) * out_width + col0 + c;
+  if (v4) {
+    Vec4<real> acc{{0, 0, 0, 0}};
+    if (t < li.T)
+      for (int s = 0; s < S; ++s) {
+        const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
+        if (row < 0) continue;
+        const int te = cp ? pair_lane(t, li.T, i, snd) : t;
+        if (te >= 0) {
+          const Vec4<real> v = *reinterpret_cast<const Vec4<real>*>(e + (((long)b * e_rows + row) * TPe + te) * e_width + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc.v[j] += v.v[j];
+        }
+      }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc.v[j] *= scale;
+    *reinterpret_cast<Vec4<real>*>(o) = acc;
+    return;
+  }
   real acc = 0;
   if (t < li.T)
     for (int s = 0; s < S; ++s) {
@@ -186,7 +208,7 @@ __global__ void __launch_bounds__(256) k_edge_sum(const real* __restrict__ e, in
       const int te = cp ? pair_lane(t, li.T, i, snd) : t;
       if (te >= 0) acc += e[(((long)b * e_rows + row) * TPe + te) * e_width + c];
     }
-  out[(((long)b * li.N + i) * li.TP + t) * out_width + col0 + c] = acc * scale;
+  o[0] = acc * scale;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -248,7 +270,7 @@ void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, cons
 template <typename real>
 void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,
                      const int32_t* tab, int S, int W, double scale, int B, LaneInfo li, int compact) {
-  const long total = (long)B * li.N * li.TP * W;
+  const long total = (long)B * li.N * li.TP * (((W & 3) == 0 && (col0 & 3) == 0) ? W / 4 : W);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_edge_sum<real>), dim3(nblk(total)), dim3(256), 0, st, e, e_rows, e_width, out,
                      out_width, col0, tab, S, W, (real)scale, B, li, compact);
 }
