@@ -34,6 +34,7 @@ SIGNATURES = [
                                    c_void_p, c_void_p, POINTER(c_double)]),
     ('dqmc_set_ecp', c_int, [c_void_p, c_int, POINTER(c_double), c_int, c_int, POINTER(c_double)]),
     ('dqmc_ecp_rotation', c_int, [c_void_p, c_uint64, c_void_p]),
+    ('dqmc_set_pseudo_hamiltonian', c_int, [c_void_p, c_int, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_int32)]),
     ('dqmc_energy_stats', c_int, [c_void_p, c_void_p, c_void_p, c_int, POINTER(c_double)]),
     ('dqmc_energy_stats_allgather', c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, POINTER(c_double)]),
     ('dqmc_merge_energy_stats', c_int, [POINTER(c_double), c_int, POINTER(c_double)]),

@@ -112,6 +112,9 @@ __device__ __forceinline__ double u01(uint32_t hi, uint32_t lo) {  // [0,1) with
 // lane of edge (recv, send), or -1 if that lane is identically zero.  This is the block sparsity that folx
 // exploits for the reference (last paragraph).
 constexpr int PAIR_LANES = 8;
+// Pseudo-Hamiltonian coefficients per (walker, electron), double[PH_STRIDE]: the row-major 3x3 lower Cholesky
+// factor Q of A (9), Q^-1 b (3), and the electron's local PH potential (1); written by k_ph_coeffs (kernels_ecp.hip).
+constexpr int PH_STRIDE = 13;
 __device__ __forceinline__ int pair_lane(int t, int T, int recv, int send) {
   if (t == 0) return 0;
   if (t == T - 1) return PAIR_LANES - 1;
@@ -133,11 +136,31 @@ __device__ __forceinline__ int pair_lane_full(int ct, int T, int recv, int send)
 // difference d = r_recv - r_send (send < 0: a nucleus, no dependence), rho = sqrt(eps + d.d).
 // Reference: gnn/edge_features.py:21-123 + utils.py:79-85; derivative lanes per SURVEY.md
 // appendix C.  All arithmetic in double (inputs are 3 coordinates; cost is negligible).
+//
+// Pseudo-Hamiltonian seeding (reference ecp/pseudo_hamiltonian.py:115-146): with Q_recv / Q_send given (row-major
+// 3x3 lower Cholesky factors of the per-electron matrices A = Q Q^T), derivative lane (e, x) is the derivative
+// along column x of Q_e (the coordinate change r_e = Q_e v_e with Q held fixed) and the last lane is
+// sum_e tr(A_e Hess_e f) instead of the Laplacian.  NULL factors = the identity = the plain Laplacian.
 __device__ __forceinline__ void pair_feature_lane(const double d[3], double eps, int recv, int send, int t,
-                                                  const LaneInfo li, bool log_rescale, double out[4]) {
+                                                  const LaneInfo li, bool log_rescale, double out[4],
+                                                  const double* Qr = nullptr, const double* Qs = nullptr) {
   const double d2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
   const double rho = sqrt(eps + d2);
   const int n_ends = (recv == send) ? 0 : (send >= 0 ? 2 : 1);
+  // A_eff = sum over the electron ends of Q Q^T:  trA = tr(A_eff),  Ad = A_eff d,  dAd = d.A_eff.d
+  double trA = 3.0 * n_ends, dAd = n_ends * d2, Ad[3] = {n_ends * d[0], n_ends * d[1], n_ends * d[2]};
+  if (Qr && n_ends) {
+    trA = 0.0; dAd = 0.0; Ad[0] = Ad[1] = Ad[2] = 0.0;
+    for (int end = 0; end < n_ends; ++end) {
+      const double* Q = end ? Qs : Qr;
+      for (int c = 0; c < 3; ++c) {                    // column c of Q
+        const double qd = Q[0 + c] * d[0] + Q[3 + c] * d[1] + Q[6 + c] * d[2];
+        dAd += qd * qd;
+        for (int a = 0; a < 3; ++a) { Ad[a] += Q[3 * a + c] * qd; }
+        trA += Q[c] * Q[c] + Q[3 + c] * Q[3 + c] + Q[6 + c] * Q[6 + c];
+      }
+    }
+  }
   // lane of rho and of the three components of d
   double rho_t = 0.0, dc_t[3] = {0.0, 0.0, 0.0};
   double sgn = 0.0;
@@ -149,10 +172,16 @@ __device__ __forceinline__ void pair_feature_lane(const double d[3], double eps,
     const int c = t - 1, e = c / 3;
     x = c - 3 * e;
     sgn = (e == recv ? 1.0 : 0.0) - (e == send ? 1.0 : 0.0);
-    rho_t = sgn * d[x] / rho;
-    dc_t[x] = sgn;
+    if (Qr && sgn != 0.0) {
+      const double* Q = (e == recv) ? Qr : Qs;
+      for (int a = 0; a < 3; ++a) dc_t[a] = sgn * Q[3 * a + x];
+      rho_t = (dc_t[0] * d[0] + dc_t[1] * d[1] + dc_t[2] * d[2]) / rho;
+    } else {
+      rho_t = sgn * d[x] / rho;
+      dc_t[x] = sgn;
+    }
   } else if (t == li.T - 1) {
-    rho_t = n_ends * (3.0 / rho - d2 / (rho * rho * rho));
+    rho_t = trA / rho - dAd / (rho * rho * rho);
   }
   if (!log_rescale) {
     out[0] = rho_t; out[1] = dc_t[0]; out[2] = dc_t[1]; out[3] = dc_t[2];
@@ -162,7 +191,7 @@ __device__ __forceinline__ void pair_feature_lane(const double d[3], double eps,
   const double s = l1 / rho;
   const double s1 = (ir - s) / rho;
   const double s2 = (-ir * ir - 2.0 * s1) / rho;
-  const double sumJ2 = n_ends * d2 / (rho * rho);             // sum_c rho_c^2
+  const double sumJ2 = dAd / (rho * rho);                     // sum_c rho_c^2
   if (t == 0) {
     out[0] = l1;
     for (int a = 0; a < 3; ++a) out[1 + a] = d[a] * s;
@@ -172,7 +201,7 @@ __device__ __forceinline__ void pair_feature_lane(const double d[3], double eps,
   } else if (t == li.T - 1) {
     out[0] = rho_t * ir - sumJ2 * ir * ir;
     const double sL = s1 * rho_t + s2 * sumJ2;
-    for (int a = 0; a < 3; ++a) out[1 + a] = d[a] * sL + 2.0 * n_ends * s1 * d[a] / rho;
+    for (int a = 0; a < 3; ++a) out[1 + a] = d[a] * sL + 2.0 * s1 * Ad[a] / rho;
   } else {
     out[0] = out[1] = out[2] = out[3] = 0.0;
   }

@@ -62,11 +62,13 @@ struct dqmc_ctx {
                        const int32_t* up_idx, const int32_t* down_idx, const void* unif, uint8_t* accept_out, double* stats7) = 0;
   virtual int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) = 0;
   virtual int ecp_rotation(uint64_t seed, const void* phi) = 0;
+  virtual int set_ph(int n_grid, double r_max, const double* rv_loc, const double* rv_l2, const int32_t* mask) = 0;
   virtual int energy_stats(const void* e, const void* w, int B, double* out7) = 0;
   virtual int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
+  bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   int device = 0;           // every entry point makes this the calling thread's current device
   double* d_gather = nullptr;   // all-gathered energy records (dqmc_energy_stats_allgather)
@@ -202,6 +204,15 @@ struct Engine : dqmc_ctx {
   int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
   std::vector<double> w64_h, ecp_loc_h;
   int ecp_loc_nt_h = 0;
+  // pseudo-Hamiltonian (dqmc_set_pseudo_hamiltonian): radial tables of the PH nuclei, compacted
+  double* d_ph_loc = nullptr;
+  double* d_ph_l2 = nullptr;
+  int32_t* d_ph_nuc = nullptr;
+  int ph_n = 0, ph_grid = 0;
+  double ph_rmax = 0.0;
+  size_t off_phq = 0;
+  std::vector<double> ph_loc_h, ph_l2_h;      // host copies for the float64 twin
+  std::vector<int32_t> ph_mask_h;
   dqmc_ctx* twin = nullptr;
   int32_t* d_flag = nullptr;     // [0] = count, [1..] = walker indices
   size_t flag_cap = 0;
@@ -222,6 +233,9 @@ struct Engine : dqmc_ctx {
     if (d_ecp_loc) (void)hipFree(d_ecp_loc);
     if (d_ecp_nl) (void)hipFree(d_ecp_nl);
     if (d_ecp_nuc) (void)hipFree(d_ecp_nuc);
+    if (d_ph_loc) (void)hipFree(d_ph_loc);
+    if (d_ph_l2) (void)hipFree(d_ph_l2);
+    if (d_ph_nuc) (void)hipFree(d_ph_nuc);
     if (d_ecp) (void)hipFree(d_ecp);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (d_w) (void)hipFree(d_w);
@@ -1042,6 +1056,7 @@ struct Engine : dqmc_ctx {
     }
     off_logdet = bump(sizeof(double) * (size_t)B * sys.n_det * TP);
     off_signk = bump(sizeof(int32_t) * (size_t)B * sys.n_det);
+    if (ph_n && TP > 1) off_phq = bump(sizeof(double) * (size_t)B * N * dqmc::PH_STRIDE);
     if (off > ws_bytes) {
       if (d_ws) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ws)); d_ws = nullptr; ws_bytes = 0; }
       hipError_t e = hipMalloc((void**)&d_ws, off);
@@ -1059,7 +1074,8 @@ struct Engine : dqmc_ctx {
     for (size_t k = 0; k < bufs.size(); ++k) b += sizeof(real) * (size_t)bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width;
     size_t zrow = 4;
     for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && (size_t)pad4(o.i[21]) > zrow) zrow = (size_t)pad4(o.i[21]);
-    return b + sizeof(real) * zrow * TP + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det;
+    return b + sizeof(real) * zrow * TP + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det +
+           (ph_n && TP > 1 ? sizeof(double) * (size_t)N * dqmc::PH_STRIDE : 0);
   }
 
   // Execute the layer program on B walkers, in chunks if the activation workspace of the whole batch would exceed
@@ -1091,6 +1107,14 @@ struct Engine : dqmc_ctx {
     if (!lanes_supported(li.TP)) return fail(DQMC_E_UNSUPPORTED, "no kernel instance for " + std::to_string(li.TP) + " lanes");
     int rc = plan(B, li.TP);
     if (rc) return rc;
+    // pseudo-Hamiltonian: the local-energy pass (not the plain gradient of psi_grad / the Langevin sampler) seeds its
+    // derivative lanes with the per-electron Cholesky factors of A(r_i) (ecp/pseudo_hamiltonian.py:115-146)
+    const double* phq = nullptr;
+    if (laplacian && ph_n && e_loc && !ph_skip) {
+      double* q = reinterpret_cast<double*>(d_ws + off_phq);
+      dqmc::launch_ph_coeffs<real>(st, r, R, d_ph_nuc, ph_n, d_ph_loc, d_ph_l2, ph_grid, ph_rmax, B, N, q);
+      phq = q;
+    }
     // edge-stream ops (destination carries pair-compact lanes) go to the companion stream in Laplacian mode
     const bool dual = laplacian && dual_stream && !timing_serial() && std::any_of(compact.begin(), compact.end(), [](char c) { return c != 0; });
     std::vector<char> pending_ev(bufs.size(), 0);
@@ -1137,13 +1161,13 @@ struct Engine : dqmc_ctx {
       switch (op.kind) {
         case DQMC_OP_FEAT_EN:
           t_begin("feat", 0);
-          dqmc::launch_feat_en<real>(st, r, R, bptr(i[0]), B, sys.n_nuc, sys.n_up, bufs[i[0]].width, li, sys.norm_eps, i[1], i[2]);
+          dqmc::launch_feat_en<real>(st, r, R, bptr(i[0]), B, sys.n_nuc, sys.n_up, bufs[i[0]].width, li, sys.norm_eps, i[1], i[2], phq);
           t_end();
           break;
         case DQMC_OP_FEAT_EE:
           t_begin("feat", 0, so);
           dqmc::launch_feat_ee<real>(so, r, R, d_it + i[1], bptr(i[0]), B, i[2], li, sys.norm_eps, i[3],
-                                     li.TP > 1 && compact[i[0]]);
+                                     li.TP > 1 && compact[i[0]], phq);
           t_end();
           break;
         case DQMC_OP_LINEAR: {
@@ -1250,7 +1274,7 @@ struct Engine : dqmc_ctx {
           t_begin("orbitals", 0);
           dqmc::launch_orbitals<real>(st, r, R, bptr(i[0]), bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, d_w + i[2], d_w + i[3],
                                       d_w + i[4], d_w + i[5], B, sys.n_up, sys.n_nuc, i[6] > 0 ? i[6] : 1, sys.n_det, li,
-                                      sys.norm_eps);
+                                      sys.norm_eps, phq);
           t_end();
           break;
         case DQMC_OP_SLOGDET:
@@ -1274,6 +1298,7 @@ struct Engine : dqmc_ctx {
           a.eps = sys.norm_eps;
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
           a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
+          a.phq = phq;
           if (flag_on && laplacian) { a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset; }
           t_begin("final", 0);
           dqmc::launch_final<real>(st, a);
@@ -1354,6 +1379,7 @@ struct Engine : dqmc_ctx {
         rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
                      h_itable.data(), h_itable.size());
         if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
+        if (!rc && !ph_mask_h.empty()) rc = t->set_ph(ph_grid, ph_rmax, ph_loc_h.data(), ph_l2_h.data(), ph_mask_h.data());
         if (rc == DQMC_E_UNSUPPORTED && refine == 1) {
           // no float64 kernel set for this program (e.g. the scalar attention tiles of 42 electrons exceed the LDS):
           // the float32 results stand and the refinement switches itself off
@@ -1382,7 +1408,9 @@ struct Engine : dqmc_ctx {
       t_begin("refine", 0);
       dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_flag + 1, n, n3, nR3, r64, R64);
       t_end();
+      twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
       rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
+      twin->ph_skip = false;
       if (rc) return rc;
       t_begin("refine", 0);
       dqmc::launch_refine_scatter(st, d_flag + 1, n, n3, e64, s64, g64, l64, sg64, (float*)e_loc, (float*)stats, (long)B, (float*)grad,
@@ -1435,6 +1463,42 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
   int ecp_rotation(uint64_t seed, const void* phi) override { ecp_seed = seed; ecp_phi = phi; return DQMC_OK; }
+
+  // Pseudo-Hamiltonian tables (ecp/pseudo_hamiltonian.py:73-112): rV_loc and rV_L2 on the regular grid
+  // linspace(0, r_max, n_grid), one row per nucleus; rows of nuclei with mask 0 are ignored.  An all-zero mask
+  // (or n_grid 0) switches the PH off.
+  int set_ph(int n_grid, double r_max, const double* rv_loc, const double* rv_l2, const int32_t* mask) override {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (d_ph_loc) { HIP_TRY(hipFree(d_ph_loc)); d_ph_loc = nullptr; }
+    if (d_ph_l2) { HIP_TRY(hipFree(d_ph_l2)); d_ph_l2 = nullptr; }
+    if (d_ph_nuc) { HIP_TRY(hipFree(d_ph_nuc)); d_ph_nuc = nullptr; }
+    ph_n = ph_grid = 0; ph_rmax = 0.0;
+    ph_loc_h.clear(); ph_l2_h.clear(); ph_mask_h.clear();
+    std::vector<int32_t> nuc;
+    if (mask && n_grid > 0) for (int a = 0; a < sys.n_nuc; ++a) if (mask[a]) nuc.push_back(a);
+    if (nuc.empty()) { if (twin) return twin->set_ph(0, 0.0, nullptr, nullptr, nullptr); return DQMC_OK; }
+    if (n_grid < 2 || !(r_max > 0.0) || !rv_loc || !rv_l2) return fail(DQMC_E_ARG, "pseudo-Hamiltonian tables need n_grid >= 2, r_max > 0");
+    if (ecp_n_nl) return fail(DQMC_E_ARG, "a pseudo-Hamiltonian and a non-local Gaussian ECP cannot both be set");
+    std::vector<double> loc, l2;
+    for (int a : nuc) {
+      loc.insert(loc.end(), rv_loc + (size_t)a * n_grid, rv_loc + (size_t)(a + 1) * n_grid);
+      l2.insert(l2.end(), rv_l2 + (size_t)a * n_grid, rv_l2 + (size_t)(a + 1) * n_grid);
+    }
+    HIP_TRY(hipMalloc((void**)&d_ph_loc, sizeof(double) * loc.size()));
+    HIP_TRY(hipMalloc((void**)&d_ph_l2, sizeof(double) * l2.size()));
+    HIP_TRY(hipMalloc((void**)&d_ph_nuc, sizeof(int32_t) * nuc.size()));
+    HIP_TRY(hipMemcpy(d_ph_loc, loc.data(), sizeof(double) * loc.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ph_l2, l2.data(), sizeof(double) * l2.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_ph_nuc, nuc.data(), sizeof(int32_t) * nuc.size(), hipMemcpyHostToDevice));
+    ph_n = (int)nuc.size(); ph_grid = n_grid; ph_rmax = r_max;
+    if (sizeof(real) == 4) {
+      ph_loc_h.assign(rv_loc, rv_loc + (size_t)sys.n_nuc * n_grid);
+      ph_l2_h.assign(rv_l2, rv_l2 + (size_t)sys.n_nuc * n_grid);
+      ph_mask_h.assign(mask, mask + sys.n_nuc);
+    }
+    if (twin) return twin->set_ph(n_grid, r_max, rv_loc, rv_l2, mask);
+    return DQMC_OK;
+  }
 
   // E_loc with the non-local ECP term: the Laplacian pass, then 12 N n_nl value-only psi evaluations per
   // walker in batches of <= ecp_max_cfg quadrature walkers (gaussian_type_ecp.py:161-255).
@@ -1842,6 +1906,12 @@ int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l
   if (!ctx) return fail(DQMC_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
   return ctx->set_ecp(n_terms_loc, loc_host, n_l, n_terms_nl, nl_host);
+}
+int dqmc_set_pseudo_hamiltonian(dqmc_ctx* ctx, int n_grid, double r_max, const double* rv_loc_host, const double* rv_l2_host,
+                                const int32_t* mask_host) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->set_ph(n_grid, r_max, rv_loc_host, rv_l2_host, mask_host);
 }
 int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");

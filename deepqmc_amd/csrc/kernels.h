@@ -13,10 +13,10 @@ namespace dqmc {
 // ---- kernels_graph.hip ----
 template <typename real>
 void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B, int n_nuc, int n_up, int width,
-                    LaneInfo li, double eps, int log_rescale, int use_spin);
+                    LaneInfo li, double eps, int log_rescale, int use_spin, const double* phq = nullptr);
 template <typename real>
 void launch_feat_ee(hipStream_t st, const real* r, const real* R, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
-                    double eps, int log_rescale, int compact);
+                    double eps, int log_rescale, int compact, const double* phq = nullptr);
 template <typename real>
 void launch_const_rows(hipStream_t st, const real* tab, real* x, int B, int rows, int width, LaneInfo li);
 template <typename real>
@@ -173,7 +173,7 @@ int launch_attention_mfma(hipStream_t st, const float* q, const float* k, const 
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
                      int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
-                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps);
+                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps, const double* phq = nullptr);
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li, int use_mfma);
@@ -208,6 +208,9 @@ struct FinalArgs {
   int32_t* flag_idx;
   double refine_thresh;
   int b_offset;
+  // pseudo-Hamiltonian (ecp/pseudo_hamiltonian.py): per-(walker, electron) factors [B][N][PH_STRIDE] the derivative
+  // lanes were seeded with (and the electron's share of the local PH potential); nullptr = ordinary kinetic energy
+  const double* phq;
 };
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a);
 
@@ -226,6 +229,9 @@ template <typename real> void launch_ecp_points(hipStream_t st, const EcpArgs& a
 template <typename real>
 void launch_ecp_reduce(hipStream_t st, const EcpArgs& a, const real* logq, const int32_t* signq, const real* log0,
                        const int32_t* sign0, real* e_loc, real* stats, real* v_nl_out);
+template <typename real>
+void launch_ph_coeffs(hipStream_t st, const real* r, const real* R, const int32_t* ph_nuc, int n_ph, const double* rv_loc,
+                      const double* rv_l2, int n_grid, double r_max, int B, int N, double* phq);
 
 // ---- kernels_mcmc.hip ----
 template <typename real>

@@ -125,7 +125,73 @@ void launch_ecp_reduce(hipStream_t st, const EcpArgs& a, const real* logq, const
                      signq, log0, sign0, e_loc, stats, v_nl_out);
 }
 
+// ---- pseudo-Hamiltonian coefficients ----------------------------------------------------------------------------
+// Reference: ecp/pseudo_hamiltonian.py:173-234.  For electron i of walker b, with d_I = r_i - R_I, rho_I = |d_I|
+// (plain norm, geom/general.py:19-21) and the tabulated radial functions rV_loc / rV_L2 of the PH nuclei (linear
+// interpolation on the regular grid [0, r_max], zero outside -- RegularGridInterpolator(fill_value=0), :95-101):
+//   A_i = 1/2 I + sum_I [ rV_L2(rho) rho I - rV_L2(rho)/rho d d^T ],    b_i = sum_I 2 rV_L2(rho)/rho d,
+//   V_ph(b) = sum_i sum_I rV_loc(rho)/rho.
+// Written per (walker, electron): the lower Cholesky factor Q of A (jax.scipy.linalg.cholesky(A, lower=True), :257)
+// Q^-1 b (so that b . grad_r = (Q^-1 b) . grad_v, :268-271) and the electron's share of V_ph (k_final sums them).
+__device__ __forceinline__ double ph_interp(const double* tab, int n_grid, double inv_h, double rho) {
+  const double x = rho * inv_h;
+  if (!(x >= 0.0) || x > (double)(n_grid - 1)) return 0.0;
+  int k = (int)x;
+  if (k > n_grid - 2) k = n_grid - 2;
+  const double f = x - k;
+  return tab[k] + f * (tab[k + 1] - tab[k]);
+}
+template <typename real>
+__global__ void __launch_bounds__(256) k_ph_coeffs(const real* __restrict__ r, const real* __restrict__ R,
+                                                   const int32_t* __restrict__ ph_nuc, int n_ph,
+                                                   const double* __restrict__ rv_loc, const double* __restrict__ rv_l2,
+                                                   int n_grid, double r_max, int B, int N, double* __restrict__ phq) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * N) return;
+  const double inv_h = (double)(n_grid - 1) / r_max;
+  const real* ri = r + (long)idx * 3;
+  double A[3][3] = {{0.5, 0, 0}, {0, 0.5, 0}, {0, 0, 0.5}}, bv[3] = {0, 0, 0}, vloc = 0.0;
+  for (int j = 0; j < n_ph; ++j) {
+    const real* Rn = R + ph_nuc[j] * 3;
+    double d[3], d2 = 0.0;
+    for (int c = 0; c < 3; ++c) { d[c] = (double)ri[c] - (double)Rn[c]; d2 += d[c] * d[c]; }
+    const double rho = sqrt(d2);
+    const double rvl2 = ph_interp(rv_l2 + (long)j * n_grid, n_grid, inv_h, rho);
+    const double v = rvl2 / rho;
+    vloc += ph_interp(rv_loc + (long)j * n_grid, n_grid, inv_h, rho) / rho;
+    for (int a = 0; a < 3; ++a) {
+      bv[a] += 2.0 * v * d[a];
+      A[a][a] += rvl2 * rho;
+      for (int c = 0; c < 3; ++c) A[a][c] -= v * d[a] * d[c];
+    }
+  }
+  // lower Cholesky factor (a non-positive pivot gives NaN, as LAPACK potrf does through jax)
+  double Q[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  Q[0][0] = sqrt(A[0][0]);
+  Q[1][0] = A[1][0] / Q[0][0];
+  Q[2][0] = A[2][0] / Q[0][0];
+  Q[1][1] = sqrt(A[1][1] - Q[1][0] * Q[1][0]);
+  Q[2][1] = (A[2][1] - Q[2][0] * Q[1][0]) / Q[1][1];
+  Q[2][2] = sqrt(A[2][2] - Q[2][0] * Q[2][0] - Q[2][1] * Q[2][1]);
+  double y[3];
+  y[0] = bv[0] / Q[0][0];
+  y[1] = (bv[1] - Q[1][0] * y[0]) / Q[1][1];
+  y[2] = (bv[2] - Q[2][0] * y[0] - Q[2][1] * y[1]) / Q[2][2];
+  double* o = phq + (long)idx * PH_STRIDE;
+  for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) o[3 * a + c] = Q[a][c];
+  for (int a = 0; a < 3; ++a) o[9 + a] = y[a];
+  o[12] = vloc;
+}
+template <typename real>
+void launch_ph_coeffs(hipStream_t st, const real* r, const real* R, const int32_t* ph_nuc, int n_ph, const double* rv_loc,
+                      const double* rv_l2, int n_grid, double r_max, int B, int N, double* phq) {
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ph_coeffs<real>), dim3((unsigned)(((long)B * N + 255) / 256)), dim3(256), 0, st, r, R,
+                     ph_nuc, n_ph, rv_loc, rv_l2, n_grid, r_max, B, N, phq);
+}
+
 #define DQMC_INST(real)                                                                                            \
+  template void launch_ph_coeffs<real>(hipStream_t, const real*, const real*, const int32_t*, int, const double*,  \
+                                       const double*, int, double, int, int, double*);                             \
   template void launch_ecp_points<real>(hipStream_t, const EcpArgs&, real*);                                       \
   template void launch_ecp_reduce<real>(hipStream_t, const EcpArgs&, const real*, const int32_t*, const real*,     \
                                         const int32_t*, real*, real*, real*);

@@ -11,7 +11,7 @@ namespace dqmc {
 template <typename real>
 __global__ void __launch_bounds__(256) k_feat_en(const real* __restrict__ r, const real* __restrict__ R, real* __restrict__ x,
                                                  int B, int n_nuc, int n_up, int width, LaneInfo li, double eps,
-                                                 int log_rescale, int use_spin) {
+                                                 int log_rescale, int use_spin, const double* __restrict__ phq) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * li.N * li.TP * n_nuc;
   if (idx >= total) return;
@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_feat_en(const real* __restrict__ r, con
   double d[3];
   for (int k = 0; k < 3; ++k) d[k] = (double)r[((long)b * li.N + i) * 3 + k] - (double)R[a * 3 + k];
   double f[4];
-  pair_feature_lane(d, eps, i, -1, t, li, log_rescale != 0, f);
+  pair_feature_lane(d, eps, i, -1, t, li, log_rescale != 0, f, phq ? phq + ((long)b * li.N + i) * PH_STRIDE : nullptr);
   real* row = x + (((long)b * li.N + i) * li.TP + t) * width;
   for (int k = 0; k < 4; ++k) row[4 * a + k] = (real)f[k];
   if (a == 0) {  // spin column and zero padding of the row tail
@@ -39,7 +39,7 @@ template <typename real>
 __global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, const real* __restrict__ R,
                                                  const int32_t* __restrict__ pairs,
                                                  real* __restrict__ e, int B, int n_rows, LaneInfo li, double eps,
-                                                 int log_rescale, int compact) {
+                                                 int log_rescale, int compact, const double* __restrict__ phq) {
   // compact: the destination carries the 8 pair lanes of common.h (Laplacian mode only)
   const int TPd = compact ? PAIR_LANES : li.TP;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,7 +59,8 @@ __global__ void __launch_bounds__(256) k_feat_ee(const real* __restrict__ r, con
     for (int c = 0; c < 3; ++c)
       d[c] = (double)r[((long)b * li.N + rc) * 3 + c] - (sd >= 0 ? (double)r[((long)b * li.N + sd) * 3 + c] : (double)R[(-1 - sd) * 3 + c]);
     double f[4];
-    pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f);
+    pair_feature_lane(d, eps, rc, sd, t, li, log_rescale != 0, f, phq ? phq + ((long)b * li.N + rc) * PH_STRIDE : nullptr,
+                      (phq && sd >= 0) ? phq + ((long)b * li.N + sd) * PH_STRIDE : nullptr);
     for (int c = 0; c < 4; ++c) o.v[c] = (real)f[c];
   }
   *reinterpret_cast<Vec4<real>*>(e + idx * 4) = o;
@@ -218,17 +219,17 @@ static inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256)
 
 template <typename real>
 void launch_feat_en(hipStream_t st, const real* r, const real* R, real* x, int B, int n_nuc, int n_up, int width,
-                    LaneInfo li, double eps, int log_rescale, int use_spin) {
+                    LaneInfo li, double eps, int log_rescale, int use_spin, const double* phq) {
   const long total = (long)B * li.N * li.TP * n_nuc;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_en<real>), dim3(nblk(total)), dim3(256), 0, st, r, R, x, B, n_nuc, n_up,
-                     width, li, eps, log_rescale, use_spin);
+                     width, li, eps, log_rescale, use_spin, phq);
 }
 template <typename real>
 void launch_feat_ee(hipStream_t st, const real* r, const real* R, const int32_t* pairs, real* e, int B, int n_rows, LaneInfo li,
-                    double eps, int log_rescale, int compact) {
+                    double eps, int log_rescale, int compact, const double* phq) {
   const long total = (long)B * n_rows * (compact ? PAIR_LANES : li.TP);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_feat_ee<real>), dim3(nblk(total)), dim3(256), 0, st, r, R, pairs, e, B, n_rows,
-                     li, eps, log_rescale, compact);
+                     li, eps, log_rescale, compact, phq);
 }
 // Constant rows (learned embeddings that do not depend on the electron positions: hk.Embed of the electron /
 // nuclear embeddings, gnn/electron_gnn.py:497-503,596-625 with positional_embeddings = false): value lane from the
@@ -277,9 +278,9 @@ void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, rea
 
 #define DQMC_INST(real)                                                                                              \
   template void launch_feat_en<real>(hipStream_t, const real*, const real*, real*, int, int, int, int, LaneInfo,     \
-                                     double, int, int);                                                              \
+                                     double, int, int, const double*);                                               \
   template void launch_feat_ee<real>(hipStream_t, const real*, const real*, const int32_t*, real*, int, int, LaneInfo, double, \
-                                     int, int);                                                                      \
+                                     int, int, const double*);                                                       \
   template void launch_const_rows<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                   \
   template void launch_spin_mean<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                    \
   template void launch_row_sum<real>(hipStream_t, const real*, real*, int, int, int, LaneInfo);                      \

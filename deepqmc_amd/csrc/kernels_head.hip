@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
                                                   int orb_width, const real* __restrict__ pi_up,
                                                   const real* __restrict__ pi_dn, const real* __restrict__ ze_up,
                                                   const real* __restrict__ ze_dn, int B, int n_up, int n_nuc, int n_env,
-                                                  int K, LaneInfo li, double eps) {
+                                                  int K, LaneInfo li, double eps, const double* __restrict__ phq) {
   // One thread per (walker, electron, orbital k*N+mu): the envelope value / gradient / Laplacian are
   // computed once (n_nuc*n_env exponentials) and then applied to all TP lanes of the backflow row;
   // neighbouring threads walk neighbouring orbitals, so the backflow reads and the Slater-matrix
@@ -70,6 +70,7 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
     return;
   }
   {
+    const double* Q = phq ? phq + ((long)b * N + i) * PH_STRIDE : nullptr;
     double rho = 0, u[3] = {0, 0, 0}, g2 = 0, lr = 0;
     int nuc = 0, ev = 0;
     auto entry = [&](double pa, double za) {
@@ -82,6 +83,16 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
         for (int c = 0; c < 3; ++c) u[c] = d[c] * ir;
         g2 = d2 * ir * ir;                                   // |grad rho|^2
         lr = 3.0 * ir - d2 * ir * ir * ir;                   // Laplacian of rho
+        if (Q) {   // pseudo-Hamiltonian lanes: derivatives along the columns of Q, tr(A Hess) with A = Q Q^T
+          double qd[3], trA = 0.0;
+          for (int c = 0; c < 3; ++c) {
+            qd[c] = (Q[0 + c] * d[0] + Q[3 + c] * d[1] + Q[6 + c] * d[2]) * ir;
+            trA += Q[c] * Q[c] + Q[3 + c] * Q[3 + c] + Q[6 + c] * Q[6 + c];
+          }
+          for (int c = 0; c < 3; ++c) u[c] = qd[c];
+          g2 = qd[0] * qd[0] + qd[1] * qd[1] + qd[2] * qd[2];
+          lr = trA * ir - g2 * ir;
+        }
       }
       const double z = fabs(za);
       const double w = pa * exp(-z * rho);
@@ -586,6 +597,20 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
           g1 = sc * alp * alp / (u * u); g2 = -2 * sc * alp * alp / (u * u * u);
         }
         // both electrons: 2 * (g'' |grad rho|^2 + g' Lap rho)
+        if (a.phq) {    // pseudo-Hamiltonian: sum over the two ends of g'' |Q^T grad rho|^2 + g' tr(A Hess rho)
+          double dAd = 0.0, trA = 0.0;
+          const double dv[3] = {(double)r[i * 3] - (double)r[j * 3], (double)r[i * 3 + 1] - (double)r[j * 3 + 1],
+                                (double)r[i * 3 + 2] - (double)r[j * 3 + 2]};
+          for (int end = 0; end < 2; ++end) {
+            const double* Q = a.phq + ((long)b * N + (end ? j : i)) * PH_STRIDE;
+            for (int c = 0; c < 3; ++c) {
+              const double qd = Q[0 + c] * dv[0] + Q[3 + c] * dv[1] + Q[6 + c] * dv[2];
+              dAd += qd * qd;
+              trA += Q[c] * Q[c] + Q[3 + c] * Q[3 + c] + Q[6 + c] * Q[6 + c];
+            }
+          }
+          cusp_lap += g2 * dAd / (rho * rho) + g1 * (trA / rho - dAd / (rho * rho * rho));
+        } else
         cusp_lap += 2.0 * (g2 * d2 / (rho * rho) + g1 * (3.0 / rho - d2 / (rho * rho * rho)));
       }
     }
@@ -612,7 +637,7 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
   lap = grp16_sum(lap);
   // per derivative lane (lanes over t): g_t = sum_k p_k J_kt (+ Jastrow + cusp gradients)
   real* grad = reinterpret_cast<real*>(a.grad);
-  double sumJ2 = 0.0, qf2 = 0.0;
+  double sumJ2 = 0.0, qf2 = 0.0, first_order = 0.0;
   for (int t = 1 + l; t < T - 1; t += 16) {
     const int c = t - 1, e = c / 3, xyz = c - 3 * e;
     double g = 0.0;
@@ -632,9 +657,14 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
         const double sc = same ? a.same_scale : a.anti_scale, alp = (double)al[same ? 0 : 1];
         const double g1 = a.cusp_kind == 1 ? sc / ((1 + alp * rho) * (1 + alp * rho))
                                            : sc * alp * alp / ((alp + rho) * (alp + rho));
+        if (a.phq) {
+          const double* Q = a.phq + ((long)b * N + e) * PH_STRIDE;
+          g += g1 * (Q[0 + xyz] * dv[0] + Q[3 + xyz] * dv[1] + Q[6 + xyz] * dv[2]) / rho;
+        } else
         g += g1 * dv[xyz] / rho;
       }
     }
+    if (a.phq) first_order += a.phq[((long)b * N + e) * PH_STRIDE + 9 + xyz] * g;   // b . grad_r = (Q^-1 b) . grad_v
     qf2 += g * g;
     if (live && grad) grad[(long)b * (3 * N) + c] = (real)g;
   }
@@ -669,7 +699,16 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
       for (int c = 0; c < 3; ++c) { const double d = (double)R[n * 3 + c] - (double)R[m * 3 + c]; d2 += d * d; }
       e_nuc += a.charges[n] * a.charges[m] / sqrt(d2);
     }
-  const double e_kin = -0.5 * (lap + qf2);                  // reference physics.py:108
+  double e_kin = -0.5 * (lap + qf2);                        // reference physics.py:108
+  if (a.phq) {
+    // ecp/pseudo_hamiltonian.py:236-278: the lanes are derivatives in the transformed coordinates (A = Q Q^T carries
+    // the 1/2 of the kinetic energy), E_kin = sum_i b_i . grad_i - (tr-Laplacian + |grad_v|^2); :173-190 local term
+    first_order = grp16_sum(first_order);
+    e_kin = first_order - (lap + qf2);
+    double vph = 0.0;
+    for (int i = l; i < N; i += 16) vph += a.phq[((long)b * N + i) * PH_STRIDE + 12];
+    v_loc += grp16_sum(vph);
+  }
   const double e_loc = e_kin + v_loc + v_el + e_nuc;        // reference hamil.py:172 (V_nl is added by k_ecp_reduce)
   if (!live || l != 0) return;
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
@@ -691,10 +730,10 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
 template <typename real>
 void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* bf, int bf_width, real* orb,
                      int orb_width, const real* pi_up, const real* pi_dn, const real* ze_up, const real* ze_dn, int B,
-                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps) {
+                     int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps, const double* phq) {
   const long total = (long)B * li.N * K * li.N;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_orbitals<real>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r, R,
-                     bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps);
+                     bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps, phq);
 }
 
 // use_mfma (engine option "slogdet_mfma"): 1 = f64-MFMA derivative traces where profitable (N > 16), 2 = from
@@ -740,7 +779,7 @@ template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
 #define DQMC_INST(real)                                                                                              \
   template void launch_orbitals<real>(hipStream_t, const real*, const real*, const real*, int, real*, int,           \
                                       const real*, const real*, const real*, const real*, int, int, int, int, int,   \
-                                      LaneInfo, double);                                                             \
+                                      LaneInfo, double, const double*);                                              \
   template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo, int);     \
   template void launch_final<real>(hipStream_t, const FinalArgs&);
 DQMC_INST(float)

@@ -95,3 +95,76 @@ class GaussianTypeECP:
                 tables[el] = load_ecp(ecp_type, [el])
                 assert tables[el], f'Effective core potential of type {ecp_type} not found for {el} atom.'
         return cls.from_tables(charges, ecp_mask, tables)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Pseudo-Hamiltonians (reference ecp/pseudo_hamiltonian.py).  Host side: the radial tables; the arithmetic
+# (coefficients A, b per electron, the transformed forward-Laplacian, the local term) runs in the HIP library
+# (csrc/kernels_ecp.hip: k_ph_coeffs; pair_feature_lane, k_orbitals, k_final).
+
+# pseudo_hamiltonian.py:18-30 (default file suffix per element, the OPH23 selection)
+ELEMENTS_WITH_EXISTING_PH = {15: ('P', 'cc'), 16: ('S', 'cc'), 17: ('Cl', 'cc'), 24: ('Cr', 'cc'), 25: ('Mn', 'hf'),
+                             26: ('Fe', 'cc'), 27: ('Co', 'cc'), 28: ('Ni', 'hf'), 29: ('Cu', 'hf'), 30: ('Zn', 'cc')}
+PH_GRID, PH_RMAX = 10001, 10.0        # pseudo_hamiltonian.py:95 (rx = linspace(0, 10, 10001))
+
+
+def parse_ph_xml(xml_file):
+    """(r*V_loc + Z_eff, r*V_L2, n_valence) from a QMCPACK-style semilocal pseudopotential file whose s, p, d
+    channels were built as a pseudo-Hamiltonian (pseudo_hamiltonian.py:32-70): with s(r), d(r) the r*V tables of the
+    l = 0 and l = 2 channels, v0 = s - d, the local function is d + v0 + zval and the L^2 function -v0 / 6."""
+    from xml.etree import ElementTree
+    root = ElementTree.parse(xml_file).getroot()
+    zval = float(root.find('header').attrib['zval'])
+    semilocal = root.find('semilocal')
+    chan = {}
+    for vps in semilocal.findall('vps'):
+        chan[vps.attrib['l']] = np.array(vps.find('radfunc').find('data').text.split(), np.float64)
+    s, d = chan['s'], chan['d']
+    v0 = s - d
+    return d + v0 + zval, -v0 / 6.0, zval
+
+
+class PseudoHamiltonian:
+    """ns_valence[n_nuc] and the tables rv_loc / rv_l2 [n_nuc, n_grid] on linspace(0, r_max, n_grid)
+    (rows of nuclei outside `ecp_mask` are zero).  pseudo_hamiltonian.py:73-112,159-171."""
+
+    def __init__(self, ns_valence, rv_loc, rv_l2, r_max, ecp_mask):
+        self.ns_valence = np.asarray(ns_valence, np.float64)
+        self.rv_loc = np.ascontiguousarray(rv_loc, np.float64)
+        self.rv_l2 = np.ascontiguousarray(rv_l2, np.float64)
+        self.r_max = float(r_max)
+        self.ecp_mask = np.asarray(ecp_mask, bool)
+        assert self.rv_loc.shape == self.rv_l2.shape == (len(self.ns_valence), self.rv_loc.shape[1])
+
+    @classmethod
+    def from_tables(cls, charges, ecp_mask, tables, r_max=PH_RMAX):
+        """`tables[element] = (rv_loc[n_grid], rv_l2[n_grid], n_valence)` -- what `parse_ph_xml` returns."""
+        n_grid = max((len(tables[ELEMENTS[int(z)]][0]) for z, use in zip(charges, ecp_mask) if use), default=2)
+        ns_valence, loc, l2 = [], np.zeros((len(charges), n_grid)), np.zeros((len(charges), n_grid))
+        for a, (z, use) in enumerate(zip(charges, ecp_mask)):
+            if use:
+                t_loc, t_l2, n_val = tables[ELEMENTS[int(z)]]
+                assert len(t_loc) == len(t_l2) == n_grid, 'all pseudo-Hamiltonian tables must share one grid'
+                loc[a], l2[a] = t_loc, t_l2
+                ns_valence.append(float(n_val))
+            else:
+                ns_valence.append(float(z))
+        return cls(ns_valence, loc, l2, r_max, ecp_mask)
+
+    @classmethod
+    def from_xml_dir(cls, charges, ecp_type, ecp_mask, ph_data_dir):
+        """The reference's lookup (pseudo_hamiltonian.py:73-112): `<ph_data_dir>/<El>.<suffix>.xml`, suffix from
+        `ecp_type` ('PHcc' -> 'cc'; bare 'PH' -> the per-element default).  The reference ships these files in
+        deepqmc/ecp/ph_data (separately licensed); point `ph_data_dir` at them."""
+        import os
+        suffix_req = str(ecp_type)[2:] if str(ecp_type).startswith('PH') else str(ecp_type)
+        tables = {}
+        for z, use in zip(charges, ecp_mask):
+            if use:
+                z = int(z)
+                assert z in ELEMENTS_WITH_EXISTING_PH, \
+                    f'Pseudo-Hamiltonian for atomic number {z} not found (probably does not exist!).'
+                name, default_suffix = ELEMENTS_WITH_EXISTING_PH[z]
+                if name not in tables:
+                    tables[name] = parse_ph_xml(os.path.join(ph_data_dir, f'{name}.{suffix_req or default_suffix}.xml'))
+        return cls.from_tables(charges, ecp_mask, tables)

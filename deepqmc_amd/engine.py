@@ -79,9 +79,13 @@ class Engine:
         self._ctx = ctx
         self._check(rc)
         self._ecp_phi = None
-        if getattr(hamil, 'pot', None) is not None:     # Gaussian-type ECP tables -> device
-            pot = hamil.pot
-            dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a.size else None
+        pot = getattr(hamil, 'pot', None)
+        dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a.size else None
+        if pot is not None and hasattr(pot, 'rv_l2'):       # pseudo-Hamiltonian tables -> device
+            mask = np.ascontiguousarray(pot.ecp_mask, np.int32)
+            self._check(self.lib.dqmc_set_pseudo_hamiltonian(self._ctx, pot.rv_loc.shape[1], pot.r_max, dp(pot.rv_loc), dp(pot.rv_l2),
+                                                             mask.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))))
+        elif pot is not None:                               # Gaussian-type ECP tables -> device
             self._check(self.lib.dqmc_set_ecp(self._ctx, pot.loc_params.shape[3], dp(pot.loc_params),
                                               pot.nl_params.shape[1], pot.nl_params.shape[3], dp(pot.nl_params)))
         self.R = torch.as_tensor(self.R0, dtype=dtype, device=self.device).contiguous()
@@ -145,7 +149,7 @@ class Engine:
         r = self._t(r)
         B = r.shape[0]
         assert r.shape[1:] == (self.N, 3)
-        if getattr(self.hamil, 'pot', None) is not None and self.hamil.pot.nl_params.size:
+        if getattr(getattr(self.hamil, 'pot', None), 'nl_params', np.zeros(0)).size:
             if rng is None and ecp_phi is None:      # gaussian_type_ecp.py:183 `assert rng is not None`
                 raise DqmcError('a Hamiltonian with a non-local ECP needs `rng` (the seed of the quadrature rotation)')
             if ecp_phi is None and not isinstance(rng, (int, np.integer)):

@@ -35,11 +35,12 @@ def get_shell(z) -> int:
 class MolecularHamiltonian:
     """hamil.py:70-154.  `ecp_type` selects Gaussian-type ECPs as in the reference; their
     coefficient tables come from `ecp_tables` (pyscf ECP format, see deepqmc_amd/ecp.py) or, when
-    pyscf is importable, from pyscf exactly as in the reference.  Pseudo-Hamiltonians
-    (`'PH'` types, ecp/pseudo_hamiltonian.py) are not built."""
+    pyscf is importable, from pyscf exactly as in the reference.  `'PH...'` types select a pseudo-Hamiltonian
+    (ecp/pseudo_hamiltonian.py); its radial tables come from `ph_tables` ({element: (rV_loc, rV_L2, n_valence)})
+    or from the reference's XML files under `ph_data_dir`."""
 
     def __init__(self, *, mol: Molecule, ecp_type: Optional[str] = None,
-                 ecp_mask=None, elec_std: float = 1.0, ecp_tables=None):
+                 ecp_mask=None, elec_std: float = 1.0, ecp_tables=None, ph_tables=None, ph_data_dir=None):
         self.mol = mol
         self.elec_std = elec_std
         self.ecp_type = ecp_type
@@ -52,11 +53,18 @@ class MolecularHamiltonian:
         self.pot = None                                         # GaussianTypeECP or None (bare Coulomb)
         if self.ecp_mask.any():                                 # hamil.py:130-138
             assert self.ecp_type is not None, 'ECP type must be specified if ECPs are used.'
-            if 'PH' in str(self.ecp_type):
-                raise NotImplementedError('pseudo-Hamiltonian ECPs (ecp/pseudo_hamiltonian.py) are not built')
-            from .ecp import GaussianTypeECP
-            self.pot = (GaussianTypeECP.from_tables(mol.charges, self.ecp_mask, ecp_tables) if ecp_tables is not None
-                        else GaussianTypeECP.from_pyscf(mol.charges, self.ecp_type, self.ecp_mask))
+            from .ecp import GaussianTypeECP, PseudoHamiltonian
+            if 'PH' in str(self.ecp_type):                      # hamil.py:135-136
+                if ph_tables is not None:
+                    self.pot = PseudoHamiltonian.from_tables(mol.charges, self.ecp_mask, ph_tables)
+                elif ph_data_dir is not None:
+                    self.pot = PseudoHamiltonian.from_xml_dir(mol.charges, self.ecp_type, self.ecp_mask, ph_data_dir)
+                else:
+                    raise RuntimeError(f'ecp_type={ecp_type!r} needs the pseudo-Hamiltonian tables: pass `ph_tables=` or '
+                                       '`ph_data_dir=` (the directory of the reference\'s deepqmc/ecp/ph_data/*.xml)')
+            else:
+                self.pot = (GaussianTypeECP.from_tables(mol.charges, self.ecp_mask, ecp_tables) if ecp_tables is not None
+                            else GaussianTypeECP.from_pyscf(mol.charges, self.ecp_type, self.ecp_mask))
             self.ns_valence = self.pot.ns_valence
         else:
             self.ns_valence = np.asarray(mol.charges, np.float64)   # physics.py:127-129

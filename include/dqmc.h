@@ -180,6 +180,21 @@ int dqmc_set_ecp(dqmc_ctx* ctx, int n_terms_loc, const double* loc_host, int n_l
  * from Philox4x32-10 keyed by (seed, nucleus, walker, electron). */
 int dqmc_ecp_rotation(dqmc_ctx* ctx, uint64_t seed, const void* phi);
 
+/* Pseudo-Hamiltonian (reference ecp/pseudo_hamiltonian.py: PseudoHamiltonian.local_potential :173-190,
+ * compute_coefficients_of_differential_operators :192-234, kinetic_term :236-278; replaces load_PH_functions'
+ * XML lookup :73-112 by caller-supplied tables).  `charges_host` of dqmc_create must be the valence charges.
+ *   rv_loc_host, rv_l2_host: double[n_nuc][n_grid] -- r*V_loc(r) (+ Z_eff) and r*V_L2(r) on the regular grid
+ *             linspace(0, r_max, n_grid) (what parse_xml :32-70 returns; linear interpolation, zero beyond r_max);
+ *   mask_host: int32[n_nuc], non-zero = this nucleus carries a PH (rows of the others are ignored).
+ * An all-zero mask or n_grid == 0 switches the PH off.  Afterwards dqmc_local_energy evaluates
+ *   E_kin = sum_i b(r_i).grad_i log|psi| - sum_i tr(A(r_i) Hess_ii) - |Q^T grad|^2,   A = Q Q^T (3x3 per electron),
+ * by seeding the forward-Laplacian lanes with the columns of the Cholesky factors Q (the reference's coordinate
+ * change r = Q v with Q held fixed), adds sum rV_loc(rho)/rho to V_loc, and reports in stats[4], stats[5] and
+ * `grad` the transformed Laplacian, |grad_v|^2 and grad_v = Q^T grad_r (what the reference's kinetic_term returns).
+ * dqmc_psi_grad and the Langevin entry points keep the plain gradient.  Not combinable with a non-local dqmc_set_ecp. */
+int dqmc_set_pseudo_hamiltonian(dqmc_ctx* ctx, int n_grid, double r_max, const double* rv_loc_host,
+                                const double* rv_l2_host, const int32_t* mask_host);
+
 /* n_sub Metropolis sub-steps, in place on the sampler state
  * (sampling/electron_samplers.py:102-138,347-357).
  *   r real[B][N][3], logpsi real[B], sign int32[B], age int32[B], tau real[1] (device).
