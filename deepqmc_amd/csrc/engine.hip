@@ -150,6 +150,7 @@ struct Engine : dqmc_ctx {
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
+  int fused_ablate = 0;
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
   size_t ws_budget = (size_t)32 << 30;   // activation workspace per evaluation chunk (option "ws_budget_mb"); several contexts
@@ -474,6 +475,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
     if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
+    if (s == "fused_ablate") { fused_ablate = value; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
@@ -501,7 +503,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
       fused_dbg = value;
-      if (value && !d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80 + 1024)));
+      if (value && !d_prof) { HIP_TRY(hipMalloc((void**)&d_prof, sizeof(long long) * (9 * ops.size() + 80 + 1024 + 2 * 8192))); HIP_TRY(hipMemsetAsync(d_prof, 0, sizeof(long long) * (9 * ops.size() + 80 + 1024 + 2 * 8192), st)); }
       return DQMC_OK;
     }
     if (s == "fused_lds_kb") { fused2_lds_budget = (size_t)value * 1024; return build_fused_plan(); }
@@ -908,7 +910,7 @@ struct Engine : dqmc_ctx {
             u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
             if ((rb0 + u.d.ma) * 16 <= Rtot && cg * 32 + 32 <= ldw) u.d.flags |= 16;
             // small layers take the lean unit body (kernel_fused2.hip: fused2_unit_lean)
-            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= 8 && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
+            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= dqmc::FUSED_GROUP_QUADS && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
             u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
             level_units.push_back(u);
           }
@@ -978,6 +980,8 @@ struct Engine : dqmc_ctx {
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
     a.B = B; a.WT = fused2_WT; a.wt_shift = fused2_shift; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det;
     a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
+    a.ablate = fused_ablate;
+    a.prof_wg = (fused_dbg & 2) ? d_prof + 9 * ops.size() + 80 + 1024 : nullptr;
     a.scratch_off = (int)((fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real), (int)n_itable)) / sizeof(real));
     a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));
     a.n_it = (int)n_itable;
@@ -1767,7 +1771,7 @@ struct Engine : dqmc_ctx {
       return DQMC_OK;
     }
     if (buf == -3) {   // per-op shader-clock stamps of the fused kernel (workgroup 0)
-      if (!d_prof || n > 9 * ops.size() + 80 + 1024) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
+      if (!d_prof || n > 9 * ops.size() + 80 + 1024 + 2 * 8192) return fail(DQMC_E_ARG, "profile not enabled or size mismatch");
       std::vector<long long> tmp(n);
       HIP_TRY(hipMemcpy(tmp.data(), d_prof, sizeof(long long) * n, hipMemcpyDeviceToHost));
       for (size_t k = 0; k < n; ++k) out[k] = (double)tmp[k];

@@ -60,118 +60,41 @@ template <typename real> __device__ __forceinline__ real act2_value(int act, rea
   return v;
 }
 
-// One unit: MA row blocks x 2 column blocks of y = act(concat(pieces) W + b) (+ residual) on the tile.
-// `pre`: the first quad of B fragments of THIS unit, requested by the previous unit of the wave before its epilogue
-// (so the L2 round trip overlaps that epilogue, the LDS stores and the level barrier); on return it holds the first
-// quad of the wave's next unit (FDesc::next_unit).
+// The B operand (weights) of a unit travels in GROUPS of FUSED_GROUP_QUADS quads of k-steps (x 2 column blocks x 16 bytes per lane).  While the MFMAs of one group run from `cur`, the loads of the next group -- the next four quads of
+// this piece, the first of the next piece, or the first of the wave's NEXT UNIT -- are already in flight into `nxt`, so an
+// L2 round trip (~700 cycles) is covered by 32 MFMAs instead of being paid once per quad.  All loads are unconditional
+// with clamped quad indices (a conditional load makes the compiler copy the loaded registers at the join, which needs
+// the data at once: the earlier four-deep ring waited for every quad it had just requested -- the 448-wide layers ran at
+// 19 k cycles against 7 k of MFMA work).  Quads past the end of a piece re-read its last quad and are not multiplied.
+template <typename real> struct BSet { typename RVec4<real>::type b[FUSED_GROUP_QUADS][2]; };
+
+template <typename real>
+__device__ __forceinline__ void fused2_load_group(BSet<real>& s, const typename RVec4<real>::type* w, int cb1, int qstride, int n_left) {
+  const int last = n_left - 1;
+#pragma unroll
+  for (int dd = 0; dd < FUSED_GROUP_QUADS; ++dd) {
+    const int qi = (dd < last ? dd : last) * qstride;      // wave-uniform clamp
+    s.b[dd][0] = w[qi];
+    s.b[dd][1] = w[qi + cb1];
+  }
+}
+// first group of the unit described by nd (w_off, w_cb1, qstride, quads of its first piece)
+template <typename real>
+__device__ __forceinline__ void fused2_prefetch_unit(const Fused2Args<real>& a, DescPtr nd, BSet<real>& s) {
+  const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + nd->w_off + (threadIdx.x & 63);
+  fused2_load_group<real>(s, nb, nd->w_cb1, nd->qstride, nd->a_nq[0]);
+}
+
+// Epilogue shared by the unit bodies: bias + activation + residual, store to LDS (or HBM for buffers later kernels read).
 template <typename real, int MA>
-__device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d, typename RVec4<real>::type& pre0,
-                                            typename RVec4<real>::type& pre1) {
+__device__ __forceinline__ void fused2_epilogue(const Fused2Args<real>& a, DescPtr d, typename Mfma<real>::acc_t (&acc)[MA][2],
+                                                const real (&bias_v)[2]) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
-  typedef typename Mfma<real>::acc_t acc_t;
   constexpr int NRW = 2;
-  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int lane = threadIdx.x & 63, l15 = lane & 15;
   const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
   const int wtm1 = a.WT - 1;
-  int mrow[MA];
-#pragma unroll
-  for (int x = 0; x < MA; ++x) {
-    const int m = row0 + x * 16 + l15;
-    mrow[x] = m < rtot ? m : row0;                          // dummy rows read a valid row, dropped at the store
-  }
-  acc_t acc[MA][NRW];
-#pragma unroll
-  for (int x = 0; x < MA; ++x)
-#pragma unroll
-    for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
-  const int bias_off = d->bias_off;
-  real bias_v[NRW];
-#pragma unroll
-  for (int y = 0; y < NRW; ++y) {
-    const int col = col_u + y * 16 + l15;
-    bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : (real)0;
-  }
-  const Vec4<real>* wbase = reinterpret_cast<const Vec4<real>*>(a.wpk) + d->w_off + lane;
-  const int cb1 = d->w_cb1, qstride = d->qstride, bcast = d->bcast, n_pieces = d->n_pieces;
-  int q0 = 0;
-  for (int p = 0; p < n_pieces; ++p) {
-    const int base = d->a_base[p], stride = d->a_stride[p], KS = d->a_ks[p], NQ = d->a_nq[p];
-    const bool bc = (bcast >> p) & 1;
-    int ao[MA];
-#pragma unroll
-    for (int x = 0; x < MA; ++x) ao[x] = base + (bc ? (mrow[x] & wtm1) : mrow[x]) * stride + l4;
-    // B fragments: one 16-byte load per lane = 4 consecutive k-steps of one 16-column block (fragment-major,
-    // quad-interleaved packing, engine.hip: pack_fused_weights); a ring of D quads stays in flight to cover
-    // the L2 round trip, A fragments (LDS) run one quad ahead.
-    constexpr int D = 4;
-    const Vec4<real>* wq0 = wbase + (long)q0 * qstride;
-    const Vec4<real>* wq1 = wq0 + cb1;
-    Vec4<real> ring[D][NRW];
-    if (p == 0) {
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) { ring[0][0].v[kk] = pre0[kk]; ring[0][1].v[kk] = pre1[kk]; }
-    } else {
-      ring[0][0] = wq0[0]; ring[0][1] = wq1[0];
-    }
-#pragma unroll
-    for (int dd = 1; dd < D; ++dd) {
-      if (dd < NQ) {                               // wave-uniform; short layers load only what they use
-        ring[dd][0] = wq0[(long)dd * qstride];
-        ring[dd][1] = wq1[(long)dd * qstride];
-      }
-    }
-    real fan[4][MA];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int ks = kk < KS ? kk : KS - 1;
-#pragma unroll
-      for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
-    }
-    for (int q = 0; q < NQ; q += D) {
-#pragma unroll
-      for (int dd = 0; dd < D; ++dd) {
-        if (q + dd < NQ) {                         // wave-uniform
-          Vec4<real> cur[NRW];
-          cur[0] = ring[dd][0]; cur[1] = ring[dd][1];
-          if (q + dd + D < NQ) {
-            ring[dd][0] = wq0[(long)(q + dd + D) * qstride];
-            ring[dd][1] = wq1[(long)(q + dd + D) * qstride];
-          }
-          real fa[4][MA];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {         // A fragments of the next quad (clamped past the end)
-            int ks = (q + dd + 1) * 4 + kk;
-            ks = ks < KS ? ks : KS - 1;
-#pragma unroll
-            for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
-          }
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int x = 0; x < MA; ++x) {
-              acc[x][0] = Mfma<real>::run(fa[kk][x], cur[0].v[kk], acc[x][0]);
-              acc[x][1] = Mfma<real>::run(fa[kk][x], cur[1].v[kk], acc[x][1]);
-            }
-        }
-      }
-    }
-    q0 += NQ;
-  }
-  {
-    const int nu = d->next_unit;                   // request the next unit's first B quad now
-    if (nu > 0) {
-      const DescPtr nd = d + nu;
-      const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + nd->w_off + lane;
-      pre0 = nb[0];
-      pre1 = nb[nd->w_cb1];
-    }
-  }
-  // ---- epilogue: bias + activation + residual, store to LDS (or HBM for buffers later kernels read) ----
   const int flags = d->flags, act = flags & 3;
   const bool dst_global = (flags & 8) != 0;
   const real res_scale = (flags & 4) ? (real)0.70710678118654752440 : (real)1;
@@ -273,112 +196,146 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
   }
 }
 
-// Lean unit for the many SMALL layers (edge MLPs, second layers of the node MLPs): one piece, one row block, at most
-// 8 quads of k-steps (K <= 128), LDS destination, tanh or no activation.  The general unit executes ~700 instructions for
-// such a layer (piece loop, weight ring, double-buffered A fragments, descriptor fields it never needs) around 2-32
-// MFMAs, and with four waves per SIMD sharing the issue slots that instruction count IS its latency; this straight-line
-// version loads every B quad up front (quad 0 arrived with the previous unit) and keeps everything else in registers.
-template <typename real>
-__device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, DescPtr d, typename RVec4<real>::type& pre0,
-                                                 typename RVec4<real>::type& pre1) {
+// One unit: MA row blocks x 2 column blocks of y = act(concat(pieces) W + b) (+ residual) on the tile.
+// `nxt`: on entry the first group of B quads of THIS unit (requested by the previous unit of the wave, so the L2 round
+// trip overlapped that unit's tail, its LDS stores and the level barrier); on return the first group of the wave's next
+// unit (FDesc::next_unit; without one, a harmless re-read of this unit's own first group).
+template <typename real, int MA>
+__device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d, BSet<real>& nxt) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
   typedef typename Mfma<real>::acc_t acc_t;
   typedef typename RVec4<real>::type rv4;
+  constexpr int NRW = 2;
+  const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
+  const int wtm1 = a.WT - 1;
+  int mrow[MA];
+#pragma unroll
+  for (int x = 0; x < MA; ++x) {
+    const int m = row0 + x * 16 + l15;
+    mrow[x] = m < rtot ? m : row0;                          // dummy rows read a valid row, dropped at the store
+  }
+  acc_t acc[MA][NRW];
+#pragma unroll
+  for (int x = 0; x < MA; ++x)
+#pragma unroll
+    for (int y = 0; y < NRW; ++y) acc[x][y] = acc_t{0, 0, 0, 0};
+  const int bias_off = d->bias_off;
+  real bias_v[NRW];
+#pragma unroll
+  for (int y = 0; y < NRW; ++y) {
+    const int col = col_u + y * 16 + l15;
+    bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : (real)0;
+  }
+  const rv4* wbase = reinterpret_cast<const rv4*>(a.wpk) + d->w_off + lane;
+  const int cb1 = d->w_cb1, qstride = d->qstride, bcast = d->bcast, n_pieces = d->n_pieces;
+  // where the group after the last one of this unit comes from
+  const int nu = d->next_unit;
+  const DescPtr nd = d + nu;                                // nu == 0: this unit itself
+  const rv4* nu_w = reinterpret_cast<const rv4*>(a.wpk) + nd->w_off + lane;
+  const int nu_cb1 = nd->w_cb1, nu_qs = nd->qstride, nu_nq = nd->a_nq[0];
+  int q0 = 0;
+  for (int p = 0; p < n_pieces; ++p) {
+    const int base = d->a_base[p], stride = d->a_stride[p], KS = d->a_ks[p], NQ = d->a_nq[p];
+    const bool bc = (bcast >> p) & 1;
+    const bool last_piece = p + 1 == n_pieces;
+    const int nq_next_piece = last_piece ? nu_nq : d->a_nq[last_piece ? p : p + 1];
+    int ao[MA];
+#pragma unroll
+    for (int x = 0; x < MA; ++x) ao[x] = base + (bc ? (mrow[x] & wtm1) : mrow[x]) * stride + l4;
+    real fan[4][MA];                                        // A fragments (LDS) run one quad ahead
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ks = kk < KS ? kk : KS - 1;
+#pragma unroll
+      for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+    }
+    constexpr int G = FUSED_GROUP_QUADS;
+    for (int q = 0; q < NQ; q += G) {
+      BSet<real> cur = nxt;                                 // arrived long ago: register moves, no wait
+      {
+        const bool more = q + G < NQ;                       // wave-uniform selects, then ONE unconditional load sequence
+        const rv4* gw = more ? wbase + (long)(q0 + q + G) * qstride : (last_piece ? nu_w : wbase + (long)(q0 + NQ) * qstride);
+        const int g_cb1 = (more || !last_piece) ? cb1 : nu_cb1, g_qs = (more || !last_piece) ? qstride : nu_qs;
+        const int g_left = more ? NQ - (q + G) : nq_next_piece;
+        fused2_load_group<real>(nxt, gw, g_cb1, g_qs, g_left);
+      }
+#pragma unroll
+      for (int dd = 0; dd < G; ++dd) {
+        if (q + dd < NQ) {                                  // wave-uniform
+          real fa[4][MA];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fa[kk][x] = fan[kk][x];
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {                  // A fragments of the next quad (clamped past the end)
+            int ks = (q + dd + 1) * 4 + kk;
+            ks = ks < KS ? ks : KS - 1;
+#pragma unroll
+            for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
+          }
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int x = 0; x < MA; ++x) {
+              acc[x][0] = Mfma<real>::run(fa[kk][x], cur.b[dd][0][kk], acc[x][0]);
+              acc[x][1] = Mfma<real>::run(fa[kk][x], cur.b[dd][1][kk], acc[x][1]);
+            }
+        }
+      }
+    }
+    q0 += NQ;
+  }
+  fused2_epilogue<real, MA>(a, d, acc, bias_v);
+}
+
+// Lean unit for the many SMALL layers (edge MLPs, second layers of the node MLPs): one piece, one row block, at most
+// FUSED_GROUP_QUADS quads of k-steps, LDS destination, tanh or no activation.  Its whole B operand arrived with the previous
+// unit (`nxt`); the next unit's first group is requested first thing, all A fragments are read up front (clamped
+// addresses, so the loads need no branches and their latency is paid once), then up to 32 MFMAs and the epilogue.
+template <typename real>
+__device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, DescPtr d, BSet<real>& nxt) {
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* smem = reinterpret_cast<real*>(smem_raw);
+  typedef typename Mfma<real>::acc_t acc_t;
   const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
   const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
   const int KS = d->a_ks[0], NQ = d->a_nq[0];
   const int bias_off = d->bias_off;
-  const int col0v = col_u + l15, col1v = col_u + 16 + l15;
-  const bool c0 = col0v < ldw, c1 = col1v < ldw;
-  const real bias0 = (bias_off >= 0 && c0) ? a.w[bias_off + col0v] : (real)0;
-  const real bias1 = (bias_off >= 0 && c1) ? a.w[bias_off + col1v] : (real)0;
-  const rv4* wq = reinterpret_cast<const rv4*>(a.wpk) + d->w_off + lane;
-  const int cb1 = d->w_cb1, qstride = d->qstride;
-  rv4 b0[4], b1[4];
-  b0[0] = pre0; b1[0] = pre1;
+  real bias_v[2];
 #pragma unroll
-  for (int dd = 1; dd < 4; ++dd)
-    if (dd < NQ) { b0[dd] = wq[dd * qstride]; b1[dd] = wq[dd * qstride + cb1]; }
+  for (int y = 0; y < 2; ++y) {
+    const int col = col_u + y * 16 + l15;
+    bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : (real)0;
+  }
+  const BSet<real> cur = nxt;
+  fused2_prefetch_unit<real>(a, d + d->next_unit, nxt);     // next_unit == 0: a re-read of this unit's own group
   const int m = row0 + l15;
   const int ao = d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + l4;
-  acc_t acc0 = acc_t{0, 0, 0, 0}, acc1 = acc_t{0, 0, 0, 0};
-  for (int qb = 0; qb < NQ; qb += 4) {             // batches of 4 quads (NQ <= 8: at most two)
-    rv4 n0[4], n1[4];
-    const bool more = qb + 4 < NQ;
-    if (more) {                                    // request the next batch before this one is multiplied
+  constexpr int G = FUSED_GROUP_QUADS;
+  real fa[G][4];
 #pragma unroll
-      for (int dd = 0; dd < 4; ++dd)
-        if (qb + 4 + dd < NQ) { n0[dd] = wq[(qb + 4 + dd) * qstride]; n1[dd] = wq[(qb + 4 + dd) * qstride + cb1]; }
+  for (int dd = 0; dd < G; ++dd)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int ks = dd * 4 + kk;
+      fa[dd][kk] = smem[ao + (ks < KS ? ks : KS - 1) * 4];
     }
+  acc_t acc[1][2];
+  acc[0][0] = acc_t{0, 0, 0, 0}; acc[0][1] = acc_t{0, 0, 0, 0};
 #pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {
-      if (qb + dd < NQ) {                          // wave-uniform
-        real fa[4];
+  for (int dd = 0; dd < G; ++dd) {
+    if (dd < NQ) {                                          // wave-uniform
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const int ks = (qb + dd) * 4 + kk;
-          fa[kk] = smem[ao + (ks < KS ? ks : KS - 1) * 4];    // clamped past the end: those weights are zero
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          acc0 = Mfma<real>::run(fa[kk], b0[dd][kk], acc0);
-          acc1 = Mfma<real>::run(fa[kk], b1[dd][kk], acc1);
-        }
+      for (int kk = 0; kk < 4; ++kk) {
+        acc[0][0] = Mfma<real>::run(fa[dd][kk], cur.b[dd][0][kk], acc[0][0]);
+        acc[0][1] = Mfma<real>::run(fa[dd][kk], cur.b[dd][1][kk], acc[0][1]);
       }
     }
-    if (more) {
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) { b0[dd] = n0[dd]; b1[dd] = n1[dd]; }
-    }
   }
-  {
-    const int nu = d->next_unit;                   // request the next unit's first B quad now
-    if (nu > 0) {
-      const DescPtr nd = d + nu;
-      const rv4* nb = reinterpret_cast<const rv4*>(a.wpk) + nd->w_off + lane;
-      pre0 = nb[0];
-      pre1 = nb[nd->w_cb1];
-    }
-  }
-  const int flags = d->flags;
-  real o0[4], o1[4];
-#pragma unroll
-  for (int rgi = 0; rgi < 4; ++rgi) { o0[rgi] = acc0[rgi] + bias0; o1[rgi] = acc1[rgi] + bias1; }
-  if ((flags & 3) == 1) {
-#pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) { o0[rgi] = fast_tanh<real>(o0[rgi]); o1[rgi] = fast_tanh<real>(o1[rgi]); }
-  }
-  int me[4];
-  bool rk[4];
-#pragma unroll
-  for (int rgi = 0; rgi < 4; ++rgi) {
-    const int mm = row0 + Mfma<real>::row_of(lane, rgi);
-    rk[rgi] = mm < rtot;
-    me[rgi] = rk[rgi] ? mm : row0;
-  }
-  const int cc0 = c0 ? col0v : col_u, cc1 = c1 ? col1v : col_u;
-  const int res_base = d->res_base;
-  if (res_base >= 0) {
-    const int rs = d->res_stride;
-    const real res_scale = (flags & 4) ? (real)0.70710678118654752440 : (real)1;
-#pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) {
-      o0[rgi] = (smem[res_base + me[rgi] * rs + cc0] + o0[rgi]) * res_scale;
-      o1[rgi] = (smem[res_base + me[rgi] * rs + cc1] + o1[rgi]) * res_scale;
-    }
-  }
-  const int db = d->dst_base, ds = d->dst_stride;
-  if (flags & 16) {
-#pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) { smem[db + me[rgi] * ds + cc0] = o0[rgi]; smem[db + me[rgi] * ds + cc1] = o1[rgi]; }
-  } else {
-#pragma unroll
-    for (int rgi = 0; rgi < 4; ++rgi) {
-      if (rk[rgi] && c0) smem[db + me[rgi] * ds + cc0] = o0[rgi];
-      if (rk[rgi] && c1) smem[db + me[rgi] * ds + cc1] = o1[rgi];
-    }
-  }
+  fused2_epilogue<real, 1>(a, d, acc, bias_v);
 }
 
 // Slater-matrix entries A[(wl, k)][el][mu] = envelope(el; k, mu) * backflow(el; k, mu) for the tile (the arithmetic of
@@ -772,6 +729,7 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   const int w0 = blockIdx.x * a.WT;
   const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
 #if defined(__HIPCC__)
+  if (a.prof_wg && threadIdx.x == 0 && blockIdx.x < 8192) a.prof_wg[2 * blockIdx.x] = (long long)wall_clock64();
   if (a.stagger > 0) {
     // The workgroups that share a CU start together and would walk through the program in lockstep: all in an MFMA-
     // heavy layer at once (each getting a quarter of the matrix pipe), then all in an issue-bound phase with the pipe
@@ -816,15 +774,10 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     __syncthreads();
   }
   DescPtr d = (DescPtr)a.descs + ((const DQMC_UNIFORM int32_t*)a.wave_begin)[wave];
-  typename RVec4<real>::type pre0 = {0, 0, 0, 0}, pre1 = {0, 0, 0, 0};
+  BSet<real> nxt;
   {
     const int fu = ((const DQMC_UNIFORM int32_t*)a.wave_begin)[4 + wave];      // first unit of this wave's list, or -1
-    if (fu >= 0) {
-      const DescPtr nd = (DescPtr)a.descs + fu;
-      const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + nd->w_off + (threadIdx.x & 63);
-      pre0 = nb[0];
-      pre1 = nb[nd->w_cb1];
-    }
+    fused2_prefetch_unit<real>(a, (DescPtr)a.descs + (fu >= 0 ? fu : 0), nxt);  // (no unit: any valid descriptor's weights)
   }
   const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
   int n_d = 0;
@@ -837,16 +790,16 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     } else if (kind == 4) {
       wave_lds_fence();          // chained MLP layer: the rows this wave just stored are the rows it reads next
     } else if (kind == 5) {
-      fused2_unit_lean<real>(a, d, pre0, pre1);
+      fused2_unit_lean<real>(a, d, nxt);
     } else if (kind == 1) {
       if (MA1) {
-        fused2_unit<real, 1>(a, d, pre0, pre1);
+        fused2_unit<real, 1>(a, d, nxt);
       } else {
         const int ma = d->ma;
-        if (ma == 1) fused2_unit<real, 1>(a, d, pre0, pre1);
-        else if (ma == 2) fused2_unit<real, 2>(a, d, pre0, pre1);
-        else if (ma == 3) fused2_unit<real, 3>(a, d, pre0, pre1);
-        else fused2_unit<real, 4>(a, d, pre0, pre1);
+        if (ma == 1) fused2_unit<real, 1>(a, d, nxt);
+        else if (ma == 2) fused2_unit<real, 2>(a, d, nxt);
+        else if (ma == 3) fused2_unit<real, 3>(a, d, nxt);
+        else fused2_unit<real, 4>(a, d, nxt);
       }
     } else {
       fused2_generic<real>(a, (OpPtr)a.ops + d->op, nw);
@@ -856,6 +809,9 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   if (a.mc.enabled) {
     fused2_mc_tail<real>(a, nw, stamp ? a.prof + wave * 256 + n_d + 1 : nullptr);     // every wave list ends with a barrier
   }
+#if defined(__HIPCC__)
+  if (a.prof_wg && threadIdx.x == 0 && blockIdx.x < 8192) a.prof_wg[2 * blockIdx.x + 1] = (long long)wall_clock64();
+#endif
 }
 
 // OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.

@@ -68,6 +68,8 @@ struct FusedBuf {
   long goff;      // byte offset of the buffer in the workspace
 };
 // One entry of a wave's work list; built on the host (engine.hip: build_fused2_plan), read through scalar loads.
+// quads of k-steps per B-operand group of the fused kernel (kernel_fused2.hip: BSet); lean units hold at most one group
+constexpr int FUSED_GROUP_QUADS = 2;
 struct FDesc {
   int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, K <= 128, LDS destination)
   int32_t op;           // scheduled op index (FusedArgs::ops)
@@ -142,6 +144,9 @@ template <typename real> struct Fused2Args {
   int stagger, stagger_div; // start delay of the k-th co-resident workgroup of a CU: k * stagger * 8128 cycles; workgroups per dispatch wave
   FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
+  int ablate;               // profiling only (option "fused_ablate"): bit 0 lean units skip the bias load, bit 1 reuse the prefetched
+                            // B quad for every quad, bit 2 no next-unit prefetch -- WRONG results, timing experiments
+  long long* prof_wg;       // optional constant-rate (100 MHz) stamps of EVERY workgroup: [n_blocks][2] start, end
   LaneInfo li;
   double eps;
 };

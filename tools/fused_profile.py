@@ -8,7 +8,7 @@ from deepqmc_amd.sampling import synthetic_walkers
 from deepqmc_amd.wf import NeuralNetworkWaveFunction
 
 ap = argparse.ArgumentParser(); ap.add_argument('--wt', type=int, default=0); ap.add_argument('--walkers', type=int, default=4096)
-ap.add_argument('--sched', type=int, default=-1); ap.add_argument('--substep', type=int, default=0)
+ap.add_argument('--sched', type=int, default=-1); ap.add_argument('--opt', action='append', default=[]); ap.add_argument('--quiet', type=int, default=0); ap.add_argument('--substep', type=int, default=0)
 args = ap.parse_args()
 h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
 wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cuda:0')
@@ -18,8 +18,11 @@ if args.sched >= 0:
     eng.set_option('fused_sched', args.sched)
 if args.wt:
     eng.set_option('fused_wt', args.wt)
+for o in args.opt:
+    k, v = o.split('='); eng.set_option(k, int(v))
 eng.set_option('fused_dbg', 1)
-eng.set_option('fused_print', 2)
+if not args.quiet:
+    eng.set_option('fused_print', 2)
 r = torch.as_tensor(synthetic_walkers(h, args.walkers).astype(np.float32), device='cuda:0')
 if args.substep:       # whole Metropolis sub-steps: the last three stamps of each wave are the tail (matrices, determinants, accept)
     sg, lg = eng.wf_eval(r)
