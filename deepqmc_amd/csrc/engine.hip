@@ -150,7 +150,6 @@ struct Engine : dqmc_ctx {
   int32_t* d_wpk_off = nullptr;   // per scheduled op: {packed-weight offset, barrier-after flag}
   real* d_wpk = nullptr;
   long long* d_prof = nullptr;
-  int fused_ablate = 0;
   // pair-compact edge buffers (common.h: PAIR_LANES): which buffers carry 8 lanes in Laplacian mode, and the
   // (receiver, sender) of each of their rows (for the lane maps of debug_read)
   size_t ws_budget = (size_t)32 << 30;   // activation workspace per evaluation chunk (option "ws_budget_mb"); several contexts
@@ -475,7 +474,6 @@ struct Engine : dqmc_ctx {
     if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
     if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
-    if (s == "fused_ablate") { fused_ablate = value; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
@@ -929,7 +927,14 @@ struct Engine : dqmc_ctx {
       for (size_t k = 0; k < lists[w].size(); ++k) {
         if (lists[w][k].kind != 1 && lists[w][k].kind != 5) continue;
         if (last_unit < 0) begin[4 + w] = begin[w] + (int32_t)k;
-        else lists[w][last_unit].next_unit = (int32_t)k - last_unit;
+        last_unit = (int)k;
+      }
+      last_unit = -1;
+      for (size_t k = lists[w].size(); k-- > 0;) {     // every unit carries the first-group parameters of the unit after it
+        dqmc::FDesc& u = lists[w][k];
+        if (u.kind != 1 && u.kind != 5) continue;
+        const dqmc::FDesc& nx = last_unit < 0 ? u : lists[w][last_unit];
+        u.nx_w_off = nx.w_off; u.nx_cb1 = nx.w_cb1; u.nx_qstride = nx.qstride; u.nx_nq = nx.a_nq[0];
         last_unit = (int)k;
       }
       flat.insert(flat.end(), lists[w].begin(), lists[w].end());
@@ -980,7 +985,6 @@ struct Engine : dqmc_ctx {
     a.w = d_w; a.wpk = d_wpk; a.itable = d_it; a.ws = d_ws; a.r = r; a.R = R;
     a.B = B; a.WT = fused2_WT; a.wt_shift = fused2_shift; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det;
     a.li = li; a.eps = sys.norm_eps; a.prof = fused_dbg ? d_prof : nullptr;
-    a.ablate = fused_ablate;
     a.prof_wg = (fused_dbg & 2) ? d_prof + 9 * ops.size() + 80 + 1024 : nullptr;
     a.scratch_off = (int)((fused2_lds - (size_t)dqmc::fused2_scratch_bytes(fused2_WT, N, sys.n_det, (int)sizeof(real), (int)n_itable)) / sizeof(real));
     a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));

@@ -199,7 +199,7 @@ __device__ __forceinline__ void fused2_epilogue(const Fused2Args<real>& a, DescP
 // One unit: MA row blocks x 2 column blocks of y = act(concat(pieces) W + b) (+ residual) on the tile.
 // `nxt`: on entry the first group of B quads of THIS unit (requested by the previous unit of the wave, so the L2 round
 // trip overlapped that unit's tail, its LDS stores and the level barrier); on return the first group of the wave's next
-// unit (FDesc::next_unit; without one, a harmless re-read of this unit's own first group).
+// unit (FDesc::nx_*; without one, a harmless re-read of this unit's own first group).
 template <typename real, int MA>
 __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d, BSet<real>& nxt) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
@@ -231,10 +231,8 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
   const rv4* wbase = reinterpret_cast<const rv4*>(a.wpk) + d->w_off + lane;
   const int cb1 = d->w_cb1, qstride = d->qstride, bcast = d->bcast, n_pieces = d->n_pieces;
   // where the group after the last one of this unit comes from
-  const int nu = d->next_unit;
-  const DescPtr nd = d + nu;                                // nu == 0: this unit itself
-  const rv4* nu_w = reinterpret_cast<const rv4*>(a.wpk) + nd->w_off + lane;
-  const int nu_cb1 = nd->w_cb1, nu_qs = nd->qstride, nu_nq = nd->a_nq[0];
+  const rv4* nu_w = reinterpret_cast<const rv4*>(a.wpk) + d->nx_w_off + lane;
+  const int nu_cb1 = d->nx_cb1, nu_qs = d->nx_qstride, nu_nq = d->nx_nq;
   int q0 = 0;
   for (int p = 0; p < n_pieces; ++p) {
     const int base = d->a_base[p], stride = d->a_stride[p], KS = d->a_ks[p], NQ = d->a_nq[p];
@@ -311,7 +309,10 @@ __device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, Desc
     bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : (real)0;
   }
   const BSet<real> cur = nxt;
-  fused2_prefetch_unit<real>(a, d + d->next_unit, nxt);     // next_unit == 0: a re-read of this unit's own group
+  {
+    const typename RVec4<real>::type* nb = reinterpret_cast<const typename RVec4<real>::type*>(a.wpk) + d->nx_w_off + (threadIdx.x & 63);
+    fused2_load_group<real>(nxt, nb, d->nx_cb1, d->nx_qstride, d->nx_nq);      // (the last unit re-reads its own group)
+  }
   const int m = row0 + l15;
   const int ao = d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + l4;
   constexpr int G = FUSED_GROUP_QUADS;

@@ -94,8 +94,9 @@ struct FDesc {
   int32_t res_stride;
   int32_t flags;        // bits 0-1 activation, bit 2 scale by 1/sqrt(2), bit 3 destination in HBM, bit 4 no partial row/column block
   int32_t g_r0, g_col0; // HBM destination: first row / column
-  int32_t next_unit;    // distance (in descriptors) to the next kind-1 descriptor of this wave's list, 0 = none
-  int32_t pad[3];
+  // first weight group of the wave's NEXT unit (of this unit itself when it is the last): the unit requests it before its
+  // own epilogue without touching that unit's descriptor (a dependent scalar load = one more ~250-cycle round trip)
+  int32_t nx_w_off, nx_cb1, nx_qstride, nx_nq;
 };
 static_assert(sizeof(FDesc) == 160, "FDesc is 40 dwords");
 // Metropolis sub-step folded into the fused kernel (N <= 4): propose r' = r + tau xi in the prologue, the K
@@ -144,8 +145,6 @@ template <typename real> struct Fused2Args {
   int stagger, stagger_div; // start delay of the k-th co-resident workgroup of a CU: k * stagger * 8128 cycles; workgroups per dispatch wave
   FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
-  int ablate;               // profiling only (option "fused_ablate"): bit 0 lean units skip the bias load, bit 1 reuse the prefetched
-                            // B quad for every quad, bit 2 no next-unit prefetch -- WRONG results, timing experiments
   long long* prof_wg;       // optional constant-rate (100 MHz) stamps of EVERY workgroup: [n_blocks][2] start, end
   LaneInfo li;
   double eps;
