@@ -142,7 +142,7 @@ struct Engine : dqmc_ctx {
   double* d_acc = nullptr;     // [1] acceptance, then [7] stats, then [7] energy record
   std::vector<real> wtmp;
   // fused value-only plan
-  bool fused_enabled = true;
+  int fused_enabled = 1;      // 0 off, 1 where it is the faster value path (fused_pays), 2 always
   int fused_n_ops = 0, fused_wt_req = 0, fused_dbg = 0, fused_sched_mode = 3, fused_occ_req = 0;
   size_t wpk_cap = 0;
   std::vector<int> f_order, f_level;   // fused schedule: op index and dependency level per slot
@@ -460,7 +460,7 @@ struct Engine : dqmc_ctx {
   // of WT walkers with LDS-resident buffers; buffers read by later ops stay in the workspace.
   int option(const char* name, int value) override {
     const std::string s(name);
-    if (s == "fused") { fused_enabled = value != 0; return DQMC_OK; }
+    if (s == "fused") { fused_enabled = value; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ_req = value; return DQMC_OK; }
     if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
@@ -1156,7 +1156,7 @@ struct Engine : dqmc_ctx {
       return DQMC_OK;
     };
     size_t first_op = 0;
-    if (!laplacian && fused_enabled && fused_n_ops > 0 && fused2_WT > 0) {
+    if (!laplacian && fused_n_ops > 0 && fused2_WT > 0 && (fused_enabled >= 2 || (fused_enabled == 1 && fused_pays(B)))) {
       rc = run_fused2(r, R, B, li);
       if (rc) return rc;
       first_op = (size_t)fused_n_ops;
@@ -1324,6 +1324,10 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
   bool timing_serial() const { return false; }
+  // The LDS-resident kernel is the faster VALUE path for the small systems it was built for (N <= 4: one launch per
+  // Metropolis sub-step) and for small batches of any system (one launch against ~50); for larger systems at large
+  // batch the layered MFMA kernels win (N2 / FermiNet, 4096 walkers: 1.38 ms against 1.61 ms per value pass).
+  bool fused_pays(int B) const { return N <= 4 || B < 1024; }
 
   int wf_eval(const void* r, const void* R, int B, void* logpsi, int32_t* sign) override {
     return run((const real*)r, (const real*)R, B, false, (real*)logpsi, sign, nullptr, nullptr, nullptr);

@@ -259,7 +259,8 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign replaced). */
 int dqmc_last_refined(dqmc_ctx* ctx);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
- * MCMC) with the single LDS-resident kernel instead of one launch per op (0 keeps every
+ * MCMC) with the single LDS-resident kernel instead of one launch per op where that is the faster path
+ * (N <= 4, or fewer than 1024 walkers; 2 = always, 0 = never, which also keeps every
  * activation buffer readable by dqmc_debug_read); "fused_substep" (1): fold propose / determinants /
  * accept of a Metropolis sub-step into that kernel when N <= 4; "fused_wt": walkers per workgroup tile (0 = automatic);
  * "fused_sched" (3: list scheduling under an LDS budget, 2: as late as possible, 1: full dependency
@@ -269,7 +270,7 @@ int dqmc_last_refined(dqmc_ctx* ctx);
  * per value-mode batch of the non-local ECP term; "ws_budget_mb": activation workspace per evaluation
  * (larger batches are split into walker chunks); "lane_compact" (1): 8-lane storage of the edge stream;
  * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never);
- * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 128; "fused_chain" (0): second layers
+ * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 32; "fused_chain" (0): second layers
  * of row-wise MLPs in the same wave as the first (measured slower); "fused_wg_per_cu" (4): LDS share a tile is planned for;
  * "dual_stream" (1): edge stream of the Laplacian pass on a companion HIP stream;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
