@@ -202,6 +202,7 @@ struct Engine : dqmc_ctx {
   double refine_thresh = 16.0;
   bool flag_on = false;
   int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
+  std::vector<std::pair<std::string, int>> twin_opts;
   std::vector<double> w64_h, ecp_loc_h;
   int ecp_loc_nt_h = 0;
   // pseudo-Hamiltonian (dqmc_set_pseudo_hamiltonian): radial tables of the PH nuclei, compacted
@@ -460,6 +461,10 @@ struct Engine : dqmc_ctx {
   // of WT walkers with LDS-resident buffers; buffers read by later ops stay in the workspace.
   int option(const char* name, int value) override {
     const std::string s(name);
+    if (s.rfind("twin.", 0) == 0) {            // an option of the float64 refinement twin (applied when it is created, too)
+      twin_opts.emplace_back(s.substr(5), value);
+      return twin ? twin->option(s.c_str() + 5, value) : DQMC_OK;
+    }
     if (s == "fused") { fused_enabled = value; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ_req = value; return DQMC_OK; }
@@ -1399,6 +1404,7 @@ struct Engine : dqmc_ctx {
           refine = 0;
           return DQMC_OK;
         }
+        for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
         if (rc) { delete t; return rc; }
         t->ws_budget = ws_budget / 2;
         twin = t;
