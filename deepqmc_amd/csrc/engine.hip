@@ -178,6 +178,7 @@ struct Engine : dqmc_ctx {
   hipEvent_t ev_fork = nullptr;
   int fused_stagger_div = 256;
   int fused_stagger = 0;         // option "fused_stagger": start delay between the co-resident workgroups of a CU (x 8128 cycles)
+  int fused_prio = 1;            // option "fused_prio": issue priority rotates among the tiles that share a CU (1: per level, 2: per unit, 0: off)
   int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
   int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
   std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
@@ -477,6 +478,7 @@ struct Engine : dqmc_ctx {
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
     if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
+    if (s == "fused_prio") { fused_prio = value; return DQMC_OK; }
     if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
@@ -995,7 +997,7 @@ struct Engine : dqmc_ctx {
     a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));
     a.n_it = (int)n_itable;
     a.ma1 = fused2_ma1 ? 1 : 0;
-    a.stagger = fused_stagger; a.stagger_div = fused_stagger_div;
+    a.stagger = fused_stagger; a.stagger_div = fused_stagger_div; a.prio_mode = fused_prio;
     if (mc) a.mc = *mc;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)

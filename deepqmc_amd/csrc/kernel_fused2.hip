@@ -783,9 +783,29 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
   int n_d = 0;
   if (stamp) a.prof[wave * 256] = clock64();
+#if defined(__HIPCC__)
+  // The arbiter of a SIMD serves its oldest wave first, so of the four tiles that share a CU the first placed runs at
+  // nearly the speed of a lone tile and the last placed absorbs all the waiting (89 / 101 / 116 / 129 us) -- and the CU runs
+  // three, two, one tile(s) for the last 40 us.  Rotating the issue priority among the co-resident tiles lets them advance
+  // together (workgroup b is the (b / n_cu)-th placed on its CU: dispatch fills the CUs breadth-first).
+  const int prio_slot = a.prio_mode ? (int)(blockIdx.x / (unsigned)a.stagger_div) & 3 : 0;
+  int prio_tick = 0;
+#endif
   for (;; ++d) {
     const int kind = d->kind;
     if (kind == 0) break;
+#if defined(__HIPCC__)
+    if (a.prio_mode && (kind == 2 || a.prio_mode == 2)) {
+      ++prio_tick;
+      const int pv = prio_slot + prio_tick;
+      switch (pv & 3) {            // (the priority is an instruction immediate)
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
+#endif
     if (kind == 2) {
       __syncthreads();
     } else if (kind == 4) {

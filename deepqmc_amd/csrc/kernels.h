@@ -142,6 +142,7 @@ template <typename real> struct Fused2Args {
   int scratch_off;          // LDS offset (in reals) of the per-tile scratch: positions, Jastrow, log|det|, det signs
   int it_off, n_it;         // LDS byte offset and length of the staged int table
   int ma1;                  // every unit is one row block high: launch the specialised kernel
+  int prio_mode;            // 0: hardware default (oldest wave first); 1/2: issue priority rotates among the co-resident workgroups per level / per unit
   int stagger, stagger_div; // start delay of the k-th co-resident workgroup of a CU: k * stagger * 8128 cycles; workgroups per dispatch wave
   FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]

@@ -272,7 +272,9 @@ int dqmc_last_refined(dqmc_ctx* ctx);
  * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never);
  * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 32; "fused_chain" (0): second layers
  * of row-wise MLPs in the same wave as the first (measured slower); "fused_wg_per_cu" (4): LDS share a tile is planned for;
- * "dual_stream" (1): edge stream of the Laplacian pass on a companion HIP stream;
+ * "fused_prio" (1): the co-resident tiles of a CU take turns at the highest issue priority, level by level, instead of the
+ * hardware's oldest-wave-first order (2: unit by unit, 0: off); "dual_stream" (1): edge stream of the Laplacian pass on a
+ * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (16): the trigger of mode 1.
  * Unknown names return DQMC_E_ARG. */
