@@ -71,7 +71,7 @@ struct FusedBuf {
 // quads of k-steps per B-operand group of the fused kernel (kernel_fused2.hip: BSet); lean units hold at most one group
 constexpr int FUSED_GROUP_QUADS = 2;
 struct FDesc {
-  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, K <= 128, LDS destination)
+  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, at most FUSED_GROUP_QUADS quads of k-steps, LDS destination)
   int32_t op;           // scheduled op index (FusedArgs::ops)
   int32_t ma;           // row blocks of the unit (1..4); column blocks are always 2
   int32_t n_pieces;
