@@ -1447,6 +1447,7 @@ struct Engine : dqmc_ctx {
   //   nl [n_nuc][n_l][2][n_t_nl] channels l = 0..n_l-1; nuclei whose block is all zero have no non-local part
   int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) override {
     if (n_t_loc < 0 || n_l < 0 || n_t_nl < 0) return fail(DQMC_E_ARG, "negative ECP table size");
+    if (ph_n && nl && n_l > 0 && n_t_nl > 0) return fail(DQMC_E_ARG, "a pseudo-Hamiltonian and a non-local Gaussian ECP cannot both be set");
     HIP_TRY(hipStreamSynchronize(st));
     if (d_ecp_loc) { HIP_TRY(hipFree(d_ecp_loc)); d_ecp_loc = nullptr; }
     if (d_ecp_nl) { HIP_TRY(hipFree(d_ecp_nl)); d_ecp_nl = nullptr; }
