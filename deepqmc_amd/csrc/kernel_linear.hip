@@ -351,17 +351,15 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
     }
     // Laplacian-mode batches of a few hundred walkers (the float64 refinement pass, small evaluation batches) would
     // occupy a fraction of the 256 CUs with the 16-groups-per-workgroup tiles: shrink the tile until >= 512 workgroups
-    case 8: {
-      const long wg4 = ((long)a.B * a.nrows + 31) / 32 * ((a.ldw + 63) / 64);
-      if (wg4 >= 512) launch_nr<real, 4, -1>(st, a);
-      else if (wg4 >= 256) launch_nr<real, 2, -1>(st, a);
-      else launch_nr<real, 1, -1>(st, a);
-      break;
-    }
+    // Laplacian-mode layers of the small systems (8-lane pair-compact edge rows; 16 lanes = up to 4 electrons).  These
+    // layers are narrow (K, N <= 448 / 128) and stream their rows from HBM once: what they need is MANY workgroups in
+    // flight, not tall tiles.  Measured at 4096 LiH walkers: 64-row tiles for the narrow layers and 128-row x 128-column
+    // tiles (8 waves) for the wide ones take the whole E_loc pass from 2.06 to 1.80 ms against the 256-row tiles that suit
+    // the large GEMMs of the bigger systems; small batches (the float64 refinement pass) get the small tiles anyway.
+    case 8: launch_nr<real, 1, -1>(st, a); break;
     case 16: {
-      const long wg4 = ((long)a.B * a.nrows + 15) / 16 * ((a.ldw + 63) / 64);
-      if (wg4 >= 512) launch_nr<real, 4, 4>(st, a);
-      else if (wg4 >= 256) launch_nr<real, 2, 2>(st, a);
+      const long wg2 = ((long)a.B * a.nrows + 7) / 8 * ((a.ldw + 127) / 128);      // workgroups of the 128 x 128 tiling
+      if (a.ldw > 64 && wg2 >= 256) launch_nr<real, 2, 2>(st, a);
       else launch_nr<real, 1, 1>(st, a);
       break;
     }
