@@ -60,8 +60,20 @@ class MolecularHamiltonian:
                 elif ph_data_dir is not None:
                     self.pot = PseudoHamiltonian.from_xml_dir(mol.charges, self.ecp_type, self.ecp_mask, ph_data_dir)
                 else:
-                    raise RuntimeError(f'ecp_type={ecp_type!r} needs the pseudo-Hamiltonian tables: pass `ph_tables=` or '
-                                       '`ph_data_dir=` (the directory of the reference\'s deepqmc/ecp/ph_data/*.xml)')
+                    # the reference reads <deepqmc package>/ecp/ph_data (pseudo_hamiltonian.py:91-93): use that directory when
+                    # the reference package is installed next to this one, or the DEEPQMC_PH_DATA environment variable
+                    import importlib.util
+                    import os
+                    cand = os.environ.get('DEEPQMC_PH_DATA')
+                    if cand is None:
+                        spec = importlib.util.find_spec('deepqmc')
+                        if spec is not None and spec.submodule_search_locations:
+                            cand = os.path.join(list(spec.submodule_search_locations)[0], 'ecp', 'ph_data')
+                    if cand is None or not os.path.isdir(cand):
+                        raise RuntimeError(f'ecp_type={ecp_type!r} needs the pseudo-Hamiltonian tables: pass `ph_tables=` or '
+                                           '`ph_data_dir=` (the directory of the reference\'s deepqmc/ecp/ph_data/*.xml), or set '
+                                           'DEEPQMC_PH_DATA')
+                    self.pot = PseudoHamiltonian.from_xml_dir(mol.charges, self.ecp_type, self.ecp_mask, cand)
             else:
                 self.pot = (GaussianTypeECP.from_tables(mol.charges, self.ecp_mask, ecp_tables) if ecp_tables is not None
                             else GaussianTypeECP.from_pyscf(mol.charges, self.ecp_type, self.ecp_mask))

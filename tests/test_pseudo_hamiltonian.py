@@ -139,3 +139,14 @@ def test_hip_pseudo_hamiltonian_f32_and_refinement_twin():
     the twin must carry the same tables and agree to output rounding."""
     _hip_vs_oracle('paulinet', [True, True], dtype=torch.float32, refine=0, tol=2e-4)
     _hip_vs_oracle('paulinet', [True, True], dtype=torch.float32, refine=2, tol=2e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PH_DATA), reason='reference pseudo-Hamiltonian tables not present')
+def test_reference_tables_through_the_facade(monkeypatch):
+    """`ecp_type='PHcc'` with the reference's own XML directory (environment variable, as a maintainer without the
+    deepqmc package on the path would set it): HCl keeps 7 + 1 valence electrons, the tables land on the reference's grid."""
+    monkeypatch.setenv('DEEPQMC_PH_DATA', REF_PH_DATA)
+    mol = Molecule(coords=np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 2.4]]), charges=np.array([17, 1]), charge=0, spin=0)
+    h = MolecularHamiltonian(mol=mol, ecp_type='PHcc')
+    assert h.ecp_mask.tolist() == [True, False] and h.ns_valence.tolist() == [7.0, 1.0] and (h.n_up, h.n_down) == (4, 4)
+    assert h.pot.rv_loc.shape == (2, 10001) and h.pot.r_max == 10.0 and not h.pot.rv_l2[1].any()
