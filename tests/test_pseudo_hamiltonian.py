@@ -150,3 +150,21 @@ def test_reference_tables_through_the_facade(monkeypatch):
     h = MolecularHamiltonian(mol=mol, ecp_type='PHcc')
     assert h.ecp_mask.tolist() == [True, False] and h.ns_valence.tolist() == [7.0, 1.0] and (h.n_up, h.n_down) == (4, 4)
     assert h.pot.rv_loc.shape == (2, 10001) and h.pot.r_max == 10.0 and not h.pot.rv_l2[1].any()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PH_DATA), reason='reference pseudo-Hamiltonian tables not present')
+def test_hip_hcl_with_the_reference_chlorine_table(monkeypatch):
+    """End to end on a molecule the reference's tables cover: HCl with the OPH23 chlorine pseudo-Hamiltonian (7 valence
+    electrons on Cl), 8 electrons, float64, HIP path (emulated) against the oracle restatement on the reference's grid."""
+    monkeypatch.setenv('DEEPQMC_PH_DATA', REF_PH_DATA)
+    mol = Molecule(coords=np.array([[0.0, 0.0, 0.0], [0.0, 0.0, 2.4]]), charges=np.array([17, 1]), charge=0, spin=0)
+    h = MolecularHamiltonian(mol=mol, ecp_type='PHcc')
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(0, perturb_envelopes=0.1)
+    r = synthetic_walkers(h, 1, seed=3)
+    e, stats = wf.engine(params).local_energy(torch.as_tensor(r))
+    e_ref, st, _ = oph.local_energy(owf.to_torch(params), wf.spec, T(r[0]), T(mol.coords), T(h.ns_valence), h.n_up, [True, False],
+                                    T(h.pot.rv_loc), T(h.pot.rv_l2), h.pot.r_max, geom.F32_EPS)
+    np.testing.assert_allclose(float(e[0]), float(e_ref), rtol=1e-8)
+    for key in ('hamil/E_kin', 'hamil/V_loc', 'hamil/lap', 'hamil/quantum_force'):
+        np.testing.assert_allclose(float(stats[key][0]), float(st[key]), rtol=1e-8, atol=1e-8, err_msg=key)
