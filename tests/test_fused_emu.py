@@ -73,10 +73,19 @@ def test_plan_variants_agree():
     eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     rt = torch.as_tensor(make_walkers(mol, h.n_elec, 6))
     s0, l0 = eng.wf_eval(rt)
-    for opt, val in (('fused_lean', 0), ('fused_chain', 1)):
+    for opt, val in (('fused_lean', 0), ('fused_chain', 1), ('fused_prio', 0), ('fused_prio', 2), ('fused', 2)):
         eng.set_option(opt, val)
         s1, l1 = eng.wf_eval(rt)
         np.testing.assert_array_equal(s1.numpy(), s0.numpy())
         np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=1e-13, atol=1e-13)
     eng.set_option('fused_lean', 1)
     eng.set_option('fused_chain', 0)
+    eng.set_option('fused_prio', 1)
+    eng.set_option('fused', 1)
+    # "fused" = 1 picks the LDS-resident kernel only where it is the faster value path: not for larger systems at large batch
+    # (the layered kernels run then: same psi to float64 round-off)
+    eng.set_option('fused', 0)
+    s2, l2 = eng.wf_eval(rt)
+    np.testing.assert_array_equal(s2.numpy(), s0.numpy())
+    np.testing.assert_allclose(l2.numpy(), l0.numpy(), rtol=1e-12, atol=1e-12)
+    eng.set_option('fused', 1)
