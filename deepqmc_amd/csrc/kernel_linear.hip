@@ -365,7 +365,7 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
       else launch_nr<real, 1, 1>(st, a);
       break;
     }
-    case 32: launch_nr<real, 4, 2>(st, a); break;
+    case 32: launch_nr<real, 2, 1>(st, a); break;      // (H2O / PauliNet, 4096 walkers: E_loc-only +3 % against <4, 2>)
     case 48: launch_nr<real, 3, 1>(st, a); break;
     case 64: launch_nr<real, 4, 1>(st, a); break;
     case 96: launch_nr<real, 6, 1>(st, a); break;
