@@ -63,14 +63,28 @@ def _opaque_class(module, name):
 _SAFE_BUILTINS = {'dict', 'list', 'tuple', 'set', 'frozenset', 'complex', 'slice', 'range', 'bytearray', 'bytes', 'int', 'float', 'bool', 'str'}
 
 
+# Exact (module, name) pairs a NumPy array / scalar / dtype pickle refers to (NumPy 1.x and 2.x module paths).  Nothing
+# else of NumPy is reachable: `np.load`, `np.save`, `np.fromfile` ... are callables like any other.
+_NUMPY_CORE = ('numpy.core.multiarray', 'numpy._core.multiarray', 'numpy.core.numeric', 'numpy._core.numeric')
+_SAFE_NUMPY = ({('numpy', 'ndarray'), ('numpy', 'dtype')}
+               | {(m, n) for m in _NUMPY_CORE[:2] for n in ('_reconstruct', 'scalar', '_frombuffer')}
+               | {(m, '_frombuffer') for m in _NUMPY_CORE[2:]})
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
+        # protocol >= 4 resolves dotted names attribute by attribute ('builtins.eval' under any allowed module):
+        # no legitimate entry of a checkpoint has one
+        if '.' in name:
+            raise pickle.UnpicklingError(f'refusing dotted name {module}:{name} in a checkpoint')
         if module == 'numpy' or module.startswith('numpy.'):
-            if name in ('ndarray', 'dtype', '_reconstruct', 'scalar', '_frombuffer') or module in ('numpy.dtypes',):
+            if (module, name) in _SAFE_NUMPY:
                 return super().find_class(module, name)
-            if module in ('numpy.core.multiarray', 'numpy._core.multiarray', 'numpy.core.numeric', 'numpy._core.numeric'):
-                return super().find_class(module, name)
-            return getattr(np, name)
+            if module == 'numpy.dtypes' and name.endswith('DType') and name.isidentifier():
+                cls = getattr(np.dtypes, name, None)
+                if isinstance(cls, type) and issubclass(cls, np.dtype):
+                    return cls
+            raise pickle.UnpicklingError(f'refusing {module}.{name} in a checkpoint')
         if module in ('jax._src.array', 'jax.interpreters.xla', 'jaxlib.xla_extension') and name == '_reconstruct_array':
             return _reconstruct_array
         if module == 'deepqmc.types' and name == 'TrainState':
@@ -79,10 +93,12 @@ class _Unpickler(pickle.Unpickler):
             return Psi
         if module == 'collections' and name in ('OrderedDict', 'defaultdict', 'deque'):
             return super().find_class(module, name)
+        if (module, name) == ('_codecs', 'encode'):      # how protocol <= 2 spells a bytes object (str -> bytes, no side effects)
+            return super().find_class(module, name)
         if module == 'builtins' and name in _SAFE_BUILTINS:
             return super().find_class(module, name)
-        if module == 'builtins':
-            raise pickle.UnpicklingError(f'refusing builtins.{name} in a checkpoint')
+        if module in ('builtins', '__builtin__'):
+            raise pickle.UnpicklingError(f'refusing {module}.{name} in a checkpoint')
         return _opaque_class(module, name)
 
 

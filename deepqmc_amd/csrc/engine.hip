@@ -131,7 +131,7 @@ struct Engine : dqmc_ctx {
   char* d_ws = nullptr;
   size_t ws_bytes = 0;
   std::vector<size_t> buf_off;  // byte offsets for the current (B, TP)
-  size_t off_logdet = 0, off_signk = 0, off_z = 0;
+  size_t off_logdet = 0, off_signk = 0, off_z = 0, off_cond = 0, off_kappa = 0;
   int split_bcast = 1;           // option "split_bcast": per-walker pieces of a linear layer multiplied once per walker
   int last_B = 0;
   // mcmc scratch
@@ -201,6 +201,7 @@ struct Engine : dqmc_ctx {
   // re-evaluated by a float64 twin of this context and their results replace the float32 ones
   int refine = 1;
   double refine_thresh = 16.0;
+  double refine_cond = 0.0;      // > 0: walkers whose conditioning record (kernels_head.hip) exceeds it are refined as well
   bool flag_on = false;
   int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
   std::vector<std::pair<std::string, int>> twin_opts;
@@ -488,6 +489,7 @@ struct Engine : dqmc_ctx {
       return build_fused_plan();
     }
     if (s == "refine") { refine = value; return DQMC_OK; }
+    if (s == "refine_cond") { if (value < 0) return fail(DQMC_E_ARG, "refine_cond must be >= 0"); refine_cond = (double)value; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
@@ -1071,6 +1073,8 @@ struct Engine : dqmc_ctx {
     }
     off_logdet = bump(sizeof(double) * (size_t)B * sys.n_det * TP);
     off_signk = bump(sizeof(int32_t) * (size_t)B * sys.n_det);
+    off_cond = bump(sizeof(double) * (size_t)B * sys.n_det);      // conditioning record per determinant (Laplacian mode)
+    off_kappa = bump(sizeof(double) * (size_t)B);                 // ... and its psi-weighted sum per walker
     if (ph_n && TP > 1) off_phq = bump(sizeof(double) * (size_t)B * N * dqmc::PH_STRIDE);
     if (off > ws_bytes) {
       if (d_ws) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ws)); d_ws = nullptr; ws_bytes = 0; }
@@ -1295,7 +1299,8 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_SLOGDET:
           t_begin("slogdet", 0);
           dqmc::launch_slogdet<real>(st, bptr(i[0]), bufs[i[0]].width, reinterpret_cast<double*>(d_ws + off_logdet),
-                                     reinterpret_cast<int32_t*>(d_ws + off_signk), B, sys.n_det, li, slogdet_mfma);
+                                     reinterpret_cast<int32_t*>(d_ws + off_signk), B, sys.n_det, li, slogdet_mfma,
+                                     laplacian ? reinterpret_cast<double*>(d_ws + off_cond) : nullptr);
           t_end();
           break;
         case DQMC_OP_FINAL: {
@@ -1314,6 +1319,7 @@ struct Engine : dqmc_ctx {
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
           a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
           a.phq = phq;
+          if (laplacian) { a.cond = reinterpret_cast<double*>(d_ws + off_cond); a.kappa_out = reinterpret_cast<double*>(d_ws + off_kappa); a.refine_cond = refine_cond; }
           if (flag_on && laplacian) { a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset; }
           t_begin("final", 0);
           dqmc::launch_final<real>(st, a);
@@ -1785,6 +1791,11 @@ struct Engine : dqmc_ctx {
       const size_t cnt = (size_t)last_B * sys.n_det * last_TP;
       if (n != cnt) return fail(DQMC_E_ARG, "size mismatch");
       HIP_TRY(hipMemcpy(out, d_ws + off_logdet, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+      return DQMC_OK;
+    }
+    if (buf == -4) {   // conditioning record per walker of the last Laplacian-mode evaluation
+      if (n != (size_t)last_B || last_TP == 1) return fail(DQMC_E_ARG, "size mismatch or no Laplacian-mode evaluation");
+      HIP_TRY(hipMemcpy(out, d_ws + off_kappa, sizeof(double) * n, hipMemcpyDeviceToHost));
       return DQMC_OK;
     }
     if (buf == -3) {   // per-op shader-clock stamps of the fused kernel (workgroup 0)

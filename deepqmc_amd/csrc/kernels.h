@@ -181,7 +181,7 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
                      int n_up, int n_nuc, int n_env, int K, LaneInfo li, double eps, const double* phq = nullptr);
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
-                    LaneInfo li, int use_mfma);
+                    LaneInfo li, int use_mfma, double* cond = nullptr);
 struct FinalArgs {
   const void* r;          // real[B][N][3]
   const void* R;          // real[n_nuc][3]
@@ -213,6 +213,11 @@ struct FinalArgs {
   int32_t* flag_idx;
   double refine_thresh;
   int b_offset;
+  // conditioning record of the determinant kernels (kernels_head.hip: slogdet_cond), [B][K], or nullptr; walkers whose
+  // weighted record sum_k |p_k| kappa_k exceeds refine_cond (> 0) are flagged as well; kappa_out [B] receives it (debug)
+  const double* cond;
+  double refine_cond;
+  double* kappa_out;
   // pseudo-Hamiltonian (ecp/pseudo_hamiltonian.py): per-(walker, electron) factors [B][N][PH_STRIDE] the derivative
   // lanes were seeded with (and the electron's share of the local PH potential); nullptr = ordinary kinetic energy
   const double* phq;

@@ -131,6 +131,14 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
   for (int t = li.T; t < li.TP; ++t) orow[(long)t * orb_width] = (real)0;
 }
 
+// Conditioning record of the Laplacian-mode determinant kernels (float32 build: what the refinement keys on besides
+// the node cancellation): kappa = (1/N) sum_ij |A_ij| |(A^-1)_ji|, the sum of the MAGNITUDES of the terms of
+// tr(A^-1 A) = N.  It bounds the response of log|det A| -- and, with dA_c in place of A, of the derivative traces --
+// to a relative perturbation eps of every matrix entry (|d log det| <= eps N kappa), is 1 for a diagonal matrix and,
+// unlike |A| |A^-1|, does not change when rows or columns are rescaled (envelopes decaying at different rates).
+// float32 orbitals carry eps ~ 6e-8 per entry: kappa ~ 1e4..1e6 (random-init TransPsiformer) means float32 cannot
+// deliver 1e-5 on E_loc whatever the kernels do.
+
 // slogdet of one N x N matrix per wave plus its forward-Laplacian lanes:
 //   J_c = tr(A^-1 dA_c),   L = tr(A^-1 A_L) - sum_c tr((A^-1 dA_c)^2)        
 // Gauss-Jordan with partial pivoting in LDS (double), sign = (-1)^swaps * prod sign(pivot)
@@ -139,7 +147,7 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
 template <typename real, int NMAX>
 __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, int orb_width,
                                                 double* __restrict__ logdet, int32_t* __restrict__ sign_k, int K,
-                                                LaneInfo li) {
+                                                LaneInfo li, double* __restrict__ cond) {
   __shared__ double A[NMAX * NMAX];
   __shared__ double Inv[NMAX * NMAX];
   __shared__ double M[NMAX * NMAX];
@@ -200,6 +208,15 @@ __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, in
     sign_k[bk] = sgn;
   }
   if (li.T == 1) return;
+  if (cond) {      // componentwise condition number of the matrix (comment above k_slogdet)
+    double c = 0.0;
+    for (int e = lane; e < NN; e += 64) {
+      const int i = e / N, j = e - i * N;
+      c += fabs((double)base[e]) * fabs(Inv[j * N + i]);
+    }
+    c = wave_sum<double>(c);
+    if (lane == 0) cond[bk] = c / N;
+  }
   double tr2_sum = 0.0;
   for (int t = 1; t < li.T; ++t) {
     const real* At = base + (long)t * orb_width;
@@ -253,7 +270,7 @@ __device__ __forceinline__ Mfma<double>::acc_t slogdet_tile_mm(const double (&fa
 template <typename real>
 __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ orb, int orb_width,
                                                       double* __restrict__ logdet, int32_t* __restrict__ sign_k,
-                                                      LaneInfo li) {
+                                                      LaneInfo li, double* __restrict__ cond) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   const int N = li.N, NN = N * N, T = li.T;
   const int nt = (N + 15) / 16, N16 = nt * 16, NS = N16 + 1;
@@ -318,6 +335,18 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
   if (tid == 0) {
     logdet[bk * li.TP] = logabs;
     sign_k[bk] = sgn;
+  }
+  if (cond) {      // kappa = sum |A_ij| |(A^-1)_ji| / N; colp is free after the elimination
+    double c = 0.0;
+    for (int e = tid; e < NN; e += nthr) {
+      const int i = e / N, j = e - i * N;
+      c += fabs((double)base[e]) * fabs(Inv[j * NS + i]);
+    }
+    c = wave_sum<double>(c);
+    if (lane == 0) colp[wave] = c;
+    __syncthreads();
+    if (tid == 0) cond[bk] = (colp[0] + colp[1] + colp[2] + colp[3]) / N;
+    __syncthreads();
   }
   double tr2_sum = 0.0;
   typedef Mfma<double>::acc_t acc_t;
@@ -452,7 +481,7 @@ __global__ void __launch_bounds__(64) k_slogdet_lu(const real* __restrict__ orb,
 template <typename real, int N>
 __global__ void __launch_bounds__(256) k_slogdet_small(const real* __restrict__ orb, int orb_width,
                                                        double* __restrict__ logdet, int32_t* __restrict__ sign_k,
-                                                       long n_mat, LaneInfo li) {
+                                                       long n_mat, LaneInfo li, double* __restrict__ cond) {
   const long bk = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (bk >= n_mat) return;
   const real* base = orb + bk * li.TP * orb_width;
@@ -501,6 +530,14 @@ __global__ void __launch_bounds__(256) k_slogdet_small(const real* __restrict__ 
   logdet[bk * li.TP] = logabs;
   sign_k[bk] = sgn;
   if (li.T == 1) return;
+  if (cond) {
+    double c = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+      for (int j = 0; j < N; ++j) c += fabs((double)base[i * N + j]) * fabs(Inv[j][i]);
+    cond[bk] = c / N;
+  }
   double tr2_sum = 0.0;
   for (int t = 1; t < li.T; ++t) {
     const real* At = base + (long)t * orb_width;
@@ -635,6 +672,13 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
     lap += pk * (x[(long)k * TP + T - 1] + s2);
   }
   lap = grp16_sum(lap);
+  // conditioning of the determinants that carry psi: sum_k |p_k| kappa_k (kernels above)
+  double kappa = 0.0;
+  if (a.cond) {
+    for (int k = l; k < K; k += 16)
+      kappa += fabs((cc ? (double)cc[k] : 1.0) * exp(x[(long)k * TP] - shift) / psi) * (sk[k] ? a.cond[(long)b * K + k] : 0.0);
+    kappa = grp16_sum(kappa);
+  }
   // per derivative lane (lanes over t): g_t = sum_k p_k J_kt (+ Jastrow + cusp gradients)
   real* grad = reinterpret_cast<real*>(a.grad);
   double sumJ2 = 0.0, qf2 = 0.0, first_order = 0.0;
@@ -714,8 +758,10 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.flag_idx) {      // float32 build: hand ill-conditioned walkers to the float64 refinement pass
     const double ratio = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc));
-    if (!(ratio <= a.refine_thresh)) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;
+    const bool ill = a.cond && a.refine_cond > 0 && !(kappa <= a.refine_cond);
+    if (!(ratio <= a.refine_thresh) || ill) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;
   }
+  if (a.kappa_out) a.kappa_out[b] = kappa;
   if (a.stats) {
     real* s = reinterpret_cast<real*>(a.stats);
     s[0L * a.stats_ld + b] = (real)v_el;
@@ -740,36 +786,36 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
 // N > 8 on, 0 = never
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
-                    LaneInfo li, int use_mfma) {
+                    LaneInfo li, int use_mfma, double* cond) {
   const int slogdet_use_mfma = use_mfma;
   const unsigned grid = (unsigned)((long)B * K);
   const long n_mat = (long)B * K;
   const unsigned gsm = (unsigned)((n_mat + 255) / 256);
   if (li.N == 2)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 2>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
-                       sign_k, n_mat, li);
+                       sign_k, n_mat, li, cond);
   else if (li.N == 3)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 3>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
-                       sign_k, n_mat, li);
+                       sign_k, n_mat, li, cond);
   else if (li.N == 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 4>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
-                       sign_k, n_mat, li);
+                       sign_k, n_mat, li, cond);
   else if (li.T == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu<real>), dim3(grid), dim3(64), sizeof(double) * li.N * (li.N | 1), st,
                        orb, orb_width, logdet, sign_k, li);
   else if (li.N <= 48 && ((slogdet_use_mfma == 1 && li.N > 16) || (slogdet_use_mfma >= 2 && li.N > 8)))     // >= 2 x 2 tiles (14 x 14: the wave-per-matrix kernel is faster); N16 <= 48: 57 KB of LDS
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_mfma<real>), dim3(grid), dim3(256),
                        sizeof(double) * ((size_t)3 * (((li.N + 15) / 16) * 16) * ((((li.N + 15) / 16) * 16) + 1) + (((li.N + 15) / 16) * 16) + 16),
-                       st, orb, orb_width, logdet, sign_k, li);
+                       st, orb, orb_width, logdet, sign_k, li, cond);
   else if (li.N <= 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
-                       sign_k, K, li);
+                       sign_k, K, li, cond);
   else if (li.N <= 16)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 16>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
-                       sign_k, K, li);
+                       sign_k, K, li, cond);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 44>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
-                       sign_k, K, li);
+                       sign_k, K, li, cond);
 }
 
 template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
@@ -780,7 +826,8 @@ template <typename real> void launch_final(hipStream_t st, const FinalArgs& a) {
   template void launch_orbitals<real>(hipStream_t, const real*, const real*, const real*, int, real*, int,           \
                                       const real*, const real*, const real*, const real*, int, int, int, int, int,   \
                                       LaneInfo, double, const double*);                                              \
-  template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo, int);     \
+  template void launch_slogdet<real>(hipStream_t, const real*, int, double*, int32_t*, int, int, LaneInfo, int,  \
+                                     double*);                                                                   \
   template void launch_final<real>(hipStream_t, const FinalArgs&);
 DQMC_INST(float)
 DQMC_INST(double)

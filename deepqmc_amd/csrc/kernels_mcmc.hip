@@ -308,7 +308,9 @@ __global__ void __launch_bounds__(256) k_exchange_propose(const real* __restrict
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)B * N) return;
   const int b = (int)(idx / N), i = (int)(idx - (long)b * N);
-  const int u = up_idx[b], d = n_up + down_idx[b];
+  // indices are clamped into their spin blocks: a caller's out-of-range choice can never read outside r
+  const int n_dn = N - n_up, ui = up_idx[b], di = down_idx[b];
+  const int u = ui < 0 ? 0 : (ui >= n_up ? n_up - 1 : ui), d = n_up + (di < 0 ? 0 : (di >= n_dn ? n_dn - 1 : di));
   const int src = i == u ? d : (i == d ? u : i);
   for (int c = 0; c < 3; ++c) r_prop[idx * 3 + c] = r[((long)b * N + src) * 3 + c];
 }

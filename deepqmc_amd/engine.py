@@ -259,6 +259,10 @@ class Engine:
     def exchange_step(self, state, up_idx, down_idx, unif, R=None, return_accept=False):
         """One opposite-spin exchange step, in place on state {'r','log','sign','age','tau'} (dqmc_exchange_step)."""
         B = self._check_state(state, ('r', 'log', 'sign', 'age', 'tau'))
+        for name, idx, n in (('up_idx', up_idx, self.hamil.n_up), ('down_idx', down_idx, self.hamil.n_down)):
+            host = idx if isinstance(idx, np.ndarray) else (idx if isinstance(idx, torch.Tensor) and idx.device.type == 'cpu' else None)
+            if host is not None and len(host) and (int(host.min()) < 0 or int(host.max()) >= n):     # device tensors: clamped in the kernel
+                raise DqmcError(f'{name} must lie in [0, {n})')
         up = torch.as_tensor(up_idx, device=self.device).to(torch.int32).contiguous()
         dn = torch.as_tensor(down_idx, device=self.device).to(torch.int32).contiguous()
         u = self._t(unif)
@@ -272,7 +276,18 @@ class Engine:
         out = dict(zip(SAMPLER_STAT_KEYS, list(stats)))
         return (out, acc) if return_accept else out
 
+    def check_walker_vector(self, name, t, n=None):
+        """A [B] tensor about to cross the C ABI as a raw pointer: dtype, layout and device must be the context's."""
+        if not isinstance(t, torch.Tensor) or t.dtype != self.dtype or not t.is_contiguous() or t.device.type != self.device.type \
+                or t.dim() != 1 or (n is not None and t.shape[0] != n):
+            raise DqmcError(f"'{name}' must be a contiguous 1-d {self.dtype} tensor on {self.device}"
+                            + (f' of length {n}' if n is not None else ''))
+        return t
+
     def energy_record(self, e_loc, w=None):
+        self.check_walker_vector('e_loc', e_loc)
+        if w is not None:
+            self.check_walker_vector('w', w, e_loc.shape[0])
         rec = (ctypes.c_double * 7)()
         self._check(self.lib.dqmc_energy_stats(self._ctx, e_loc.data_ptr(), w.data_ptr() if w is not None else None,
                                                e_loc.shape[0], rec))
@@ -293,6 +308,8 @@ class Engine:
             shape, idx = (B, self.spec.n_determinants, TP), -1
         elif name_or_idx == 'sign_k':
             shape, idx = (B, self.spec.n_determinants), -2
+        elif name_or_idx == 'kappa':      # conditioning record per walker (kernels_head.hip), last Laplacian-mode call
+            shape, idx = (B,), -4
         else:
             idx = self.program.buf_names[name_or_idx] if isinstance(name_or_idx, str) else int(name_or_idx)
             rows, width = self.program.bufs[idx]

@@ -77,6 +77,9 @@ class RcclCommunicator:
 def energy_stats_inlib(engine, e_loc, comm: RcclCommunicator, w=None):
     """`energy_stats` with the collective inside the HIP library (one ncclAllGather on the context's stream)."""
     import ctypes
+    engine.check_walker_vector('e_loc', e_loc)
+    if w is not None:
+        engine.check_walker_vector('w', w, e_loc.shape[0])
     out = (ctypes.c_double * 5)()
     engine._check(engine.lib.dqmc_energy_stats_allgather(engine._ctx, comm.comm, comm.world, e_loc.data_ptr(),
                                                          w.data_ptr() if w is not None else None, e_loc.shape[0], out))

@@ -15,14 +15,20 @@ import torch
 from .types import PhysicalConfiguration, Psi
 
 
-def synthetic_walkers(hamil, n: int, seed: int = 1, std: float = 1.0) -> np.ndarray:
+def synthetic_walkers(hamil, n: int, seed: int = 1, std: float = 1.0, R=None) -> np.ndarray:
     """Atom-centred Gaussian walkers r = R[nucleus] + N(0, std): electrons assigned to nuclei
-    in proportion to charge (BASELINE.md "Inputs").  The reference's shell-based initialiser
+    in proportion to charge (BASELINE.md "Inputs"), around the geometry `R` when one is given
+    (the reference hands R to its initialiser, electron_samplers.py:86-100), else around the
+    Hamiltonian's own.  The reference's shell-based initialiser
     (sampling/electron_sample_initializers.py) is out of scope."""
     rng = np.random.default_rng(seed)
     mol = hamil.mol
     centers = np.repeat(np.arange(len(mol.charges)), mol.charges.astype(int))[:hamil.n_elec]
-    return mol.coords[centers][None] + std * rng.standard_normal((n, hamil.n_elec, 3))
+    if R is None:
+        coords = mol.coords
+    else:
+        coords = np.asarray(R.detach().cpu() if hasattr(R, 'detach') else R, np.float64).reshape(-1, len(mol.charges), 3)[0]
+    return coords[centers][None] + std * rng.standard_normal((n, hamil.n_elec, 3))
 
 
 class MetropolisSampler:
@@ -49,7 +55,8 @@ class MetropolisSampler:
     def init(self, rng, params, n: int, R=None):
         """electron_samplers.py:86-100."""
         eng = self.wf.engine(params, R)
-        r = torch.as_tensor(self.sample_initializer(self.hamil, n, seed=int(rng)), dtype=eng.dtype, device=eng.device)
+        kw = {} if R is None else {'R': R}       # initialisers written for round 1 (no R argument) keep working at the default geometry
+        r = torch.as_tensor(self.sample_initializer(self.hamil, n, seed=int(rng), **kw), dtype=eng.dtype, device=eng.device)
         state = {'r': r.contiguous(), 'age': torch.zeros(n, dtype=torch.int32, device=eng.device),
                  'tau': torch.full((1,), self.initial_tau, dtype=eng.dtype, device=eng.device)}
         return self.update(state, params, R)
@@ -173,7 +180,7 @@ class MultiNuclearGeometrySampler:
 
     def sample(self, rng, smpl_state, params, mol_idxs):
         mol_idxs = [int(m) for m in np.asarray(mol_idxs).reshape(-1)]
-        counter = smpl_state['update_nuc_counter']
+        counter = np.array(smpl_state['update_nuc_counter'], copy=True)      # functional state: the caller's stays as it was
         nuc, elec = list(smpl_state['nuc']), list(smpl_state['elec'])
         pcs, stats = [], []
         for k, m in enumerate(mol_idxs):

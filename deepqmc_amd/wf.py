@@ -34,6 +34,7 @@ class NeuralNetworkWaveFunction:
         self.dtype, self.device, self.norm_eps, self._lib = dtype, device, norm_eps, lib
         self._engines = []       # [(params tree, Engine)], most recently used last (one per electronic state)
         self.max_engines = 8
+        self._evictions = 0
 
     def init(self, rng=0, phys_conf=None, **kw):
         """types.py:121-133.  `rng`: an integer seed (the JAX key stream is not reproduced)."""
@@ -46,7 +47,10 @@ class NeuralNetworkWaveFunction:
         if R is None or not self.spec.nuclei_tokens:
             return None
         import numpy as np
-        R = np.asarray(R.detach().cpu() if hasattr(R, 'detach') else R, np.float64).reshape(self.hamil.n_nuc, 3)
+        R = np.asarray(R.detach().cpu() if hasattr(R, 'detach') else R, np.float64).reshape(-1, self.hamil.n_nuc, 3)
+        if R.shape[0] > 1 and not np.array_equal(R, np.broadcast_to(R[:1], R.shape)):
+            raise ValueError('an ansatz with nuclear tokens takes ONE geometry per call (per-walker geometries differ)')
+        R = np.ascontiguousarray(R[0])
         return None if np.array_equal(R, self.hamil.mol.coords) else R.tobytes()
 
     def engine(self, params, R=None) -> Engine:
@@ -65,7 +69,13 @@ class NeuralNetworkWaveFunction:
             eng.set_params(params)
         else:
             if len(self._engines) >= self.max_engines:
-                self._engines.pop(0)[2].close()
+                # dropped, not closed: a caller may still hold the Engine; its context is released with the last reference
+                self._engines.pop(0)
+                self._evictions += 1
+                if self._evictions == 4 * self.max_engines:
+                    import warnings
+                    warnings.warn(f'NeuralNetworkWaveFunction: {self._evictions} HIP contexts evicted from a cache of '
+                                  f'{self.max_engines}; raise `max_engines` to (geometries x states) in use')
             import numpy as np
             R0 = None if gkey is None else np.frombuffer(gkey, np.float64).reshape(self.hamil.n_nuc, 3)
             eng = Engine(self.spec, self.hamil, params, dtype=self.dtype, device=self.device,

@@ -241,3 +241,24 @@ def test_emu_workspace_chunking():
         np.testing.assert_array_equal(st1[k].numpy(), st0[k].numpy(), err_msg=k)
     np.testing.assert_array_equal(s1.numpy(), s0.numpy())
     np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=1e-12, atol=1e-12)     # fused vs layered value path
+
+
+@pytest.mark.parametrize('spec_fn,molname', [(paulinet, 'LiH'), (ferminet, 'LiH'), (ferminet, 'C')])
+def test_emu_conditioning_record(spec_fn, molname):
+    """The conditioning record the float32 refinement keys on (kernels_head.hip): per determinant
+    kappa_k = sum_ij |A_ij| |(A^-1)_ji| / N, per walker sum_k |p_k| kappa_k with p_k = c_k det_k / psi --
+    from k_slogdet_small (N <= 4) and k_slogdet (N = 5) against NumPy on the orbital buffer (C: 6 electrons, spin 2)."""
+    B = 3
+    spec, mol, h, eng, r, it = _setup(spec_fn, molname, torch.float64, B)
+    eng.local_energy(torch.as_tensor(r))
+    orb = eng.debug_read('orbitals', B)
+    N, K = h.n_elec, spec.n_determinants
+    A = orb[:, :, 0, :N * N].reshape(B, K, N, N)
+    kap = (np.abs(A) * np.abs(np.swapaxes(np.linalg.inv(A), -1, -2))).sum((-1, -2)) / N
+    assert (kap >= 1 - 1e-12).all()
+    sign, logabs = np.linalg.slogdet(A)
+    cc = next((np.asarray(v['w']).reshape(-1) for k, v in
+               init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1).items() if 'conf_coeff' in k), np.ones(K))
+    det = cc[None, :K] * sign * np.exp(logabs - logabs.max(1, keepdims=True))
+    p = det / det.sum(1, keepdims=True)
+    np.testing.assert_allclose(eng.debug_read('kappa', B), (np.abs(p) * kap).sum(1), rtol=1e-9)

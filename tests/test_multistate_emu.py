@@ -179,3 +179,74 @@ def test_multi_geometry_sampler_and_energies():
     np.testing.assert_allclose(ratio[:, 0, 0].numpy(), 1.0, rtol=1e-12)
     idx = MoleculeIdxSampler(0, 3, 2)
     assert [idx.sample().tolist() for _ in range(3)] == [[0, 1], [2, 0], [1, 2]]
+
+
+def test_initial_walkers_follow_each_geometry_and_counters_are_functional():
+    """(a) MetropolisSampler.init hands R to the initialiser (electron_samplers.py:86-100), so the
+    walkers of every geometry of a MultiNuclearGeometrySampler start around THAT geometry; (b) `sample` leaves the
+    caller's update_nuc_counter untouched (functional state)."""
+    from deepqmc_amd.sampling import IdleNucleiSampler, MultiNuclearGeometrySampler
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(0, perturb_envelopes=0.1)
+    shift = np.array([[40.0, 0, 0], [40.0, 0, 0]])
+    Rs = torch.as_tensor(np.stack([h.mol.coords, h.mol.coords + shift]))
+    ms = MultiNuclearGeometrySampler(DecorrSampler(h, wf, length=1, tau=0.2), IdleNucleiSampler(), update_nuc_period=3)
+    state = ms.init(0, params, 64, Rs)
+    for m in range(2):
+        centre = state['elec'][m]['r'].numpy().mean(axis=(0, 1))
+        np.testing.assert_allclose(centre, Rs[m].numpy().mean(0) * 0 + synthetic_walkers(h, 64, seed=0 * 2 + m, R=Rs[m]).mean(axis=(0, 1)), atol=1e-12)
+        assert abs(centre[0] - float(Rs[m][:, 0].mean())) < 2.0            # 40 bohr apart: each ensemble sits on its own molecule
+        assert np.isfinite(state['elec'][m]['psi'].log.numpy()).all()
+    counter0 = state['update_nuc_counter'].copy()
+    new_state, _, _ = ms.sample(1, state, params, [0, 1])
+    np.testing.assert_array_equal(state['update_nuc_counter'], counter0)
+    np.testing.assert_array_equal(new_state['update_nuc_counter'], counter0 + 1)
+
+
+def test_exchange_indices_are_range_checked_and_stat_vectors_validated():
+    from deepqmc_amd.engine import DqmcError
+    import pytest
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(0, perturb_envelopes=0.1)
+    eng = wf.engine(params)
+    B = 3
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=3))
+    sign, log = eng.wf_eval(r)
+    st = {'r': r.clone(), 'log': log, 'sign': sign, 'age': torch.zeros(B, dtype=torch.int32), 'tau': torch.full((1,), 0.3, dtype=torch.float64)}
+    u = torch.full((B,), 0.5, dtype=torch.float64)
+    with pytest.raises(DqmcError):
+        eng.exchange_step(st, np.array([0, 2, 0]), np.array([0, 0, 0]), u)            # n_up = 2: index 2 is out of range
+    with pytest.raises(DqmcError):
+        eng.exchange_step(st, np.array([0, 1, 0]), np.array([0, -1, 0]), u)
+    eng.exchange_step(st, np.array([0, 1, 0]), np.array([1, 0, 1]), u)
+    e = torch.ones(4, dtype=torch.float64)
+    with pytest.raises(DqmcError):
+        eng.energy_record(e.to(torch.float32))
+    with pytest.raises(DqmcError):
+        eng.energy_record(torch.ones(8, dtype=torch.float64)[::2])
+    with pytest.raises(DqmcError):
+        eng.energy_record(e, torch.ones(3, dtype=torch.float64))
+    assert eng.energy_record(e)[0] == 4
+
+
+def test_engine_cache_eviction_keeps_held_engines_alive_and_accepts_tiled_R():
+    """an evicted context is dropped, not closed (a caller may hold it); a per-walker tiled R is a
+    valid geometry key."""
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    R_tiled = torch.as_tensor(np.broadcast_to(h.mol.coords, (2, 2, 3)).copy())
+    assert wf._geometry_key(R_tiled) is None                                     # no nuclear tokens: geometry per call
+    wf.max_engines = 2
+    tree = wf.init(0, perturb_envelopes=0.1)
+    r = torch.as_tensor(synthetic_walkers(h, 2, seed=3))
+    # one context per (tree, geometry), as an ansatz with nuclear tokens has: every new geometry evicts the oldest
+    geoms = [h.mol.coords * f for f in (1.0, 1.1, 1.2, 1.3)]
+    wf._geometry_key = lambda R: np.asarray(R, np.float64).tobytes()
+    held = wf.engine(tree, geoms[0])
+    ref = held.wf_eval(r)[1].clone()
+    for g in geoms[1:]:
+        wf.engine(tree, g).wf_eval(r, torch.as_tensor(g))
+    assert all(e is not held for _, _, e in wf._engines) and held._ctx is not None
+    np.testing.assert_array_equal(held.wf_eval(r)[1].numpy(), ref.numpy())
