@@ -13,7 +13,7 @@ GPU (weak scaling), synthetic walkers and random-init weights, float32.
 
 The walkers of an N-GPU run are the reference's split of ONE global batch of N x `--walkers` walkers
 (`electron_batch_size // device_count`, sampling_utils.py:253-262 -> parallel.shard_bounds).  The timed
-region is `--steps` VMC steps bracketed by barrier + synchronize, repeated back to back until >= 2 s of
+region is `--steps` VMC steps bracketed by barrier + synchronize, repeated back to back until >= 10 s of
 steady state have been measured (at least 10 blocks); `ms_per_step` is the median block (max over ranks
 per block), min / max are reported beside it.
 
@@ -199,7 +199,7 @@ def main():
                     '(library default), 2 whole E_loc pass in float64')
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (dqmc_set_option), repeatable')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
-    ap.add_argument('--min-seconds', type=float, default=2.0, help='steady-state time the timed blocks must cover')
+    ap.add_argument('--min-seconds', type=float, default=10.0, help='steady-state time the timed blocks must cover')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
                     'launch / shard / reduce path without a GPU; the numbers mean nothing)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: print the cpu_baseline JSON object and exit')
@@ -332,6 +332,8 @@ def main():
         stats['overlap/penalty'] = float(pen)
         return state, stats
 
+    refined = []           # walkers re-evaluated in float64 per step (host-side counter of the library, no sync)
+
     def vmc_step(step, state):
         if S > 1:
             return vmc_step_states(step, state)
@@ -341,6 +343,7 @@ def main():
         else:
             r = state['r']
         e, _ = loc_ene(step, params, r)
+        refined.append(eng.last_refined())
         stats = parallel.energy_stats(eng, e)
         return state, stats
 
@@ -411,6 +414,8 @@ def main():
     log(f'{len(blocks)} timed blocks done')
     elapsed = float(np.median(blocks))
     ms_per_step = 1e3 * elapsed / args.steps
+    refined_timed = list(refined[args.warmup:]) if S == 1 and not args.overlap else []
+    refine_state = eng.refine_info()
     value = S * B * world / (elapsed / args.steps)        # every state's walkers get a local energy per step
 
     # ---- the same loop with the float64 refinement switched off (secondary figure; plain float32 arithmetic) ----
@@ -478,8 +483,13 @@ def main():
                                    f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats'
                                    + (f' + {S}x{S} psi-ratio matrix + overlap penalty' if S > 1 else ''),
                        'walkers_per_gpu': B, 'n_sub': args.n_sub, 'states': S, 'parallelism': f'walker-dp{world}',
-                       'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers)', 0: 'off', 1: 'flagged walkers',
-                                  2: 'whole E_loc pass in float64'}[args.refine]},
+                       'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers, self-calibrated threshold)', 0: 'off',
+                                  1: 'flagged walkers', 2: 'whole E_loc pass in float64'}[args.refine],
+                       # what the library actually did during the timed steps (dqmc_last_refined / dqmc_refine_info)
+                       'refine_engaged': {**refine_state,
+                                          'walkers_refined_per_step_mean': float(np.mean(refined_timed)) if refined_timed else None,
+                                          'walkers_refined_per_step_max': int(np.max(refined_timed)) if refined_timed else None,
+                                          'fraction_refined': float(np.mean(refined_timed)) / B if refined_timed else None}},
             'eloc_only_evals_per_s': eloc_only,
             'energy': stats,
             'flops_per_eloc': (3 * hamil.n_elec + 2) * eng.program.flops_per_walker,

@@ -70,6 +70,7 @@ struct dqmc_ctx {
   int last_TP = 0;
   bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
+  double refine_info[4] = {0, 0, 0, 0};   // {mode, score threshold, measured error per unit of score, direct float64 calls left}
   int device = 0;           // every entry point makes this the calling thread's current device
   double* d_gather = nullptr;   // all-gathered energy records (dqmc_energy_stats_allgather)
   size_t gather_cap = 0;
@@ -200,8 +201,21 @@ struct Engine : dqmc_ctx {
   // energy is a difference of huge numbers and float32 round-off is amplified by the CI cancellation) are
   // re-evaluated by a float64 twin of this context and their results replace the float32 ones
   int refine = 1;
-  double refine_thresh = 16.0;
-  double refine_cond = 0.0;      // > 0: walkers whose conditioning record (kernels_head.hip) exceeds it are refined as well
+  // Flag rule: score > refine_thresh (kernels.h: FinalArgs).  The threshold is SELF-CALIBRATED: every refine_probe-th
+  // local-energy call (and the first) a strided sample of <= 64 walkers is evaluated by the float64 twin as well, the
+  // measured float32 error per unit of score -- its 90th percentile c over the sample -- sets
+  // refine_thresh = refine_target / c, i.e. the score at which the expected error reaches refine_target (5e-6
+  // relative, half the tolerance of the north star).  Deep / ill-conditioned systems (Psiformer, a random-init
+  // TransPsiformer) measure a large c, flag most walkers and fall into the direct float64 pass by themselves; a
+  // small system keeps a few per cent.  refine_probe = 0 freezes the threshold at the option's value.
+  double refine_thresh = 200.0;
+  double refine_target = 5e-6;
+  int refine_probe = 32;
+  int refine_ahead = 1;          // enqueue the float64 pass at a capacity before the flagged count is known on the host
+  int ahead_cap = 0, ahead_pos = 0;
+  int ahead_hist[4] = {0, 0, 0, 0};
+  int calls_since_probe = -1;    // -1: never probed
+  double probe_c = 0.0;          // last measured error per unit of score (0: none yet)
   bool flag_on = false;
   int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
   std::vector<std::pair<std::string, int>> twin_opts;
@@ -218,6 +232,7 @@ struct Engine : dqmc_ctx {
   std::vector<int32_t> ph_mask_h;
   dqmc_ctx* twin = nullptr;
   int32_t* d_flag = nullptr;     // [0] = count, [1..] = walker indices
+  double* d_score = nullptr;     // [B] error predictor of the last flagged pass
   size_t flag_cap = 0;
   char* d_ref = nullptr;
   size_t ref_bytes = 0;
@@ -229,6 +244,7 @@ struct Engine : dqmc_ctx {
     for (auto e : buf_ev) if (e) (void)hipEventDestroy(e);
     if (d_molz) (void)hipFree(d_molz);
     if (d_flag) (void)hipFree(d_flag);
+    if (d_score) (void)hipFree(d_score);
     if (d_ref) (void)hipFree(d_ref);
     if (d_descs) (void)hipFree(d_descs);
     if (d_wave_begin) (void)hipFree(d_wave_begin);
@@ -489,7 +505,9 @@ struct Engine : dqmc_ctx {
       return build_fused_plan();
     }
     if (s == "refine") { refine = value; return DQMC_OK; }
-    if (s == "refine_cond") { if (value < 0) return fail(DQMC_E_ARG, "refine_cond must be >= 0"); refine_cond = (double)value; return DQMC_OK; }
+    if (s == "refine_ahead") { refine_ahead = value; return DQMC_OK; }
+    if (s == "refine_probe") { if (value < 0) return fail(DQMC_E_ARG, "refine_probe must be >= 0"); refine_probe = value; calls_since_probe = -1; return DQMC_OK; }
+    if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
@@ -1319,8 +1337,11 @@ struct Engine : dqmc_ctx {
           a.B = B; a.n_up = sys.n_up; a.n_nuc = sys.n_nuc; a.K = sys.n_det; a.li = li;
           a.logpsi = logpsi; a.sign = sign; a.e_loc = e_loc; a.stats = stats; a.stats_ld = stats_ld; a.grad = grad;
           a.phq = phq;
-          if (laplacian) { a.cond = reinterpret_cast<double*>(d_ws + off_cond); a.kappa_out = reinterpret_cast<double*>(d_ws + off_kappa); a.refine_cond = refine_cond; }
-          if (flag_on && laplacian) { a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset; }
+          if (laplacian) { a.cond = reinterpret_cast<double*>(d_ws + off_cond); a.kappa_out = reinterpret_cast<double*>(d_ws + off_kappa); }
+          if (flag_on && laplacian) {
+            a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset;
+            a.score_out = d_score;
+          }
           t_begin("final", 0);
           dqmc::launch_final<real>(st, a);
           t_end();
@@ -1359,90 +1380,199 @@ struct Engine : dqmc_ctx {
   }
 
   // The forward-Laplacian pass; in the float32 build followed by the float64 re-evaluation of the walkers k_final
-  // flagged (typically ~1 % of |psi|^2-distributed walkers; option "refine" 0 turns it off).
+  // flagged (a few per cent of |psi|^2-distributed walkers of a small system; option "refine" 0 turns it off).
+  int ensure_twin() {
+    if (twin) return DQMC_OK;
+    auto* t = new Engine<double>();
+    t->st = st; t->device = device;
+    dqmc_system s2 = sys;
+    s2.dtype = 1;
+    int rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
+                     h_itable.data(), h_itable.size());
+    if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
+    if (!rc && !ph_mask_h.empty()) rc = t->set_ph(ph_grid, ph_rmax, ph_loc_h.data(), ph_l2_h.data(), ph_mask_h.data());
+    for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
+    if (rc) { delete t; return rc; }
+    t->ws_budget = ws_budget / 2;
+    twin = t;
+    return DQMC_OK;
+  }
+  // float64 results of the n walkers listed in d_flag[1..n] replace the float32 ones.  d_count != nullptr: the list is
+  // still being produced on the device, n is the capacity of this pass (kernels_mcmc.hip: k_refine_gather).
+  int refine_listed(const real* r, const real* R, int B, int n, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign,
+                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr) {
+    if (!d_list) d_list = d_flag + 1;
+    const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_r = 0, o_R = o_r + al(sizeof(double) * (size_t)n * n3), o_e = o_R + al(sizeof(double) * nR3),
+                 o_s = o_e + al(sizeof(double) * n), o_g = o_s + al(sizeof(double) * 6 * (size_t)n),
+                 o_l = o_g + al(sizeof(double) * (size_t)n * n3), o_sg = o_l + al(sizeof(double) * n),
+                 tot = o_sg + al(sizeof(int32_t) * n);
+    if (tot > ref_bytes) {
+      if (d_ref) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ref)); d_ref = nullptr; ref_bytes = 0; }
+      HIP_TRY(hipMalloc((void**)&d_ref, tot));
+      ref_bytes = tot;
+    }
+    double* r64 = (double*)(d_ref + o_r); double* R64 = (double*)(d_ref + o_R); double* e64 = (double*)(d_ref + o_e);
+    double* s64 = (double*)(d_ref + o_s); double* g64 = (double*)(d_ref + o_g); double* l64 = (double*)(d_ref + o_l);
+    int32_t* sg64 = (int32_t*)(d_ref + o_sg);
+    t_begin("refine", 0);
+    dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
+    t_end();
+    twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
+    const int rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
+    twin->ph_skip = false;
+    if (rc) return rc;
+    t_begin("refine", 0);
+    dqmc::launch_refine_scatter(st, d_list, d_count, n, n3, e64, s64, g64, l64, sg64, (float*)e_loc, (float*)stats, (long)B, (float*)grad,
+                                (float*)logpsi, sign);
+    t_end();
+    if (!d_count) last_refined += n;
+    return DQMC_OK;
+  }
+  // capacity of the enqueue-ahead float64 pass: 1.5 x the largest of the last counts, in steps of 32 (small batches: 8) walkers
+  void update_ahead_cap(int n, int B) {
+    ahead_hist[ahead_pos++ & 3] = n;
+    int mx = 0;
+    for (int k = 0; k < 4; ++k) mx = ahead_hist[k] > mx ? ahead_hist[k] : mx;
+    const long step = B >= 512 ? 32 : 8;
+    long cap = ((long)mx * 3 / 2 + step - 1) / step * step;
+    if (cap < step) cap = step;
+    ahead_cap = (2 * cap > B) ? 0 : (int)cap;        // a large share of the batch: the plain path decides (direct float64 mode)
+  }
+  int upload_list(const std::vector<int32_t>& idx) {
+    std::vector<int32_t> buf(idx.size() + 1);
+    buf[0] = (int32_t)idx.size();
+    std::copy(idx.begin(), idx.end(), buf.begin() + 1);
+    HIP_TRY(hipMemcpyAsync(d_flag, buf.data(), sizeof(int32_t) * buf.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return DQMC_OK;
+  }
   int lap_refined(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
+    const int rc = lap_refined_(r, R, B, e_loc, stats, grad, logpsi, sign);
+    refine_info[0] = sizeof(real) == 8 ? 0 : refine; refine_info[1] = refine_thresh; refine_info[2] = probe_c; refine_info[3] = refine_all_calls;
+    return rc;
+  }
+  int lap_refined_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     last_refined = 0;
     if constexpr (sizeof(real) == 8) {
       return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
     } else {
       if (!refine) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
       if ((size_t)B + 1 > flag_cap) {
-        if (d_flag) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_flag)); d_flag = nullptr; }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (d_flag) { HIP_TRY(hipFree(d_flag)); d_flag = nullptr; }
+        if (d_score) { HIP_TRY(hipFree(d_score)); d_score = nullptr; }
         HIP_TRY(hipMalloc((void**)&d_flag, sizeof(int32_t) * ((size_t)B + 1)));
+        HIP_TRY(hipMalloc((void**)&d_score, sizeof(double) * (size_t)B));
         flag_cap = (size_t)B + 1;
       }
       int rc = DQMC_OK;
-      int32_t n = 0;
-      // mode 1 on a system where (nearly) every walker gets flagged (ill-conditioned Slater matrices, e.g. a random-init
-      // TransPsiformer): the float32 pass would be wasted, so the following 15 calls go to float64 directly, then re-probe
+      // mode 1 on a system where most walkers get flagged (deep attention networks, ill-conditioned Slater matrices of a
+      // random-init TransPsiformer): the float32 pass would be wasted, so the following 15 calls go to float64 directly,
+      // then the float32 pass is probed again
       const bool direct = refine >= 2 || (refine == 1 && refine_all_calls > 0 && twin);
       if (refine == 1 && refine_all_calls > 0) --refine_all_calls;
       if (direct) {                // the whole forward-Laplacian pass in float64 (float32 stays the sampling dtype)
-        std::vector<int32_t> iota((size_t)B + 1);
-        iota[0] = B;
-        for (int k = 0; k < B; ++k) iota[k + 1] = k;
-        HIP_TRY(hipMemcpyAsync(d_flag, iota.data(), sizeof(int32_t) * ((size_t)B + 1), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        n = B;
-      } else {
-        HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
-        flag_on = true;
-        rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
-        flag_on = false;
+        rc = ensure_twin();
+        if (rc) return rc;
+        std::vector<int32_t> iota((size_t)B);
+        for (int k = 0; k < B; ++k) iota[k] = k;
+        rc = upload_list(iota);
+        if (rc) return rc;
+        return refine_listed(r, R, B, B, e_loc, stats, grad, logpsi, sign);
+      }
+      HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+      flag_on = true;
+      rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      flag_on = false;
+      if (rc) return rc;
+      const bool probe = refine == 1 && refine_probe > 0 && e_loc && (calls_since_probe < 0 || calls_since_probe + 1 >= refine_probe);
+      if (calls_since_probe >= 0) ++calls_since_probe;
+      int32_t n = 0;
+      if (!probe && refine_ahead && twin && ahead_cap > 0 && ahead_cap <= B) {
+        // The float64 pass is enqueued BEFORE the host knows how many walkers were flagged: it runs at a capacity derived
+        // from the recent counts, the gather / scatter kernels read the count on the device.  The ~100 launches of the
+        // twin are issued while the GPU still executes the float32 pass (they used to start only after a host round trip,
+        // with the GPU idle in between); the count is read once everything is enqueued.  An overflow (count > capacity:
+        // rare, the capacity carries 50 % headroom) is finished by a second pass over the remainder.
+        const int cap = ahead_cap;
+        rc = refine_listed(r, R, B, cap, e_loc, stats, grad, logpsi, sign, d_flag);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        if (n <= 0) return DQMC_OK;
         if (n > B) n = B;
-        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
-      }
-      if (!twin) {
-        auto* t = new Engine<double>();
-        t->st = st; t->device = device;
-        dqmc_system s2 = sys;
-        s2.dtype = 1;
-        rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
-                     h_itable.data(), h_itable.size());
-        if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
-        if (!rc && !ph_mask_h.empty()) rc = t->set_ph(ph_grid, ph_rmax, ph_loc_h.data(), ph_l2_h.data(), ph_mask_h.data());
-        if (rc == DQMC_E_UNSUPPORTED && refine == 1) {
-          // no float64 kernel set for this program (e.g. the scalar attention tiles of 42 electrons exceed the LDS):
-          // the float32 results stand and the refinement switches itself off
-          delete t;
-          refine = 0;
-          return DQMC_OK;
+        last_refined = n < cap ? n : cap;
+        if (n > cap) {
+          rc = refine_listed(r, R, B, n - cap, e_loc, stats, grad, logpsi, sign, nullptr, d_flag + 1 + cap);
+          if (rc) return rc;
         }
-        for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
-        if (rc) { delete t; return rc; }
-        t->ws_budget = ws_budget / 2;
-        twin = t;
+        update_ahead_cap(n, B);
+        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
+        HIP_TRY(hipGetLastError());
+        return DQMC_OK;
       }
-      const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
-      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
-      const size_t o_r = 0, o_R = o_r + al(sizeof(double) * (size_t)n * n3), o_e = o_R + al(sizeof(double) * nR3),
-                   o_s = o_e + al(sizeof(double) * n), o_g = o_s + al(sizeof(double) * 6 * (size_t)n),
-                   o_l = o_g + al(sizeof(double) * (size_t)n * n3), o_sg = o_l + al(sizeof(double) * n),
-                   tot = o_sg + al(sizeof(int32_t) * n);
-      if (tot > ref_bytes) {
-        if (d_ref) { HIP_TRY(hipFree(d_ref)); d_ref = nullptr; ref_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&d_ref, tot));
-        ref_bytes = tot;
+      HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (n > B) n = B;
+      if (!probe) update_ahead_cap(n, B);
+      if (!probe) {
+        if (n <= 0) return DQMC_OK;
+        rc = ensure_twin();
+        if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }   // no float64 kernel set for this program: float32 stands
+        if (rc) return rc;
+        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
+        rc = refine_listed(r, R, B, n, e_loc, stats, grad, logpsi, sign);
+        HIP_TRY(hipGetLastError());
+        return rc;
       }
-      double* r64 = (double*)(d_ref + o_r); double* R64 = (double*)(d_ref + o_R); double* e64 = (double*)(d_ref + o_e);
-      double* s64 = (double*)(d_ref + o_s); double* g64 = (double*)(d_ref + o_g); double* l64 = (double*)(d_ref + o_l);
-      int32_t* sg64 = (int32_t*)(d_ref + o_sg);
-      t_begin("refine", 0);
-      dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_flag + 1, n, n3, nR3, r64, R64);
-      t_end();
-      twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
-      rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
-      twin->ph_skip = false;
+      // ---- probe call: measure the float32 error per unit of score on a strided sample, re-derive the threshold, and
+      // apply it to THIS call as well (a caller that evaluates once gets the calibrated result)
+      rc = ensure_twin();
+      if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }
       if (rc) return rc;
-      t_begin("refine", 0);
-      dqmc::launch_refine_scatter(st, d_flag + 1, n, n3, e64, s64, g64, l64, sg64, (float*)e_loc, (float*)stats, (long)B, (float*)grad,
-                                  (float*)logpsi, sign);
-      t_end();
-      last_refined = n;
+      std::vector<int32_t> flagged((size_t)n);
+      std::vector<double> score((size_t)B);
+      std::vector<float> e32((size_t)B), e_new((size_t)B);
+      if (n) HIP_TRY(hipMemcpyAsync(flagged.data(), d_flag + 1, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(score.data(), d_score, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(e32.data(), e_loc, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      std::vector<char> done((size_t)B, 0);
+      for (int32_t b : flagged) if (b >= 0 && b < B) done[b] = 1;
+      const int ns = B < 64 ? B : 64;
+      std::vector<int32_t> sample, list(flagged);
+      for (int j = 0; j < ns; ++j) {
+        const int b = (int)((long)j * B / ns);
+        if (!done[b]) { sample.push_back(b); list.push_back(b); done[b] = 1; }   // flagged walkers say nothing about the unflagged population
+      }
+      rc = upload_list(list);
+      if (rc) return rc;
+      rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign);
+      if (rc) return rc;
+      HIP_TRY(hipMemcpyAsync(e_new.data(), e_loc, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      std::vector<double> cs;
+      for (int32_t b : sample) {
+        const double rel = std::fabs((double)e_new[b] - (double)e32[b]) / std::fmax(1.0, std::fabs((double)e_new[b]));
+        if (std::isfinite(rel) && std::isfinite(score[b]) && score[b] > 0) cs.push_back(rel / score[b]);
+      }
+      if (cs.size() >= 4) {
+        std::sort(cs.begin(), cs.end());
+        const double c = std::fmax(cs[(size_t)(0.9 * (cs.size() - 1) + 0.5)], 1e-12);
+        probe_c = probe_c > 0 ? std::sqrt(probe_c * c) : c;         // geometric smoothing over the probes
+        refine_thresh = std::fmin(std::fmax(refine_target / probe_c, 1.0), 1e9);
+      }
+      calls_since_probe = 0;
+      std::vector<int32_t> more;
+      for (int b = 0; b < B; ++b) if (!done[b] && !(score[b] <= refine_thresh)) more.push_back(b);
+      if (refine == 1 && 2 * ((long)flagged.size() + (long)more.size()) > (long)B && B >= 16) refine_all_calls = 15;
+      if (!more.empty()) {
+        rc = upload_list(more);
+        if (rc) return rc;
+        rc = refine_listed(r, R, B, (int)more.size(), e_loc, stats, grad, logpsi, sign);
+        if (rc) return rc;
+      }
       HIP_TRY(hipGetLastError());
       return DQMC_OK;
     }
@@ -2013,6 +2143,11 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
+int dqmc_refine_info(dqmc_ctx* ctx, double* out4) {
+  if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");
+  for (int k = 0; k < 4; ++k) out4[k] = ctx->refine_info[k];
+  return DQMC_OK;
+}
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));

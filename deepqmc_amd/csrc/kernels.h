@@ -206,17 +206,18 @@ struct FinalArgs {
   void* stats;    // real[6][stats_ld], this call's walkers at columns 0..B-1
   long stats_ld;  // leading dimension of stats (the caller's total batch when evaluating a chunk)
   void* grad;     // real[B][3N]
-  // float64 refinement (float32 build): walkers whose E_loc is ill conditioned -- (|lap| + |grad|^2) / max(1, |E_loc|)
-  // above refine_thresh, i.e. near a node of psi where the kinetic energy is a difference of huge numbers, or a
-  // non-finite result -- are appended to flag_idx (global walker index b_offset + b); nullptr: no flagging
+  // float64 refinement (float32 build): the float32 error of E_loc is predicted by
+  //   score = (|lap| + |grad|^2) / max(1, |E_loc|)  x  max(1, sum_k |p_k| kappa_k)
+  // -- the cancellation in E_kin = -(lap + |grad|^2)/2 (both terms ~ 1/psi^2 near a node) times the conditioning record
+  // of the Slater matrices that carry psi (kernels_head.hip, above k_slogdet).  Walkers with score > refine_thresh or a
+  // non-finite E_loc are appended to flag_idx (global walker index b_offset + b); nullptr: no flagging.
+  // score_out [B_total] (indexed like flag_idx) and kappa_out [B] (this chunk) receive the two records.
   int32_t* flag_count;
   int32_t* flag_idx;
   double refine_thresh;
   int b_offset;
-  // conditioning record of the determinant kernels (kernels_head.hip: slogdet_cond), [B][K], or nullptr; walkers whose
-  // weighted record sum_k |p_k| kappa_k exceeds refine_cond (> 0) are flagged as well; kappa_out [B] receives it (debug)
-  const double* cond;
-  double refine_cond;
+  const double* cond;     // [B][K] conditioning record of the determinant kernels, or nullptr
+  double* score_out;
   double* kappa_out;
   // pseudo-Hamiltonian (ecp/pseudo_hamiltonian.py): per-(walker, electron) factors [B][N][PH_STRIDE] the derivative
   // lanes were seeded with (and the electron's share of the local PH potential); nullptr = ordinary kinetic energy
@@ -275,9 +276,9 @@ template <typename real>
 void launch_exchange_propose(hipStream_t st, const real* r, const int32_t* up_idx, const int32_t* down_idx, int n_up, int B, int N,
                              real* r_prop);
 void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_out);
-void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, int n, int n3, int nR3,
-                          double* r64, double* R64);
-void launch_refine_scatter(hipStream_t st, const int32_t* idx, int n, int n3, const double* e64, const double* st64,
+void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, const int32_t* count, int n, int n3,
+                          int nR3, double* r64, double* R64);
+void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n3, const double* e64, const double* st64,
                            const double* g64, const double* lp64, const int32_t* sg64, float* e_loc, float* stats,
                            long stats_ld, float* grad, float* logpsi, int32_t* sign);
 

@@ -757,9 +757,10 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
   if (!live || l != 0) return;
   if (a.e_loc) reinterpret_cast<real*>(a.e_loc)[b] = (real)e_loc;
   if (a.flag_idx) {      // float32 build: hand ill-conditioned walkers to the float64 refinement pass
-    const double ratio = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc));
-    const bool ill = a.cond && a.refine_cond > 0 && !(kappa <= a.refine_cond);
-    if (!(ratio <= a.refine_thresh) || ill) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;
+    // float32 error predictor (engine.hip: lap_refined): node cancellation x conditioning of the determinants
+    const double score = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc)) * fmax(1.0, kappa);
+    if (a.score_out) a.score_out[a.b_offset + b] = score;
+    if (!(score <= a.refine_thresh)) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;     // NaN / inf land here too
   }
   if (a.kappa_out) a.kappa_out[b] = kappa;
   if (a.stats) {

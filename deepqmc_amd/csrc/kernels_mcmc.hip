@@ -349,25 +349,36 @@ void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_ou
 }
 
 // ---- float64 refinement of flagged walkers (engine.hip: Engine<float>::lap_refined) ----
+// The list idx[0..n) is either complete on the host side (count == nullptr) or still being produced on the device: then
+// `count` points at the number of flagged walkers and n is the CAPACITY the float64 pass was enqueued for -- slots past
+// min(*count, n) are filled with a valid walker (the first flagged one, or walker 0) and not scattered back, so the
+// host never has to wait for the count before it enqueues the pass.
 // gather: positions of the flagged walkers (and the geometry) widened to double
 __global__ void __launch_bounds__(256) k_refine_gather(const float* __restrict__ r, const float* __restrict__ R,
-                                                       const int32_t* __restrict__ idx, int n, int n3, int nR3,
-                                                       double* __restrict__ r64, double* __restrict__ R64) {
+                                                       const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int n,
+                                                       int n3, int nR3, double* __restrict__ r64, double* __restrict__ R64) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e < nR3) R64[e] = (double)R[e];
   if (e >= (long)n * n3) return;
   const int j = (int)(e / n3), c = (int)(e - (long)j * n3);
-  r64[e] = (double)r[(long)idx[j] * n3 + c];
+  long b;
+  if (count) {
+    const int live = *count < n ? *count : n;
+    b = live > 0 ? idx[j < live ? j : 0] : 0;
+  } else {
+    b = idx[j];
+  }
+  r64[e] = (double)r[b * n3 + c];
 }
 // scatter: the float64 results replace the float32 ones of those walkers
-__global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restrict__ idx, int n, int n3,
+__global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int n, int n3,
                                                         const double* __restrict__ e64, const double* __restrict__ st64,
                                                         const double* __restrict__ g64, const double* __restrict__ lp64,
                                                         const int32_t* __restrict__ sg64, float* __restrict__ e_loc,
                                                         float* __restrict__ stats, long stats_ld, float* __restrict__ grad,
                                                         float* __restrict__ logpsi, int32_t* __restrict__ sign) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+  if (j >= n || (count && j >= *count)) return;
   const long b = idx[j];
   if (e_loc) e_loc[b] = (float)e64[j];
   if (stats) for (int k = 0; k < 6; ++k) stats[k * stats_ld + b] = (float)st64[(long)k * n + j];
@@ -375,16 +386,16 @@ __global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restric
   if (logpsi) logpsi[b] = (float)lp64[j];
   if (sign) sign[b] = sg64[j];
 }
-void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, int n, int n3, int nR3,
-                          double* r64, double* R64) {
+void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, const int32_t* count, int n, int n3,
+                          int nR3, double* r64, double* R64) {
   long tot = (long)n * n3;
   if (tot < nR3) tot = nR3;
-  hipLaunchKernelGGL(k_refine_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, r, R, idx, n, n3, nR3, r64, R64);
+  hipLaunchKernelGGL(k_refine_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, r, R, idx, count, n, n3, nR3, r64, R64);
 }
-void launch_refine_scatter(hipStream_t st, const int32_t* idx, int n, int n3, const double* e64, const double* st64,
+void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n3, const double* e64, const double* st64,
                            const double* g64, const double* lp64, const int32_t* sg64, float* e_loc, float* stats,
                            long stats_ld, float* grad, float* logpsi, int32_t* sign) {
-  hipLaunchKernelGGL(k_refine_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, n, n3, e64, st64, g64, lp64,
+  hipLaunchKernelGGL(k_refine_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, count, n, n3, e64, st64, g64, lp64,
                      sg64, e_loc, stats, stats_ld, grad, logpsi, sign);
 }
 

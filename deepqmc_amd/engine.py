@@ -322,6 +322,12 @@ class Engine:
         """Walkers the last local-energy call re-evaluated in float64 (dqmc_last_refined)."""
         return int(self.lib.dqmc_last_refined(self._ctx))
 
+    def refine_info(self) -> dict:
+        """State of the float64 refinement after the last local-energy call (dqmc_refine_info)."""
+        out = (ctypes.c_double * 4)()
+        self._check(self.lib.dqmc_refine_info(self._ctx, out))
+        return {'mode': int(out[0]), 'score_threshold': out[1], 'error_per_score': out[2], 'direct_f64_calls_left': int(out[3])}
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
 

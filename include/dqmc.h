@@ -249,15 +249,24 @@ int dqmc_merge_energy_stats(const double* records_host, int n_ranks, double* out
 
 /* Debug / test access: copy activation buffer `buf` of the last evaluation (layout
  * real[B][rows][TP][width]) to host as double[].  n must equal B*rows*TP*width.
- * buf = -1: log|det| lanes double[B][K][TP]; buf = -2: det signs as double[B][K]. */
+ * buf = -1: log|det| lanes double[B][K][TP]; buf = -2: det signs as double[B][K]; buf = -4: the psi-weighted
+ * conditioning record of the Slater matrices, double[B] (Laplacian-mode evaluations). */
 int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out_host, size_t n);
 /* Lanes (TP) used by the last evaluation. */
 int dqmc_debug_lanes(dqmc_ctx* ctx);
 /* Walkers the last dqmc_local_energy / dqmc_psi_grad call re-evaluated in float64 (float32 contexts: the local
  * energy near a node of psi is a difference of huge numbers, E_kin = -(lap + |grad|^2)/2 with both terms ~ 1/psi^2;
- * walkers with (|lap| + |grad|^2) / max(1, |E_loc|) > "refine_thresh" (default 16) or a non-finite E_loc are run
- * again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign replaced). */
+ * walkers whose error predictor score = (|lap| + |grad|^2) / max(1, |E_loc|) x max(1, sum_k |p_k| kappa_k) -- node
+ * cancellation times the conditioning record of the Slater matrices that carry psi -- exceeds "refine_thresh", or whose
+ * E_loc is not finite, are run again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign
+ * replaced.  The threshold calibrates itself: on the first and then every "refine_probe"-th call a strided sample of
+ * <= 64 further walkers is evaluated in float64 too, the measured float32 error per unit of score (90th percentile)
+ * gives refine_thresh = target / c with target = 5e-6 relative; the count includes that sample on probe calls). */
 int dqmc_last_refined(dqmc_ctx* ctx);
+/* State of the refinement after the last local-energy call: out4 = {mode ("refine": 0 / 1 / 2; 0 in a float64
+ * context), current score threshold, measured float32 error per unit of score (0 before the first probe), calls
+ * that will still go to the direct float64 pass because most walkers were flagged}. */
+int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op where that is the faster path
  * (N <= 4, or fewer than 1024 walkers; 2 = always, 0 = never, which also keeps every
@@ -276,7 +285,9 @@ int dqmc_last_refined(dqmc_ctx* ctx);
  * hardware's oldest-wave-first order (2: unit by unit, 0: off); "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
- * float64 while sampling stays float32, 0: off), "refine_thresh" (16): the trigger of mode 1.
+ * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
+ * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set),
+ * "refine_target_e7" (50): target relative error of the unrefined walkers in units of 1e-7.
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 

@@ -105,8 +105,9 @@ def test_ecp_needs_rng_and_psi_grad_skips_the_quadrature():
 
 
 def test_f64_refinement_of_ill_conditioned_walkers():
-    """float32 context: walkers k_final flags ((|lap| + |grad|^2) / max(1, |E_loc|) above the threshold) are re-evaluated
-    by the float64 twin; their results equal a float64 engine's (rounded to float32), the others stay float32."""
+    """float32 context: walkers k_final flags (score = (|lap| + |grad|^2) / max(1, |E_loc|) x conditioning record above
+    the threshold) are re-evaluated by the float64 twin; their results equal a float64 engine's (rounded to float32),
+    the others stay float32.  Probe off = fixed threshold; the self-calibrating probe is exercised below."""
     h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
     wf32 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     wf64 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
@@ -118,8 +119,10 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     e_plain, st_plain, g_plain = e32.local_energy(r, return_grad=True)
     assert e32.last_refined() == 0
     ratio = ((st_plain['hamil/lap'].abs() + st_plain['hamil/quantum_force']) / e_plain.abs().clamp(min=1.0)).numpy()
+    ratio = ratio * np.maximum(1.0, e32.debug_read('kappa', B))
     thr = max(1, int(np.median(ratio)))            # a threshold that splits these walkers
     e32.set_option('refine', 1)
+    e32.set_option('refine_probe', 0)
     e32.set_option('refine_thresh', thr)
     e_ref, st_ref, g_ref = e32.local_energy(r, return_grad=True)
     n = e32.last_refined()
@@ -138,6 +141,54 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     e32.set_params(p2)
     e2, _ = e32.local_energy(r)
     fresh = Engine(wf32.spec, h, p2, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    fresh.set_option('refine_probe', 0)
     fresh.set_option('refine_thresh', thr)
     e3, _ = fresh.local_energy(r)
     np.testing.assert_array_equal(e2.numpy(), e3.numpy())
+    # the self-calibrating probe (library default): the first call evaluates a sample in float64 as well, derives the
+    # threshold from the measured error per unit of score and applies it to the same call
+    auto = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    auto.set_option('refine_target_e7', 1)             # 1e-7: below float32 resolution -> (nearly) every walker is refined
+    e_auto, _ = auto.local_energy(r)
+    assert auto.last_refined() == B                    # sample = all 6 walkers of this tiny batch
+    np.testing.assert_array_equal(e_auto.numpy(), e_d.numpy().astype(np.float32))
+    loose = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    loose.set_option('refine_probe', 0)
+    loose.set_option('refine_thresh', 10 ** 9)
+    e_l, _ = loose.local_energy(r)
+    assert loose.last_refined() == 0
+    np.testing.assert_array_equal(e_l.numpy(), e_plain.numpy())
+
+
+def test_enqueue_ahead_refinement_matches_the_synchronous_path():
+    """The float64 pass enqueued at a capacity before the host knows the flagged count (engine.hip: refine_ahead) must give
+    exactly what the synchronous path gives: padding slots are not scattered back, an overflow of the capacity is finished
+    by a second pass over the remainder."""
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    wf32 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf32.init(5, perturb_envelopes=0.1)
+    B = 16
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=21).astype(np.float32))
+
+    def engine(ahead):
+        e = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+        e.set_option('refine_probe', 0)
+        e.set_option('refine_ahead', ahead)
+        return e
+    plain = engine(0)
+    plain.set_option('refine', 0)
+    e0, st0 = plain.local_energy(r)
+    score = np.sort(((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e0.abs().clamp(min=1.0)).numpy()
+                    * np.maximum(1.0, plain.debug_read('kappa', B)))
+    thr_few, thr_many = int(score[-3]), max(1, int(score[-10]))        # 2 and ~9 walkers above: capacity 8 holds / overflows
+    sync, ahead = engine(0), engine(1)
+    for thr in (thr_few, thr_few, thr_many):      # sync call (sets the capacity), ahead call within capacity, overflow
+        for e in (sync, ahead):
+            e.set_option('refine_thresh', thr)
+        (es, ss, gs), (ea, sa, ga) = sync.local_energy(r, return_grad=True), ahead.local_energy(r, return_grad=True)
+        assert sync.last_refined() == ahead.last_refined() > 0
+        np.testing.assert_array_equal(es.numpy(), ea.numpy())
+        np.testing.assert_array_equal(gs.numpy(), ga.numpy())
+        for k in ss:
+            np.testing.assert_array_equal(ss[k].numpy(), sa[k].numpy())
+    assert 0 < (es.numpy() != e0.numpy()).sum() <= sync.last_refined()      # and refined walkers did change
