@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <algorithm>
@@ -69,6 +70,7 @@ struct dqmc_ctx {
   virtual int option(const char* name, int value) = 0;
   int last_TP = 0;
   bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
+  bool ecp_skip_nl = false; // ... and no non-local ECP quadrature
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   double refine_info[4] = {0, 0, 0, 0};   // {mode, score threshold, measured error per unit of score, direct float64 calls left}
   int device = 0;           // every entry point makes this the calling thread's current device
@@ -194,6 +196,10 @@ struct Engine : dqmc_ctx {
   int ecp_nt_loc = 0, ecp_n_nl = 0, ecp_L = 0, ecp_nt_nl = 0;
   uint64_t ecp_seed = 0;
   const void* ecp_phi = nullptr;
+  const int32_t* ecp_idx = nullptr;   // twin serving a float32 context: global walker index per walker (EcpArgs::walker_idx)
+  bool ecp_phi_f32 = false;
+  std::vector<double> ecp_nl_h;       // host copy of the non-local tables for the float64 twin
+  int ecp_nl_L_h = 0, ecp_nl_nt_h = 0;
   char* d_ecp = nullptr;        // quadrature walkers + their psi + psi of the walkers themselves
   size_t ecp_bytes = 0;
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
@@ -211,7 +217,10 @@ struct Engine : dqmc_ctx {
   double refine_thresh = 200.0;
   double refine_target = 5e-6;
   int refine_probe = 32;
-  int refine_ahead = 1;          // enqueue the float64 pass at a capacity before the flagged count is known on the host
+  // enqueue the float64 pass at a capacity before the flagged count is known on the host (option "refine_ahead"; off by
+  // default: the twin's kernels, not their launches, are what costs -- at 1.5 x headroom the larger pass loses 0.2 ms of a
+  // 6.3 ms step on LiH / PauliNet against the synchronous path, measured in one call)
+  int refine_ahead = 0;
   int ahead_cap = 0, ahead_pos = 0;
   int ahead_hist[4] = {0, 0, 0, 0};
   int calls_since_probe = -1;    // -1: never probed
@@ -236,6 +245,9 @@ struct Engine : dqmc_ctx {
   size_t flag_cap = 0;
   char* d_ref = nullptr;
   size_t ref_bytes = 0;
+  const double* ref_e64 = nullptr;   // float64 local energies of the last refine_listed pass (device)
+  std::vector<double> probe_sample_e;          // ... of the calibration sample of a probe call (host)
+  std::function<void()> probe_rethreshold;     // set by the probe call: derives refine_thresh from probe_sample_e
 
   ~Engine() override {
     delete twin;
@@ -1368,9 +1380,13 @@ struct Engine : dqmc_ctx {
   }
   int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
                    int32_t* sign) override {
-    if (ecp_n_nl == 0)
-      return lap_refined((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
-    return local_energy_ecp((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
+    return lap_refined((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
+  }
+  // the pass in this context's own precision: forward-Laplacian evaluation, plus the non-local ECP quadrature when the
+  // Hamiltonian has one and a local energy is asked for
+  int pass_own(const real* r, const real* R, int B, real* logpsi, int32_t* sign, real* e_loc, real* stats, real* grad) {
+    if (ecp_n_nl == 0 || !e_loc || ecp_skip_nl) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+    return local_energy_ecp(r, R, B, e_loc, stats, grad, logpsi, sign);
   }
 
   // log|psi|, sign and grad log|psi| from the forward-Laplacian pass alone: no potentials beyond k_final's, no
@@ -1389,7 +1405,8 @@ struct Engine : dqmc_ctx {
     s2.dtype = 1;
     int rc = t->init(&s2, charges_h.data(), bufs.data(), (int)bufs.size(), ops.data(), (int)ops.size(), w64_h.data(), w64_h.size(),
                      h_itable.data(), h_itable.size());
-    if (!rc && !ecp_loc_h.empty()) rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.data(), 0, 0, nullptr);
+    if (!rc && (!ecp_loc_h.empty() || !ecp_nl_h.empty()))      // the twin carries the whole ECP: its local energies include V_nl
+      rc = t->set_ecp(ecp_loc_nt_h, ecp_loc_h.empty() ? nullptr : ecp_loc_h.data(), ecp_nl_L_h, ecp_nl_nt_h, ecp_nl_h.empty() ? nullptr : ecp_nl_h.data());
     if (!rc && !ph_mask_h.empty()) rc = t->set_ph(ph_grid, ph_rmax, ph_loc_h.data(), ph_l2_h.data(), ph_mask_h.data());
     for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
     if (rc) { delete t; return rc; }
@@ -1400,8 +1417,9 @@ struct Engine : dqmc_ctx {
   // float64 results of the n walkers listed in d_flag[1..n] replace the float32 ones.  d_count != nullptr: the list is
   // still being produced on the device, n is the capacity of this pass (kernels_mcmc.hip: k_refine_gather).
   int refine_listed(const real* r, const real* R, int B, int n, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign,
-                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr) {
+                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr, int n_scatter = -1, bool use_score = false) {
     if (!d_list) d_list = d_flag + 1;
+    if (n_scatter < 0) n_scatter = n;
     const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
     auto al = [](size_t x) { return (x + 255) / 256 * 256; };
     const size_t o_r = 0, o_R = o_r + al(sizeof(double) * (size_t)n * n3), o_e = o_R + al(sizeof(double) * nR3),
@@ -1420,14 +1438,34 @@ struct Engine : dqmc_ctx {
     dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
     t_end();
     twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
+    // a Hamiltonian with a non-local ECP: the twin runs the quadrature of its walkers in float64 with the rotation angles
+    // of the walkers they stand for (its psi ratios carry the float64 value path's accuracy: float32 ratios alone put
+    // ~1e-4 relative on E_loc of a 30-electron Psiformer)
+    twin->ecp_skip_nl = (e_loc == nullptr);
+    static_cast<Engine<double>*>(twin)->ecp_seed = ecp_seed;
+    static_cast<Engine<double>*>(twin)->ecp_phi = ecp_phi;
+    static_cast<Engine<double>*>(twin)->ecp_phi_f32 = true;
+    static_cast<Engine<double>*>(twin)->ecp_idx = d_list;
     const int rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
     twin->ph_skip = false;
+    twin->ecp_skip_nl = false;
     if (rc) return rc;
     t_begin("refine", 0);
-    dqmc::launch_refine_scatter(st, d_list, d_count, n, n3, e64, s64, g64, l64, sg64, (float*)e_loc, (float*)stats, (long)B, (float*)grad,
-                                (float*)logpsi, sign);
+    // (entries past n_scatter -- the calibration sample of a probe call -- are evaluated, read by the host, not written back)
+    ref_e64 = e64;
+    if (use_score) {
+      // probe call: the new threshold needs the float64 energies of the sample on the host first; then only the walkers
+      // above it are written back (d_score / refine_thresh at that moment)
+      std::vector<double> e_h((size_t)n - n_scatter);
+      if (!e_h.empty()) HIP_TRY(hipMemcpyAsync(e_h.data(), e64 + n_scatter, sizeof(double) * e_h.size(), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      probe_sample_e = e_h;
+      if (probe_rethreshold) probe_rethreshold();
+    }
+    dqmc::launch_refine_scatter(st, d_list, d_count, n, n_scatter, use_score ? d_score : nullptr, refine_thresh, n3, e64, s64, g64, l64, sg64,
+                                (float*)e_loc, (float*)stats, (long)B, (float*)grad, (float*)logpsi, sign);
     t_end();
-    if (!d_count) last_refined += n;
+    if (!d_count && !use_score) last_refined += n_scatter;
     return DQMC_OK;
   }
   // capacity of the enqueue-ahead float64 pass: 1.5 x the largest of the last counts, in steps of 32 (small batches: 8) walkers
@@ -1456,9 +1494,9 @@ struct Engine : dqmc_ctx {
   int lap_refined_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     last_refined = 0;
     if constexpr (sizeof(real) == 8) {
-      return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      return pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
     } else {
-      if (!refine) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      if (!refine) return pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
       if ((size_t)B + 1 > flag_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if (d_flag) { HIP_TRY(hipFree(d_flag)); d_flag = nullptr; }
@@ -1484,7 +1522,7 @@ struct Engine : dqmc_ctx {
       }
       HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
       flag_on = true;
-      rc = run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+      rc = pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
       flag_on = false;
       if (rc) return rc;
       const bool probe = refine == 1 && refine_probe > 0 && e_loc && (calls_since_probe < 0 || calls_since_probe + 1 >= refine_probe);
@@ -1521,7 +1559,15 @@ struct Engine : dqmc_ctx {
         rc = ensure_twin();
         if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }   // no float64 kernel set for this program: float32 stands
         if (rc) return rc;
-        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
+        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) {
+          // most of the batch is beyond float32: this call and the next 15 evaluate everything in float64
+          refine_all_calls = 15;
+          std::vector<int32_t> iota((size_t)B);
+          for (int k = 0; k < B; ++k) iota[k] = k;
+          rc = upload_list(iota);
+          if (rc) return rc;
+          n = B;
+        }
         rc = refine_listed(r, R, B, n, e_loc, stats, grad, logpsi, sign);
         HIP_TRY(hipGetLastError());
         return rc;
@@ -1533,7 +1579,7 @@ struct Engine : dqmc_ctx {
       if (rc) return rc;
       std::vector<int32_t> flagged((size_t)n);
       std::vector<double> score((size_t)B);
-      std::vector<float> e32((size_t)B), e_new((size_t)B);
+      std::vector<float> e32((size_t)B);
       if (n) HIP_TRY(hipMemcpyAsync(flagged.data(), d_flag + 1, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(score.data(), d_score, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(e32.data(), e_loc, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
@@ -1544,29 +1590,41 @@ struct Engine : dqmc_ctx {
       std::vector<int32_t> sample, list(flagged);
       for (int j = 0; j < ns; ++j) {
         const int b = (int)((long)j * B / ns);
-        if (!done[b]) { sample.push_back(b); list.push_back(b); done[b] = 1; }   // flagged walkers say nothing about the unflagged population
+        if (!done[b]) { sample.push_back(b); list.push_back(b); }   // flagged walkers say nothing about the unflagged population
       }
+      // ONE float64 pass over flagged + sample; between its evaluation and its write-back the threshold is re-derived from
+      // the sample, and only walkers above the NEW threshold are written back: what a walker's result is depends on its
+      // score and the threshold alone -- never on having served as a calibration sample or on the threshold before the probe
       rc = upload_list(list);
       if (rc) return rc;
-      rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign);
+      probe_rethreshold = [&]() {
+        std::vector<double> cs;
+        for (size_t k = 0; k < sample.size(); ++k) {
+          const int32_t b = sample[k];
+          const double rel = std::fabs(probe_sample_e[k] - (double)e32[b]) / std::fmax(1.0, std::fabs(probe_sample_e[k]));
+          if (std::isfinite(rel) && std::isfinite(score[b]) && score[b] > 0) cs.push_back(rel / score[b]);
+        }
+        if (cs.size() >= 2) {
+          std::sort(cs.begin(), cs.end());
+          const double c = std::fmax(cs[(size_t)(0.9 * (cs.size() - 1) + 0.5)], 1e-12);
+          probe_c = probe_c > 0 ? std::sqrt(probe_c * c) : c;         // geometric smoothing over the probes
+          refine_thresh = std::fmin(std::fmax(refine_target / probe_c, 1.0), 1e9);
+        }
+      };
+      rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign, nullptr, nullptr, (int)flagged.size(), true);
+      probe_rethreshold = nullptr;
       if (rc) return rc;
-      HIP_TRY(hipMemcpyAsync(e_new.data(), e_loc, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      std::vector<double> cs;
-      for (int32_t b : sample) {
-        const double rel = std::fabs((double)e_new[b] - (double)e32[b]) / std::fmax(1.0, std::fabs((double)e_new[b]));
-        if (std::isfinite(rel) && std::isfinite(score[b]) && score[b] > 0) cs.push_back(rel / score[b]);
-      }
-      if (cs.size() >= 4) {
-        std::sort(cs.begin(), cs.end());
-        const double c = std::fmax(cs[(size_t)(0.9 * (cs.size() - 1) + 0.5)], 1e-12);
-        probe_c = probe_c > 0 ? std::sqrt(probe_c * c) : c;         // geometric smoothing over the probes
-        refine_thresh = std::fmin(std::fmax(refine_target / probe_c, 1.0), 1e9);
-      }
+      for (int32_t b : flagged) if (b >= 0 && b < B) { if (score[b] <= refine_thresh) done[b] = 2; else ++last_refined; }   // 2: evaluated, float32 result stands
       calls_since_probe = 0;
       std::vector<int32_t> more;
-      for (int b = 0; b < B; ++b) if (!done[b] && !(score[b] <= refine_thresh)) more.push_back(b);
-      if (refine == 1 && 2 * ((long)flagged.size() + (long)more.size()) > (long)B && B >= 16) refine_all_calls = 15;
+      for (int b = 0; b < B; ++b) if (!done[b] && !(score[b] <= refine_thresh)) more.push_back(b);      // (sample walkers included)
+      if (refine == 1 && 2 * ((long)flagged.size() + (long)more.size()) > (long)B && B >= 16) {
+        // most of the batch is beyond float32: the next calls go to float64 directly, and so does the rest of this one
+        // (the few walkers below the threshold of such a system are not reliably predicted either)
+        refine_all_calls = 15;
+        more.clear();
+        for (int b = 0; b < B; ++b) if (done[b] != 1) more.push_back(b);
+      }
       if (!more.empty()) {
         rc = upload_list(more);
         if (rc) return rc;
@@ -1590,8 +1648,10 @@ struct Engine : dqmc_ctx {
     if (d_ecp_nuc) { HIP_TRY(hipFree(d_ecp_nuc)); d_ecp_nuc = nullptr; }
     ecp_nt_loc = ecp_n_nl = ecp_L = ecp_nt_nl = 0;
     ecp_loc_h.clear(); ecp_loc_nt_h = 0;
+    ecp_nl_h.clear(); ecp_nl_L_h = ecp_nl_nt_h = 0;
     if (loc && n_t_loc > 0 && sizeof(real) == 4) { ecp_loc_h.assign(loc, loc + (size_t)sys.n_nuc * 6 * n_t_loc); ecp_loc_nt_h = n_t_loc; }
-    if (twin) { const int rc = twin->set_ecp(n_t_loc, loc, 0, 0, nullptr); if (rc) return rc; }
+    if (nl && n_l > 0 && n_t_nl > 0 && sizeof(real) == 4) { ecp_nl_h.assign(nl, nl + (size_t)sys.n_nuc * n_l * 2 * n_t_nl); ecp_nl_L_h = n_l; ecp_nl_nt_h = n_t_nl; }
+    if (twin) { const int rc = twin->set_ecp(n_t_loc, loc, n_l, n_t_nl, nl); if (rc) return rc; }
     if (loc && n_t_loc > 0) {
       const size_t n = (size_t)sys.n_nuc * 6 * n_t_loc;
       HIP_TRY(hipMalloc((void**)&d_ecp_loc, sizeof(double) * n));
@@ -1678,10 +1738,11 @@ struct Engine : dqmc_ctx {
     real* rq = (real*)(d_ecp + o_rq); real* lq = (real*)(d_ecp + o_lq); int32_t* sq = (int32_t*)(d_ecp + o_sq);
     real* l0 = logpsi ? logpsi : (real*)(d_ecp + o_l0);
     int32_t* s0 = sign ? sign : (int32_t*)(d_ecp + o_s0);
-    int rc = lap_refined(r, R, B, e_loc, stats, grad, l0, s0);
+    int rc = run(r, R, B, true, l0, s0, e_loc, stats, grad);
     if (rc) return rc;
     dqmc::EcpArgs a{};
     a.r = r; a.R = R; a.nl_nuc = d_ecp_nuc; a.nl = d_ecp_nl; a.phi = ecp_phi; a.seed = ecp_seed;
+    a.walker_idx = ecp_idx; a.phi_f32 = ecp_phi_f32 ? 1 : 0;
     a.B = B; a.N = N; a.n_nl = ecp_n_nl; a.L = ecp_L; a.n_t = ecp_nt_nl;
     for (int b0 = 0; b0 < B; b0 += nbw) {
       a.b0 = b0; a.nb = (B - b0) < nbw ? (B - b0) : nbw;

@@ -232,6 +232,11 @@ struct EcpArgs {
   const int32_t* nl_nuc;   // device [n_nl]: nuclei with a non-local part
   const double* nl;        // device [n_nl][L][2][n_t]: exponents ([.,l,0,.]) and coefficients ([.,l,1,.])
   const void* phi;         // real[B][n_nl][N] rotation angles, or nullptr: Philox(seed)
+  // float64 twin evaluating a gathered subset of a float32 context's walkers: walker b of this call is walker
+  // walker_idx[b] of the caller's batch (rotation angles -- explicit or Philox -- are keyed by THAT index), and the
+  // explicit angles are the caller's float array
+  const int32_t* walker_idx;
+  int phi_f32;
   uint64_t seed;
   int B, N, n_nl, L, n_t;
   int b0, nb;              // walker chunk of this launch
@@ -278,7 +283,8 @@ void launch_exchange_propose(hipStream_t st, const real* r, const int32_t* up_id
 void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_out);
 void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, const int32_t* count, int n, int n3,
                           int nR3, double* r64, double* R64);
-void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n3, const double* e64, const double* st64,
+void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n_scatter, const double* score,
+                           double thresh, int n3, const double* e64, const double* st64,
                            const double* g64, const double* lp64, const int32_t* sg64, float* e_loc, float* stats,
                            long stats_ld, float* grad, float* logpsi, int32_t* sign);
 

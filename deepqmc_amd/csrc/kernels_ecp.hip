@@ -54,11 +54,13 @@ __global__ void __launch_bounds__(256) k_ecp_points(const EcpArgs a, real* __res
   const double st = sqrt(1.0 - ct * ct);                     // sin(arccos(.)) >= 0
   const double phi = atan2(dy, dx);
   double phr;
+  const long bg = a.walker_idx ? (long)a.walker_idx[b] : (long)b;          // index that keys the rotation angle
   if (a.phi != nullptr) {
-    phr = (double)reinterpret_cast<const real*>(a.phi)[((long)b * a.n_nl + j) * N + i];
+    const long pidx = (bg * a.n_nl + j) * N + i;
+    phr = a.phi_f32 ? (double)reinterpret_cast<const float*>(a.phi)[pidx] : (double)reinterpret_cast<const real*>(a.phi)[pidx];
   } else {
     uint32_t o[4];
-    philox4x32(a.seed, 0x45435000ull + (uint64_t)j, (uint64_t)b * (uint64_t)N + (uint64_t)i, o);
+    philox4x32(a.seed, 0x45435000ull + (uint64_t)j, (uint64_t)bg * (uint64_t)N + (uint64_t)i, o);
     phr = u01(o[0], o[1]) * 0.62831853071795865;             // U[0, pi/5), ecp_utils.py:55
   }
   // u = rot_z(phr) * unit vertex; v = rot_y(theta) u; w = rot_z(phi) v

@@ -371,15 +371,17 @@ __global__ void __launch_bounds__(256) k_refine_gather(const float* __restrict__
   r64[e] = (double)r[b * n3 + c];
 }
 // scatter: the float64 results replace the float32 ones of those walkers
-__global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int n, int n3,
+__global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int n,
+                                                        int n_scatter, const double* __restrict__ score, double thresh, int n3,
                                                         const double* __restrict__ e64, const double* __restrict__ st64,
                                                         const double* __restrict__ g64, const double* __restrict__ lp64,
                                                         const int32_t* __restrict__ sg64, float* __restrict__ e_loc,
                                                         float* __restrict__ stats, long stats_ld, float* __restrict__ grad,
                                                         float* __restrict__ logpsi, int32_t* __restrict__ sign) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n || (count && j >= *count)) return;
+  if (j >= n_scatter || (count && j >= *count)) return;
   const long b = idx[j];
+  if (score && score[b] <= thresh) return;      // probe call: evaluated under the old threshold, not flagged under the new one
   if (e_loc) e_loc[b] = (float)e64[j];
   if (stats) for (int k = 0; k < 6; ++k) stats[k * stats_ld + b] = (float)st64[(long)k * n + j];
   if (grad) for (int c = 0; c < n3; ++c) grad[b * n3 + c] = (float)g64[(long)j * n3 + c];
@@ -392,10 +394,12 @@ void launch_refine_gather(hipStream_t st, const float* r, const float* R, const 
   if (tot < nR3) tot = nR3;
   hipLaunchKernelGGL(k_refine_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, r, R, idx, count, n, n3, nR3, r64, R64);
 }
-void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n3, const double* e64, const double* st64,
+void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n_scatter, const double* score,
+                           double thresh, int n3, const double* e64, const double* st64,
                            const double* g64, const double* lp64, const int32_t* sg64, float* e_loc, float* stats,
                            long stats_ld, float* grad, float* logpsi, int32_t* sign) {
-  hipLaunchKernelGGL(k_refine_scatter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, count, n, n3, e64, st64, g64, lp64,
+  if (n_scatter < 1) return;
+  hipLaunchKernelGGL(k_refine_scatter, dim3((unsigned)((n_scatter + 255) / 256)), dim3(256), 0, st, idx, count, n, n_scatter, score, thresh, n3, e64, st64, g64, lp64,
                      sg64, e_loc, stats, stats_ld, grad, logpsi, sign);
 }
 

