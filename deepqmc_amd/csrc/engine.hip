@@ -161,6 +161,11 @@ struct Engine : dqmc_ctx {
   int attention_mfma = 1;      // 1: where profitable (N > 16), 2: wherever supported, 0: never
   int slogdet_mfma = 1;        // 1: where profitable (N > 16), 2: from N > 8 on, 0: never
   std::vector<char> compact;
+  // two-layer row-wise MLPs run as ONE launch (kernel_linear.hip: CHAIN): mlp_child[k] = op index of the second layer
+  // of the LINEAR op k, or -1; mlp_skip[k]: op k is such a second layer (executed with its parent)
+  std::vector<int> mlp_child;
+  std::vector<char> mlp_skip;
+  int mlp_fuse = 1;
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
@@ -210,12 +215,12 @@ struct Engine : dqmc_ctx {
   // Flag rule: score > refine_thresh (kernels.h: FinalArgs).  The threshold is SELF-CALIBRATED: every refine_probe-th
   // local-energy call (and the first) a strided sample of <= 64 walkers is evaluated by the float64 twin as well, the
   // measured float32 error per unit of score -- its 90th percentile c over the sample -- sets
-  // refine_thresh = refine_target / c, i.e. the score at which the expected error reaches refine_target (5e-6
-  // relative, half the tolerance of the north star).  Deep / ill-conditioned systems (Psiformer, a random-init
+  // refine_thresh = refine_target / c, i.e. the score at which the expected error reaches refine_target (7e-6
+  // relative, 0.7 of the tolerance of the north star).  Deep / ill-conditioned systems (Psiformer, a random-init
   // TransPsiformer) measure a large c, flag most walkers and fall into the direct float64 pass by themselves; a
   // small system keeps a few per cent.  refine_probe = 0 freezes the threshold at the option's value.
   double refine_thresh = 200.0;
-  double refine_target = 5e-6;
+  double refine_target = 7e-6;
   int refine_probe = 32;
   // enqueue the float64 pass at a capacity before the flagged count is known on the host (option "refine_ahead"; off by
   // default: the twin's kernels, not their launches, are what costs -- at 1.5 x headroom the larger pass loses 0.2 ms of a
@@ -307,6 +312,7 @@ struct Engine : dqmc_ctx {
     int rc = validate();
     if (rc) return rc;
     analyse_lanes();
+    analyse_chains();
     rc = set_weights(w, nw);
     if (rc) return rc;
     return build_fused_plan();
@@ -380,6 +386,45 @@ struct Engine : dqmc_ctx {
       if (!ok) return fail(DQMC_E_ARG, "malformed op #" + std::to_string(k) + " kind " + std::to_string(op.kind));
     }
     return DQMC_OK;
+  }
+
+  // Row-wise two-layer MLPs (hkext.MLP with one hidden layer: the edge MLPs w / u and the node MLP h of a message-passing
+  // layer): LINEAR op k writes a private hidden buffer that exactly one later LINEAR op reads as its single piece, same
+  // rows, whole width.  The pair runs as one launch of the chained kernel at k's position, which is legal when nothing
+  // between the two ops touches the second layer's output and its residual input is complete before k.
+  void analyse_chains() {
+    const int no = (int)ops.size(), nb = (int)bufs.size();
+    mlp_child.assign(no, -1);
+    mlp_skip.assign(no, 0);
+    if (!mlp_fuse) return;
+    std::vector<int> rd, wr;
+    std::vector<std::vector<int>> writers(nb), readers(nb);
+    for (int k = 0; k < no; ++k) { op_io(ops[k], rd, wr); for (int b : wr) writers[b].push_back(k); for (int b : rd) readers[b].push_back(k); }
+    for (int c = 0; c < no; ++c) {
+      const int32_t* ci = ops[c].i;
+      if (ops[c].kind != DQMC_OP_LINEAR || ci[0] != 1 || ci[4]) continue;                 // one non-broadcast piece
+      const int hb = ci[1];
+      if (writers[hb].size() != 1 || readers[hb].size() != 1) continue;                   // a private hidden buffer
+      const int p = writers[hb][0];
+      if (p >= c || ops[p].kind != DQMC_OP_LINEAR || mlp_child[p] >= 0 || mlp_skip[p]) continue;
+      const int32_t* pi = ops[p].i;
+      bool bc = false;
+      for (int q = 0; q < pi[0]; ++q) bc = bc || pi[4 + 4 * q];
+      if (bc || pi[25] >= 0) continue;                                                    // no broadcast pieces, no residual on the hidden layer
+      if (pi[18] != ci[2] || pi[20] != ci[20] || pi[19] != 0 || pad4(ci[3]) != pad4(pi[21])) continue;   // same rows, whole width
+      if (pad4(pi[21]) > 64 || pad4(ci[21]) > 32) continue;
+      if ((pi[24] & 7) > 2 || (ci[24] & 7) > 4) continue;
+      bool ok = true;
+      if (ci[25] >= 0) for (int w : writers[ci[25]]) ok = ok && w < p;                    // residual input complete before the pair runs
+      for (int m = p + 1; m < c && ok; ++m) {                                             // nobody in between reads or writes the output buffer
+        op_io(ops[m], rd, wr);
+        for (int b : rd) ok = ok && b != ci[17];
+        for (int b : wr) ok = ok && b != ci[17];
+      }
+      if (!ok) continue;
+      mlp_child[p] = c;
+      mlp_skip[c] = 1;
+    }
   }
 
   // Which buffers can carry pair-compact lanes: outputs of FEAT_EE and of row-wise LINEAR ops on them (all
@@ -502,6 +547,7 @@ struct Engine : dqmc_ctx {
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
+    if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
@@ -1205,6 +1251,7 @@ struct Engine : dqmc_ctx {
     for (size_t opi = first_op; opi < ops.size(); ++opi) {
       const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
+      if (mlp_skip[opi]) continue;                      // second layer of a chained MLP: ran with its parent
       const hipStream_t so = stream_of(op);
       { const int rcb = before(op, so); if (rcb) return rcb; }
       switch (op.kind) {
@@ -1246,6 +1293,25 @@ struct Engine : dqmc_ctx {
           a.res_scale = i[27] ? (real)0.70710678118654752440 : (real)1;
           a.act = i[24]; a.nrows = i[20]; a.B = B; a.T = li.T; a.TP = li.TP;
           if (li.TP > 1 && compact[i[17]]) { a.T = dqmc::PAIR_LANES; a.TP = dqmc::PAIR_LANES; }   // row-wise op on edge rows
+          if (mlp_child[opi] >= 0 && dqmc::linear_chain_supported(a.TP, a.ldw, pad4(ops[mlp_child[opi]].i[21])) &&
+              compact[ops[mlp_child[opi]].i[17]] == compact[i[17]]) {
+            // hidden layer + output layer of a row-wise MLP in one launch (the hidden activations stay in LDS)
+            const dqmc_op& ch = ops[mlp_child[opi]];
+            const int32_t* c = ch.i;
+            { const int rcb = before(ch, so); if (rcb) return rcb; }
+            a.W2 = d_w + c[22]; a.ldw2 = pad4(c[21]); a.bias2 = c[23] >= 0 ? d_w + c[23] : nullptr; a.act2 = c[24];
+            a.dst = bptr(c[17]);
+            a.ld_dst = bufs[c[17]].width; a.rpw_dst = bufs[c[17]].rows; a.r0_dst = c[18]; a.col0_dst = c[19];
+            a.res = c[25] >= 0 ? bptr(c[25]) : nullptr;
+            if (c[25] >= 0) { a.ld_res = bufs[c[25]].width; a.rpw_res = bufs[c[25]].rows; a.r0_res = c[26]; }
+            a.res_scale = c[27] ? (real)0.70710678118654752440 : (real)1;
+            t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
+            dqmc::launch_linear_chain<real>(so, a);
+            t_end();
+            { const int rca = after(op, so); if (rca) return rca; }
+            { const int rca = after(ch, so); if (rca) return rca; }
+            continue;
+          }
           if (split_bcast && n_bc > 0 && n_bc < i[0] && i[20] > 1 && !(li.TP > 1 && compact[i[17]])) {
             // Per-walker (broadcast) pieces -- the spin means of the node update, reference gnn/update_features.py:64-106 --
             // contribute the same row to every electron of a walker: their product with W is computed ONCE per walker into

@@ -53,13 +53,179 @@ template <typename real> __device__ __forceinline__ void act_derivs(int act, rea
 
 template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
 
+// Where the epilogue puts its results.  HbmSink: the layer's output buffer (+ residual).  LdsSink: the hidden tile of a
+// chained two-layer MLP (k_linear<..., CHAIN = true>): row-major [BM][HS], zero where the row / column does not exist,
+// so that the second layer can multiply whole chunks.
+template <typename real> struct HbmSink {
+  const LinArgs<real>& a;
+  long drow0[2], rrow0[2];
+  __device__ __forceinline__ HbmSink(const LinArgs<real>& a_) : a(a_) {}
+  __device__ __forceinline__ void group(int slot, int g) {
+    const int b = g / a.nrows, rr = g - b * a.nrows;
+    drow0[slot] = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
+    rrow0[slot] = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
+  }
+  __device__ __forceinline__ void put(int slot, int t, int /*tile_row*/, int col, real o, bool ok) {
+    if (!ok) return;
+    if (a.res != nullptr) o = (a.res[(rrow0[slot] + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
+    a.dst[(drow0[slot] + t) * a.ld_dst + a.col0_dst + col] = o;
+  }
+};
+template <typename real> struct LdsSink {
+  real* hs;
+  int stride;
+  __device__ __forceinline__ void group(int, int) {}
+  __device__ __forceinline__ void put(int, int, int tile_row, int col, real o, bool ok) { hs[tile_row * stride + col] = ok ? o : (real)0; }
+};
+
+// bias + nonlinearity with the forward-Laplacian chain rule on the accumulators of one wave (header comment), results to
+// `sink`.  MR x NR accumulator tiles; wave `wm` of the workgroup's M stack; col_w0 = first column of the wave's tile.
+template <typename real, int MR, int NR, int GPW, typename Sink>
+__device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[MR][NR], const LinArgs<real>& a, const real* bias, int act,
+                                             int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink) {
+  constexpr bool HALF = GPW < 0;
+  constexpr int GB = GPW > 0 ? MR / GPW : 1;
+  constexpr int BM = 64 * MR;
+  const int lane = threadIdx.x & 63, cl = lane & 15;
+  if (HALF) {
+    // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15); a lane's four rows
+    // (Mfma::row_of) may belong to one group (f32 layout) or to both (f64 layout), so the value lane and
+    // the sum of squared derivative lanes of each group are gathered with quad reductions.
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      bool g_ok[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int g = ((blockIdx.x * 4 + wm) * MR + i) * 2 + h;
+        g_ok[h] = g < n_groups;
+        sink.group(h, g_ok[h] ? g : 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int col = col_w0 + n * 16 + cl;
+        const bool col_ok = col < ldw;
+        real v_part[2] = {0, 0}, s_part[2] = {0, 0};
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
+          const real x = acc[i][n][rg];
+          if (tt == 0) v_part[h] += x;
+          else if (tt < a.T - 1) s_part[h] += x * x;
+        }
+        real y[2], d1[2], d2[2], S[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          real v = quad_sum<real>(v_part[h]);
+          S[h] = quad_sum<real>(s_part[h]);
+          if (bias != nullptr && col_ok) v += bias[col];
+          act_derivs<real>(act, v, y[h], d1[h], d2[h]);
+        }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
+          const real x = acc[i][n][rg];
+          real o;
+          if (tt == 0) o = y[h];
+          else if (tt < a.T - 1) o = d1[h] * x;
+          else if (tt == a.T - 1) o = d1[h] * x + d2[h] * S[h];
+          else o = 0;
+          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, col_ok && g_ok[h]);
+        }
+      }
+    }
+  } else if (GPW > 0) {
+#pragma unroll
+    for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
+      const int g = (blockIdx.x * 4 + wm) * GPW + gj;
+      const bool g_ok = g < n_groups;        // wave-uniform
+      const int b = (g_ok ? g : 0) / a.nrows;
+      sink.group(0, g_ok ? g : 0);
+      if (pre != nullptr && g_ok) {  // per-walker part of the pre-activation (all lanes: the layer is linear in them)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_w0 + n * 16 + cl;
+          if (col < ldw) {
+#pragma unroll
+            for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg) {
+                const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
+                acc[gj * GB + tb][n][rg] += pre[((long)b * a.TP + t) * a.ld_pre + col];
+              }
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int col = col_w0 + n * 16 + cl;
+        const bool col_ok = col < ldw;
+        real v = __shfl(acc[gj * GB][n][0], cl, 64);
+        if (bias != nullptr && col_ok) v += bias[col];
+        real s_part = 0;
+#pragma unroll
+        for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
+            const real x = acc[gj * GB + tb][n][rg];
+            if (t >= 1 && t < a.T - 1) s_part += x * x;
+          }
+        const real S = quad_sum<real>(s_part);
+        real y, d1, d2;
+        act_derivs<real>(act, v, y, d1, d2);
+#pragma unroll
+        for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int row = Mfma<real>::row_of(lane, rg);
+            const int t = tb * 16 + row;
+            const real x = acc[gj * GB + tb][n][rg];
+            real o;
+            if (t == 0) o = y;
+            else if (t < a.T - 1) o = d1 * x;
+            else if (t == a.T - 1) o = d1 * x + d2 * S;
+            else o = 0;
+            sink.put(0, t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, col_ok && g_ok);
+          }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int tile_row = wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
+        const int m = blockIdx.x * BM + tile_row;
+        const bool m_ok = m < n_groups;
+        const int b = (m_ok ? m : 0) / a.nrows;
+        sink.group(0, m_ok ? m : 0);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_w0 + n * 16 + cl;
+          const bool col_ok = col < ldw;
+          real v = acc[i][n][rg];
+          if (pre != nullptr && col_ok) v += pre[(long)b * a.ld_pre + col];
+          if (bias != nullptr && col_ok) v += bias[col];
+          real y, d1, d2;
+          act_derivs<real>(act, v, y, d1, d2);
+          sink.put(0, 0, tile_row, col, y, col_ok && m_ok);
+        }
+      }
+  }
+}
+
 // GPW = -1: groups of 8 lanes (the pair-compact edge buffers of common.h), two per MFMA row block.
 // MR row blocks x NR column blocks per wave; GPW groups per wave (0: value-only rows); the
 // workgroup is 4 waves in M times WN waves in N (WN = 2: 512 threads, BN = 128, so a 128-wide
 // layer reads its A rows from HBM once).  A tile in LDS is row-major with stride BK + 2: the
 // 16 rows x 2 k of a half-wave fragment read land on 32 distinct banks (18*row mod 32 is a
 // permutation of the even banks), and the staging store is two 8-byte writes per thread.
-template <typename real, int MR, int NR, int GPW, int WN>
+//
+// CHAIN (WN = 1, one column tile): a row-wise two-layer MLP  Y = act2(act(X W + b) W2 + b2) (+ residual)  -- the edge
+// MLPs w / u and the node MLP h of a message-passing layer (reference gnn/electron_gnn.py:116-160, hkext.py:99-113) --
+// in ONE launch: the hidden activations of the tile (chain rule applied, all lanes) go to LDS instead of HBM and are the
+// A operand of the second product.  The hidden layer is at most 16 NR wide, the output at most 16 NR2.
+template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2>
 __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16;
@@ -68,10 +234,15 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   constexpr int GB = GPW > 0 ? MR / GPW : 1;            // row blocks per group
   constexpr int APT = MR / WN;                          // A float4 per thread and chunk
   constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
+  constexpr int HS = CHAIN ? BN + 2 : 1;                // hidden tile stride: 2 * odd -> conflict-free fragment reads
+  constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
+  static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
   typedef typename Mfma<real>::acc_t acc_t;
   __shared__ real As[BM * AS];
   __shared__ real Bs[BK * BS];
+  __shared__ real Hs[CHAIN ? BM * HS : 1];
+  __shared__ real Bs2[CHAIN ? BK * BS2 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -178,145 +349,50 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
     }
   }
 
-  // ---- epilogue ----
-  const int cl = lane & 15;
-  const int col_w0 = col_blk0 + wn * (16 * NR);
-  if (HALF) {
-    // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15); a lane's four rows
-    // (Mfma::row_of) may belong to one group (f32 layout) or to both (f64 layout), so the value lane and
-    // the sum of squared derivative lanes of each group are gathered with quad reductions.
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-      long drow0[2], rrow0[2];
-      bool g_ok[2];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int g = ((blockIdx.x * 4 + wm) * MR + i) * 2 + h;
-        g_ok[h] = g < n_groups;
-        const int gg = g_ok[h] ? g : 0;
-        const int b = gg / a.nrows, rr = gg - b * a.nrows;
-        drow0[h] = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
-        rrow0[h] = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
-      }
-#pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int col = col_w0 + n * 16 + cl;
-        const bool col_ok = col < a.ldw;
-        real v_part[2] = {0, 0}, s_part[2] = {0, 0};
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
-          const real x = acc[i][n][rg];
-          if (tt == 0) v_part[h] += x;
-          else if (tt < a.T - 1) s_part[h] += x * x;
-        }
-        real y[2], d1[2], d2[2], S[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          real v = quad_sum<real>(v_part[h]);
-          S[h] = quad_sum<real>(s_part[h]);
-          if (a.bias != nullptr && col_ok) v += a.bias[col];
-          act_derivs<real>(a.act, v, y[h], d1[h], d2[h]);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
-          const real x = acc[i][n][rg];
-          real o;
-          if (tt == 0) o = y[h];
-          else if (tt < a.T - 1) o = d1[h] * x;
-          else if (tt == a.T - 1) o = d1[h] * x + d2[h] * S[h];
-          else o = 0;
-          if (col_ok && g_ok[h]) {
-            if (a.res != nullptr) o = (a.res[(rrow0[h] + tt) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
-            a.dst[(drow0[h] + tt) * a.ld_dst + a.col0_dst + col] = o;
-          }
-        }
-      }
-    }
-  } else if (GPW > 0) {
-#pragma unroll
-    for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
-      const int g = (blockIdx.x * 4 + wm) * GPW + gj;
-      if (g >= n_groups) continue;   // wave-uniform
-      const int b = g / a.nrows, rr = g - b * a.nrows;
-      const long drow0 = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
-      const long rrow0 = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
-      if (a.pre != nullptr) {        // per-walker part of the pre-activation (all lanes: the layer is linear in them)
-#pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          const int col = col_w0 + n * 16 + cl;
-          if (col < a.ldw) {
-#pragma unroll
-            for (int tb = 0; tb < GB; ++tb)
-#pragma unroll
-              for (int rg = 0; rg < 4; ++rg) {
-                const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
-                acc[gj * GB + tb][n][rg] += a.pre[((long)b * a.TP + t) * a.ld_pre + col];
-              }
-          }
-        }
-      }
-#pragma unroll
-      for (int n = 0; n < NR; ++n) {
-        const int col = col_w0 + n * 16 + cl;
-        const bool col_ok = col < a.ldw;
-        real v = __shfl(acc[gj * GB][n][0], cl, 64);
-        if (a.bias != nullptr && col_ok) v += a.bias[col];
-        real s_part = 0;
-#pragma unroll
-        for (int tb = 0; tb < GB; ++tb)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
-            const real x = acc[gj * GB + tb][n][rg];
-            if (t >= 1 && t < a.T - 1) s_part += x * x;
-          }
-        const real S = quad_sum<real>(s_part);
-        real y, d1, d2;
-        act_derivs<real>(a.act, v, y, d1, d2);
-#pragma unroll
-        for (int tb = 0; tb < GB; ++tb)
-#pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
-            const real x = acc[gj * GB + tb][n][rg];
-            real o;
-            if (t == 0) o = y;
-            else if (t < a.T - 1) o = d1 * x;
-            else if (t == a.T - 1) o = d1 * x + d2 * S;
-            else o = 0;
-            if (col_ok) {
-              if (a.res != nullptr) o = (a.res[(rrow0 + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
-              a.dst[(drow0 + t) * a.ld_dst + a.col0_dst + col] = o;
-            }
-          }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int m = blockIdx.x * BM + wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
-        if (m >= n_groups) continue;
-        const int b = m / a.nrows, rr = m - b * a.nrows;
-        const long drow = (long)b * a.rpw_dst + a.r0_dst + rr;
-        const long rrow = a.res ? (long)b * a.rpw_res + a.r0_res + rr : 0;
-#pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          const int col = col_w0 + n * 16 + cl;
-          if (col >= a.ldw) continue;
-          real v = acc[i][n][rg];
-          if (a.pre != nullptr) v += a.pre[(long)b * a.ld_pre + col];
-          if (a.bias != nullptr) v += a.bias[col];
-          real y, d1, d2;
-          act_derivs<real>(a.act, v, y, d1, d2);
-          if (a.res != nullptr) y = (a.res[rrow * a.ld_res + a.col0_dst + col] + y) * a.res_scale;
-          a.dst[drow * a.ld_dst + a.col0_dst + col] = y;
-        }
-      }
+  if (!CHAIN) {
+    HbmSink<real> sink(a);
+    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink);
+    return;
   }
+  // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there ----
+  {
+    LdsSink<real> hsink{Hs, HS};
+    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink);
+  }
+  acc_t acc2[MR][NR2];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR2; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
+  const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
+  const int n_chunks2 = (K2 + BK - 1) / BK;
+  for (int kc = 0; kc < n_chunks2; ++kc) {
+    __syncthreads();                                      // hidden tile complete (kc = 0) / previous chunk of W2 consumed
+    for (int f = tid; f < BK * BN2 / 4; f += NT) {
+      const int k = f / (BN2 / 4), n4 = f % (BN2 / 4);
+      const int kk = kc * BK + k, col = 4 * n4;
+      Vec4<real> v{{0, 0, 0, 0}};
+      if (kk < K2 && col < a.ldw2) v = *reinterpret_cast<const Vec4<real>*>(a.W2 + (long)kk * a.ldw2 + col);
+      *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int kcol = kk * 4 + (lane >> 4);
+      if (kc * BK + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
+      real fa[MR], fb[NR2];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK + kcol];
+#pragma unroll
+      for (int j = 0; j < NR2; ++j) fb[j] = Bs2[kcol * BS2 + j * 16 + (lane & 15)];
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR2; ++j) acc2[i][j] = Mfma<real>::run(fa[i], fb[j], acc2[i][j]);
+    }
+  }
+  HbmSink<real> sink(a);
+  lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink);
 }
 
 template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
@@ -326,6 +402,32 @@ template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
+}
+template <typename real, int MR, int NR, int GPW> static void launch_chain_cfg(hipStream_t st, const LinArgs<real>& a) {
+  constexpr int BM = 64 * MR;
+  const long n_groups = (long)a.B * a.nrows;
+  const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
+                      : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2>), dim3(gx, 1), dim3(256), 0, st, a);
+}
+template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_t st, const LinArgs<real>& a) {
+  if (a.ldw > 32) launch_chain_cfg<real, MR, 4, GPW>(st, a);
+  else if (a.ldw > 16) launch_chain_cfg<real, MR, 2, GPW>(st, a);
+  else launch_chain_cfg<real, MR, 1, GPW>(st, a);
+}
+// Shapes the chained kernel is instantiated for: hidden width <= 64, output width <= 32, 8- / 16- / 32-lane groups or
+// value-only rows.
+bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out) {
+  return (TP == 1 || TP == 8 || TP == 16 || TP == 32) && ldw_hidden <= 64 && ldw_out <= 32;
+}
+template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a) {
+  switch (a.TP) {
+    case 1: launch_chain_nr<real, 1, 0>(st, a); break;
+    case 8: launch_chain_nr<real, 1, -1>(st, a); break;
+    case 16: launch_chain_nr<real, 1, 1>(st, a); break;
+    case 32: launch_chain_nr<real, 2, 1>(st, a); break;
+    default: break;
+  }
 }
 
 template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, const LinArgs<real>& a) {
@@ -376,5 +478,7 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
 
 template void launch_linear<float>(hipStream_t, const LinArgs<float>&);
 template void launch_linear<double>(hipStream_t, const LinArgs<double>&);
+template void launch_linear_chain<float>(hipStream_t, const LinArgs<float>&);
+template void launch_linear_chain<double>(hipStream_t, const LinArgs<double>&);
 
 }  // namespace dqmc

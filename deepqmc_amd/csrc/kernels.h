@@ -55,8 +55,16 @@ template <typename real> struct LinArgs {
   int nrows;          // rows per walker in this segment
   int B;
   int T, TP;
+  // chained second layer (launch_linear_chain): Y = act2(H W2 + bias2) with H = act(X W + bias) kept on chip;
+  // dst / res / col0_dst then describe Y
+  const real* W2;     // [ldw][ldw2]
+  int ldw2;           // pad4(Nout of the second layer)
+  const real* bias2;
+  int act2;
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
+template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
+bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
 struct FusedBuf {

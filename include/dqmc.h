@@ -261,7 +261,7 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * E_loc is not finite, are run again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign
  * replaced.  The threshold calibrates itself: on the first and then every "refine_probe"-th call a strided sample of
  * <= 64 further walkers is evaluated in float64 too, the measured float32 error per unit of score (90th percentile)
- * gives refine_thresh = target / c with target = 5e-6 relative; the count includes that sample on probe calls). */
+ * gives refine_thresh = target / c with target = 7e-6 relative; the count includes that sample on probe calls). */
 int dqmc_last_refined(dqmc_ctx* ctx);
 /* State of the refinement after the last local-energy call: out4 = {mode ("refine": 0 / 1 / 2; 0 in a float64
  * context), current score threshold, measured float32 error per unit of score (0 before the first probe), calls
@@ -287,7 +287,7 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
  * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set),
- * "refine_target_e7" (50): target relative error of the unrefined walkers in units of 1e-7.
+ * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 

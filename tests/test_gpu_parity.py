@@ -55,12 +55,8 @@ def test_f64_every_buffer(spec_fn, molname, B):
     spec, mol, h, tree, eng, it = setup(spec_fn, molname, torch.float64)
     r = synthetic_walkers(h, B, seed=3)
     ref = it.run(r, mol.coords, laplacian=True)
-    e, stats, grad = eng.local_energy(torch.as_tensor(r, device=DEV), return_grad=True)
-    worst = {}
-    for name, idx in eng.program.buf_names.items():
-        got = eng.debug_read(name, B)
-        worst[name] = float(np.abs(got - it.bufs[idx]).max())
-        np.testing.assert_allclose(got, it.bufs[idx], rtol=1e-9, atol=1e-9, err_msg=f'buffer {name}')
+    from buffers_util import check_every_buffer
+    (e, stats, grad), worst = check_every_buffer(eng, it, B, lambda: eng.local_energy(torch.as_tensor(r, device=DEV), return_grad=True))
     np.testing.assert_array_equal(eng.debug_read('sign_k', B), it.sign_k)
     np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(e.cpu().numpy(), ref['e_loc'], rtol=1e-9, atol=1e-8)

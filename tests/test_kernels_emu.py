@@ -34,10 +34,8 @@ def test_emu_f64_buffers_and_energy(spec_fn, molname):
     B = 3
     spec, mol, h, eng, r, it = _setup(spec_fn, molname, torch.float64, B)
     ref = it.run(r, mol.coords, laplacian=True)
-    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
-    for name, idx in eng.program.buf_names.items():
-        got = eng.debug_read(name, B)
-        np.testing.assert_allclose(got, it.bufs[idx], rtol=1e-10, atol=1e-10, err_msg=f'buffer {name}')
+    from buffers_util import check_every_buffer
+    (e, stats, grad), _ = check_every_buffer(eng, it, B, lambda: eng.local_energy(torch.as_tensor(r), return_grad=True), rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-9, atol=1e-9)
     np.testing.assert_array_equal(eng.debug_read('sign_k', B), it.sign_k)
     np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-9, atol=1e-9)

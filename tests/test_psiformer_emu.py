@@ -31,9 +31,8 @@ def test_psiformer_emu_f64():
     r = make_walkers(mol, h.n_elec, B)
     it = Interp(eng.program, mol.charges, geom.F32_EPS)
     ref = it.run(r, mol.coords, laplacian=True)
-    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
-    for name, idx in eng.program.buf_names.items():
-        np.testing.assert_allclose(eng.debug_read(name, B), it.bufs[idx], rtol=1e-9, atol=1e-9, err_msg=name)
+    from buffers_util import check_every_buffer
+    (e, stats, grad), _ = check_every_buffer(eng, it, B, lambda: eng.local_energy(torch.as_tensor(r), return_grad=True))
     np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
     val = it.run(r, mol.coords, laplacian=False)
@@ -58,9 +57,8 @@ def test_transpsiformer_emu_f64():
     r = make_walkers(mol, h.n_elec, B)
     it = Interp(eng.program, mol.charges, geom.F32_EPS)
     ref = it.run(r, mol.coords, laplacian=True)
-    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
-    for name, idx in eng.program.buf_names.items():
-        np.testing.assert_allclose(eng.debug_read(name, B), it.bufs[idx], rtol=1e-9, atol=1e-9, err_msg=name)
+    from buffers_util import check_every_buffer
+    (e, stats, grad), _ = check_every_buffer(eng, it, B, lambda: eng.local_energy(torch.as_tensor(r), return_grad=True))
     np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
     np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
     T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
