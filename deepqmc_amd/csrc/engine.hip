@@ -547,6 +547,7 @@ struct Engine : dqmc_ctx {
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
+    if (s == "linear_bkx") { dqmc::set_linear_bkx(value); return DQMC_OK; }      // (process-wide A/B hook of kernel_linear.hip)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }

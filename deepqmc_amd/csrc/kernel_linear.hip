@@ -67,8 +67,9 @@ template <typename real> struct HbmSink {
   }
   __device__ __forceinline__ void put(int slot, int t, int /*tile_row*/, int col, real o, bool ok) {
     if (!ok) return;
-    if (a.res != nullptr) o = (a.res[(rrow0[slot] + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
-    a.dst[(drow0[slot] + t) * a.ld_dst + a.col0_dst + col] = o;
+    const long dr = slot ? drow0[1] : drow0[0], rr = slot ? rrow0[1] : rrow0[0];      // (selects: a per-lane index would put the arrays in scratch)
+    if (a.res != nullptr) o = (a.res[(rr + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
+    a.dst[(dr + t) * a.ld_dst + a.col0_dst + col] = o;
   }
 };
 template <typename real> struct LdsSink {
@@ -109,8 +110,9 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         for (int rg = 0; rg < 4; ++rg) {
           const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
           const real x = acc[i][n][rg];
-          if (tt == 0) v_part[h] += x;
-          else if (tt < a.T - 1) s_part[h] += x * x;
+          const real vx = tt == 0 ? x : (real)0, sx = (tt > 0 && tt < a.T - 1) ? x * x : (real)0;
+          v_part[0] += h ? (real)0 : vx; v_part[1] += h ? vx : (real)0;
+          s_part[0] += h ? (real)0 : sx; s_part[1] += h ? sx : (real)0;
         }
         real y[2], d1[2], d2[2], S[2];
 #pragma unroll
@@ -124,12 +126,13 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         for (int rg = 0; rg < 4; ++rg) {
           const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
           const real x = acc[i][n][rg];
+          const real yh = h ? y[1] : y[0], d1h = h ? d1[1] : d1[0], d2h = h ? d2[1] : d2[0], Sh = h ? S[1] : S[0];
           real o;
-          if (tt == 0) o = y[h];
-          else if (tt < a.T - 1) o = d1[h] * x;
-          else if (tt == a.T - 1) o = d1[h] * x + d2[h] * S[h];
+          if (tt == 0) o = yh;
+          else if (tt < a.T - 1) o = d1h * x;
+          else if (tt == a.T - 1) o = d1h * x + d2h * Sh;
           else o = 0;
-          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, col_ok && g_ok[h]);
+          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, col_ok && (h ? g_ok[1] : g_ok[0]));
         }
       }
     }
@@ -225,10 +228,15 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // MLPs w / u and the node MLP h of a message-passing layer (reference gnn/electron_gnn.py:116-160, hkext.py:99-113) --
 // in ONE launch: the hidden activations of the tile (chain rule applied, all lanes) go to LDS instead of HBM and are the
 // A operand of the second product.  The hidden layer is at most 16 NR wide, the output at most 16 NR2.
-template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2>
+//
+// BKX: K chunk = 16 BKX.  The small-tile configurations (MR = 1: the narrow layers of the few-electron systems, which
+// stream their rows once) are bound by the latency of the chunk loads, not by bandwidth or MFMA rate -- each thread has
+// one 16-byte A load and one B load in flight per chunk; BKX = 2 doubles the bytes in flight per workgroup and halves
+// the number of load -> barrier -> multiply round trips.
+template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1>
 __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
-  constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16;
+  constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
   constexpr int AS = BK + 2, BS = BStride<BN>::v;
   constexpr bool HALF = GPW < 0;                        // 8-lane groups: two per row block
   constexpr int GB = GPW > 0 ? MR / GPW : 1;            // row blocks per group
@@ -242,7 +250,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   __shared__ real As[BM * AS];
   __shared__ real Bs[BK * BS];
   __shared__ real Hs[CHAIN ? BM * HS : 1];
-  __shared__ real Bs2[CHAIN ? BK * BS2 : 1];
+  __shared__ real Bs2[CHAIN ? BK2 * BS2 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -295,14 +303,16 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT], rb_[NBV];
+    Vec4<real> ra[APT][BKX], rb_[NBV];
     auto load_chunk = [&](int kc) {
-      const int k0 = kc * BK + 4 * a_kq;
 #pragma unroll
-      for (int j = 0; j < APT; ++j) {
-        if (a_src[j] != nullptr && k0 < pc.K) ra[j] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
-        else ra[j] = Vec4<real>{{0, 0, 0, 0}};
-      }
+      for (int j = 0; j < APT; ++j)
+#pragma unroll
+        for (int x = 0; x < BKX; ++x) {
+          const int k0 = kc * BK + 16 * x + 4 * a_kq;
+          if (a_src[j] != nullptr && k0 < pc.K) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
+          else ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
+        }
 #pragma unroll
       for (int j = 0; j < NBV; ++j) {
         const int f = tid + NT * j;
@@ -318,11 +328,13 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
     for (int kc = 0; kc < n_chunks; ++kc) {
       __syncthreads();  // previous chunk's fragments have been read
 #pragma unroll
-      for (int j = 0; j < APT; ++j) {
-        Vec2<real>* dst = reinterpret_cast<Vec2<real>*>(&As[a_row[j] * AS + 4 * a_kq]);
-        dst[0] = Vec2<real>{{ra[j].v[0], ra[j].v[1]}};
-        dst[1] = Vec2<real>{{ra[j].v[2], ra[j].v[3]}};
-      }
+      for (int j = 0; j < APT; ++j)
+#pragma unroll
+        for (int x = 0; x < BKX; ++x) {
+          Vec2<real>* dst = reinterpret_cast<Vec2<real>*>(&As[a_row[j] * AS + 16 * x + 4 * a_kq]);
+          dst[0] = Vec2<real>{{ra[j][x].v[0], ra[j][x].v[1]}};
+          dst[1] = Vec2<real>{{ra[j][x].v[2], ra[j][x].v[3]}};
+        }
 #pragma unroll
       for (int j = 0; j < NBV; ++j) {
         const int f = tid + NT * j;
@@ -334,7 +346,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
       __syncthreads();
       if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < BK / 4; ++kk) {
         const int kcol = kk * 4 + (lane >> 4);
         real fa[MR], fb[NR];
 #pragma unroll
@@ -365,24 +377,25 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 #pragma unroll
     for (int j = 0; j < NR2; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
   const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
-  const int n_chunks2 = (K2 + BK - 1) / BK;
+  const int n_chunks2 = (K2 + BK2 - 1) / BK2;
   for (int kc = 0; kc < n_chunks2; ++kc) {
     __syncthreads();                                      // hidden tile complete (kc = 0) / previous chunk of W2 consumed
-    for (int f = tid; f < BK * BN2 / 4; f += NT) {
+    for (int f = tid; f < BK2 * BN2 / 4; f += NT) {
       const int k = f / (BN2 / 4), n4 = f % (BN2 / 4);
-      const int kk = kc * BK + k, col = 4 * n4;
-      Vec4<real> v{{0, 0, 0, 0}};
+      const int kk = kc * BK2 + k, col = 4 * n4;
+      Vec4<real> v;
       if (kk < K2 && col < a.ldw2) v = *reinterpret_cast<const Vec4<real>*>(a.W2 + (long)kk * a.ldw2 + col);
+      else v = Vec4<real>{{0, 0, 0, 0}};
       *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = v;
     }
     __syncthreads();
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int kcol = kk * 4 + (lane >> 4);
-      if (kc * BK + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
+      if (kc * BK2 + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
       real fa[MR], fb[NR2];
 #pragma unroll
-      for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK + kcol];
+      for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK2 + kcol];
 #pragma unroll
       for (int j = 0; j < NR2; ++j) fb[j] = Bs2[kcol * BS2 + j * 16 + (lane & 15)];
 #pragma unroll
@@ -395,20 +408,36 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink);
 }
 
+// A/B hook (dqmc_set_option "linear_bkx"): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
+// 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
+static int g_linear_bkx = 3;
+void set_linear_bkx(int v) { g_linear_bkx = v; }
+template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
+  int kmax = 0;
+  for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
+  const bool on = sizeof(real) == 4 ? (g_linear_bkx == 2 || g_linear_bkx == 4) : (g_linear_bkx == 3 || g_linear_bkx == 4);
+  return on && kmax >= 32;
+}
 template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   const long n_groups = (long)a.B * a.nrows;
   const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
+  if (MR == 1 && WN == 1 && GPW != 0 && wide_chunks(a))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW != 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
 }
 template <typename real, int MR, int NR, int GPW> static void launch_chain_cfg(hipStream_t st, const LinArgs<real>& a) {
   constexpr int BM = 64 * MR;
   const long n_groups = (long)a.B * a.nrows;
   const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2>), dim3(gx, 1), dim3(256), 0, st, a);
+  if (MR == 1 && GPW != 0 && wide_chunks(a))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2, (MR == 1 && GPW != 0) ? 2 : 1>), dim3(gx, 1), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2>), dim3(gx, 1), dim3(256), 0, st, a);
 }
 template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_t st, const LinArgs<real>& a) {
   if (a.ldw > 32) launch_chain_cfg<real, MR, 4, GPW>(st, a);

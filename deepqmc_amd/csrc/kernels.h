@@ -65,6 +65,7 @@ template <typename real> struct LinArgs {
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
+void set_linear_bkx(int v);
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
 struct FusedBuf {
