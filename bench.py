@@ -180,6 +180,8 @@ def main():
     ap.add_argument('--ansatz', default='paulinet')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f64'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--equilibrate', type=int, default=400, help='untimed Metropolis sub-steps before the warm-up steps, so that the timed '
+                    'steps see |psi|^2-distributed walkers (the reference equilibrates its sampler before training, sampling_utils.py:133-170); 0: off')
     ap.add_argument('--ecp', action='store_true', help='Gaussian-type ECP on every atom heavier than He with SYNTHETIC '
                     'coefficients (pyscf tables are not available offline): exercises the 12 N n_ecp psi-ratio quadrature')
     ap.add_argument('--fused', type=int, default=1, help='0: one launch per op for psi evaluation')
@@ -380,6 +382,17 @@ def main():
         assert not args.overlap, '--overlap is a single-state arrangement'
         state = ms_state
     stats = None
+    if args.equilibrate > 0 and args.n_sub > 0:
+        # atom-centred Gaussian walkers sit near the nodes of psi far more often than |psi|^2-distributed ones: burn in
+        # with plain sub-steps (no local energy) before anything is timed or reported
+        burn = DecorrSampler(hamil, wf, length=min(50, args.equilibrate))
+        for k in range((args.equilibrate + burn.length - 1) // burn.length):
+            if S > 1:
+                state = [burn.sample(900_000 + k * S + s_, state[s_], params_s[s_])[0] for s_ in range(S)]
+            else:
+                state = burn.sample(900_000 + k, state, params)[0]
+        sync()
+        log(f'equilibrated with {args.equilibrate} sub-steps')
     for s in range(args.warmup):
         state, stats = step_fn(s, state)
     if args.overlap:

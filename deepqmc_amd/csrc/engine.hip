@@ -225,6 +225,7 @@ struct Engine : dqmc_ctx {
   // enqueue the float64 pass at a capacity before the flagged count is known on the host (option "refine_ahead"; off by
   // default: the twin's kernels, not their launches, are what costs -- at 1.5 x headroom the larger pass loses 0.2 ms of a
   // 6.3 ms step on LiH / PauliNet against the synchronous path, measured in one call)
+  int twin_full_budget = 1;      // the twin's activation workspace may be as large as this context's (option "twin_full_budget")
   int refine_ahead = 0;
   int ahead_cap = 0, ahead_pos = 0;
   int ahead_hist[4] = {0, 0, 0, 0};
@@ -547,6 +548,7 @@ struct Engine : dqmc_ctx {
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
+    if (s == "linear_f64_nr1") { dqmc::set_linear_f64_nr1(value); return DQMC_OK; }
     if (s == "linear_bkx") { dqmc::set_linear_bkx(value); return DQMC_OK; }      // (process-wide A/B hook of kernel_linear.hip)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
@@ -564,6 +566,7 @@ struct Engine : dqmc_ctx {
       return build_fused_plan();
     }
     if (s == "refine") { refine = value; return DQMC_OK; }
+    if (s == "twin_full_budget") { twin_full_budget = value; if (twin) twin->option("ws_budget_mb", (int)((value ? ws_budget : ws_budget / 2) >> 20)); return DQMC_OK; }
     if (s == "refine_ahead") { refine_ahead = value; return DQMC_OK; }
     if (s == "refine_probe") { if (value < 0) return fail(DQMC_E_ARG, "refine_probe must be >= 0"); refine_probe = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
@@ -1477,7 +1480,7 @@ struct Engine : dqmc_ctx {
     if (!rc && !ph_mask_h.empty()) rc = t->set_ph(ph_grid, ph_rmax, ph_loc_h.data(), ph_l2_h.data(), ph_mask_h.data());
     for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
     if (rc) { delete t; return rc; }
-    t->ws_budget = ws_budget / 2;
+    t->ws_budget = twin_full_budget ? ws_budget : ws_budget / 2;
     twin = t;
     return DQMC_OK;
   }
@@ -1523,11 +1526,12 @@ struct Engine : dqmc_ctx {
     if (use_score) {
       // probe call: the new threshold needs the float64 energies of the sample on the host first; then only the walkers
       // above it are written back (d_score / refine_thresh at that moment)
-      std::vector<double> e_h((size_t)n - n_scatter);
-      if (!e_h.empty()) HIP_TRY(hipMemcpyAsync(e_h.data(), e64 + n_scatter, sizeof(double) * e_h.size(), hipMemcpyDeviceToHost, st));
+      std::vector<double> e_h((size_t)n);
+      HIP_TRY(hipMemcpyAsync(e_h.data(), e64, sizeof(double) * e_h.size(), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       probe_sample_e = e_h;
       if (probe_rethreshold) probe_rethreshold();
+      n_scatter = n;                       // every evaluated walker above the NEW threshold is written back
     }
     dqmc::launch_refine_scatter(st, d_list, d_count, n, n_scatter, use_score ? d_score : nullptr, refine_thresh, n3, e64, s64, g64, l64, sg64,
                                 (float*)e_loc, (float*)stats, (long)B, (float*)grad, (float*)logpsi, sign);
@@ -1608,12 +1612,21 @@ struct Engine : dqmc_ctx {
         HIP_TRY(hipStreamSynchronize(st));
         if (n > B) n = B;
         last_refined = n < cap ? n : cap;
-        if (n > cap) {
+        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) {
+          // most of the batch is beyond float32: like the synchronous path, this call and the next 15 go to float64 whole
+          refine_all_calls = 15;
+          std::vector<int32_t> iota((size_t)B);
+          for (int k = 0; k < B; ++k) iota[k] = k;
+          rc = upload_list(iota);
+          if (rc) return rc;
+          last_refined = 0;
+          rc = refine_listed(r, R, B, B, e_loc, stats, grad, logpsi, sign);
+          if (rc) return rc;
+        } else if (n > cap) {
           rc = refine_listed(r, R, B, n - cap, e_loc, stats, grad, logpsi, sign, nullptr, d_flag + 1 + cap);
           if (rc) return rc;
         }
         update_ahead_cap(n, B);
-        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) refine_all_calls = 15;
         HIP_TRY(hipGetLastError());
         return DQMC_OK;
       }
@@ -1651,13 +1664,22 @@ struct Engine : dqmc_ctx {
       HIP_TRY(hipMemcpyAsync(score.data(), d_score, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipMemcpyAsync(e32.data(), e_loc, sizeof(float) * (size_t)B, hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
-      std::vector<char> done((size_t)B, 0);
+      std::vector<char> done((size_t)B, 0);        // 1: evaluated in float64 by the first pass of this call (flagged or sample)
       for (int32_t b : flagged) if (b >= 0 && b < B) done[b] = 1;
+      // calibration sample: a strided subset of the WHOLE batch (flagged or not: every walker is an (error, score) pair; a
+      // system whose walkers all sit above the current threshold must still be able to move it)
       const int ns = B < 64 ? B : 64;
       std::vector<int32_t> sample, list(flagged);
-      for (int j = 0; j < ns; ++j) {
-        const int b = (int)((long)j * B / ns);
-        if (!done[b]) { sample.push_back(b); list.push_back(b); }   // flagged walkers say nothing about the unflagged population
+      std::vector<int> sample_pos;                 // position of each sample walker in `list`
+      {
+        std::vector<int> pos_of((size_t)B, -1);
+        for (size_t k = 0; k < flagged.size(); ++k) if (flagged[k] >= 0 && flagged[k] < B) pos_of[flagged[k]] = (int)k;
+        for (int j = 0; j < ns; ++j) {
+          const int b = (int)((long)j * B / ns);
+          if (pos_of[b] < 0) { pos_of[b] = (int)list.size(); list.push_back(b); done[b] = 1; }
+          sample.push_back(b);
+          sample_pos.push_back(pos_of[b]);
+        }
       }
       // ONE float64 pass over flagged + sample; between its evaluation and its write-back the threshold is re-derived from
       // the sample, and only walkers above the NEW threshold are written back: what a walker's result is depends on its
@@ -1668,7 +1690,8 @@ struct Engine : dqmc_ctx {
         std::vector<double> cs;
         for (size_t k = 0; k < sample.size(); ++k) {
           const int32_t b = sample[k];
-          const double rel = std::fabs(probe_sample_e[k] - (double)e32[b]) / std::fmax(1.0, std::fabs(probe_sample_e[k]));
+          const double e64v = probe_sample_e[(size_t)sample_pos[k]];
+          const double rel = std::fabs(e64v - (double)e32[b]) / std::fmax(1.0, std::fabs(e64v));
           if (std::isfinite(rel) && std::isfinite(score[b]) && score[b] > 0) cs.push_back(rel / score[b]);
         }
         if (cs.size() >= 2) {
@@ -1678,19 +1701,24 @@ struct Engine : dqmc_ctx {
           refine_thresh = std::fmin(std::fmax(refine_target / probe_c, 1.0), 1e9);
         }
       };
-      rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign, nullptr, nullptr, (int)flagged.size(), true);
+      rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign, nullptr, nullptr, 0, true);
       probe_rethreshold = nullptr;
       if (rc) return rc;
-      for (int32_t b : flagged) if (b >= 0 && b < B) { if (score[b] <= refine_thresh) done[b] = 2; else ++last_refined; }   // 2: evaluated, float32 result stands
       calls_since_probe = 0;
+      long n_above = 0;
+      for (int b = 0; b < B; ++b) if (!(score[b] <= refine_thresh)) ++n_above;
       std::vector<int32_t> more;
-      for (int b = 0; b < B; ++b) if (!done[b] && !(score[b] <= refine_thresh)) more.push_back(b);      // (sample walkers included)
-      if (refine == 1 && 2 * ((long)flagged.size() + (long)more.size()) > (long)B && B >= 16) {
+      if (refine == 1 && 2 * n_above > (long)B && B >= 16) {
         // most of the batch is beyond float32: the next calls go to float64 directly, and so does the rest of this one
         // (the few walkers below the threshold of such a system are not reliably predicted either)
         refine_all_calls = 15;
-        more.clear();
-        for (int b = 0; b < B; ++b) if (done[b] != 1) more.push_back(b);
+        for (int b = 0; b < B; ++b) if (!done[b] || score[b] <= refine_thresh) more.push_back(b);     // not yet written back
+        last_refined = B - (int)more.size();
+      } else {
+        for (int b = 0; b < B; ++b) {
+          if (score[b] <= refine_thresh) continue;
+          if (done[b]) ++last_refined; else more.push_back(b);
+        }
       }
       if (!more.empty()) {
         rc = upload_list(more);

@@ -411,6 +411,11 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 // A/B hook (dqmc_set_option "linear_bkx"): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
 // 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
 static int g_linear_bkx = 3;
+// float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
+// alone are 96 / 128 registers and ONE wave per SIMD remains; one column block per wave (option "linear_f64_nr1")
+// doubles the waves per SIMD at the price of reading the A rows twice as often
+static int g_linear_f64_tall_nr1 = 0;
+void set_linear_f64_nr1(int v) { g_linear_f64_tall_nr1 = v; }
 void set_linear_bkx(int v) { g_linear_bkx = v; }
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
   int kmax = 0;
@@ -464,7 +469,7 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
   constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0;   // 8 waves, BN = 128: the A rows of a wide layer are read half as often
   if (a.ldw > 64 && WIDE) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, (WIDE ? 2 : 1)>(st, a);
   else if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, 1>(st, a);
-  else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW, 1>(st, a);
+  else if (a.ldw > 16 && !(sizeof(real) == 8 && MR >= 6 && g_linear_f64_tall_nr1)) launch_cfg<real, MR, 2, GPW, 1>(st, a);
   else launch_cfg<real, MR, 1, GPW, 1>(st, a);
 }
 

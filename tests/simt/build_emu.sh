@@ -1,10 +1,14 @@
 #!/bin/sh
 # Build the SIMT-emulated library from the UNMODIFIED kernel sources (test infrastructure).
+# Concurrent callers (two ranks of a gloo test) are serialised by a lock; the library is re-linked only when an object
+# changed and replaced atomically, so a process that has it mapped never sees a half-written file.
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 SRC=$HERE/../../deepqmc_amd/csrc
 OUT=$HERE/_build
 mkdir -p "$OUT"
+exec 9> "$OUT/.lock"
+flock 9
 FLAGS="-x c++ -std=c++17 -O1 -fPIC -w -I$HERE -I$SRC -I$HERE/../../include"
 pids=""
 for f in engine kernel_linear kernel_fused2 kernel_attention kernel_attention_mfma kernels_graph kernels_head kernels_mcmc kernels_ecp; do
@@ -16,6 +20,14 @@ for f in engine kernel_linear kernel_fused2 kernel_attention kernel_attention_mf
   fi
 done
 for p in $pids; do wait $p; done
-g++ -std=c++17 -O1 -fPIC -w -I"$HERE" -c "$HERE/simt_runtime.cpp" -o "$OUT/simt_runtime.o"
-g++ -shared -o "$OUT/libdqmc_emu.so" "$OUT"/engine.o "$OUT"/kernel_linear.o "$OUT"/kernel_fused2.o "$OUT"/kernel_attention.o "$OUT"/kernel_attention_mfma.o "$OUT"/kernels_graph.o "$OUT"/kernels_head.o "$OUT"/kernels_mcmc.o "$OUT"/kernels_ecp.o "$OUT"/simt_runtime.o
+if [ ! -f "$OUT/simt_runtime.o" ] || [ "$HERE/simt_runtime.cpp" -nt "$OUT/simt_runtime.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$OUT/simt_runtime.o" ]; then
+  g++ -std=c++17 -O1 -fPIC -w -I"$HERE" -c "$HERE/simt_runtime.cpp" -o "$OUT/simt_runtime.o"
+fi
+relink=0
+[ -f "$OUT/libdqmc_emu.so" ] || relink=1
+for o in "$OUT"/*.o; do [ "$o" -nt "$OUT/libdqmc_emu.so" ] && relink=1; done
+if [ $relink = 1 ]; then
+  g++ -shared -o "$OUT/libdqmc_emu.so.tmp$$" "$OUT"/engine.o "$OUT"/kernel_linear.o "$OUT"/kernel_fused2.o "$OUT"/kernel_attention.o "$OUT"/kernel_attention_mfma.o "$OUT"/kernels_graph.o "$OUT"/kernels_head.o "$OUT"/kernels_mcmc.o "$OUT"/kernels_ecp.o "$OUT"/simt_runtime.o
+  mv -f "$OUT/libdqmc_emu.so.tmp$$" "$OUT/libdqmc_emu.so"
+fi
 echo "$OUT/libdqmc_emu.so"

@@ -168,17 +168,20 @@ def test_f64_refinement_of_ill_conditioned_walkers():
 
 
 def test_enqueue_ahead_refinement_matches_the_synchronous_path():
-    """The float64 pass enqueued at a capacity before the host knows the flagged count (engine.hip: refine_ahead) must give
-    exactly what the synchronous path gives: padding slots are not scattered back, an overflow of the capacity is finished
-    by a second pass over the remainder."""
+    """The float64 pass enqueued at a capacity before the host knows the flagged count (engine.hip: option refine_ahead)
+    must give exactly what the synchronous path gives: padding slots are not scattered back, an overflow of the capacity
+    is finished by a second pass over the remainder.  (A reduced PauliNet keeps the emulation short.)"""
+    import dataclasses
+    from deepqmc_amd.params import init_params
+    from deepqmc_amd.spec import paulinet
     h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
-    wf32 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-    params = wf32.init(5, perturb_envelopes=0.1)
-    B = 16
+    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)
+    params = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    B = 24
     r = torch.as_tensor(synthetic_walkers(h, B, seed=21).astype(np.float32))
 
     def engine(ahead):
-        e = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+        e = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
         e.set_option('refine_probe', 0)
         e.set_option('refine_ahead', ahead)
         return e
@@ -187,13 +190,15 @@ def test_enqueue_ahead_refinement_matches_the_synchronous_path():
     e0, st0 = plain.local_energy(r)
     score = np.sort(((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e0.abs().clamp(min=1.0)).numpy()
                     * np.maximum(1.0, plain.debug_read('kappa', B)))
-    thr_few, thr_many = int(score[-3]), max(1, int(score[-10]))        # 2 and ~9 walkers above: capacity 8 holds / overflows
+    thr_few, thr_many = int(score[-3]), max(1, int(score[-12]))        # 2 and 11 walkers above (a minority of 24): capacity 8 holds / overflows
     sync, ahead = engine(0), engine(1)      # (refine_ahead is opt-in)
-    for thr in (thr_few, thr_few, thr_many):      # sync call (sets the capacity), ahead call within capacity, overflow
+    n_few, n_many = int((score > thr_few).sum()), int((score > thr_many).sum())
+    assert 0 < n_few <= 8 < n_many <= B // 2
+    for thr, n_expect in ((thr_few, n_few), (thr_few, n_few), (thr_many, n_many)):      # sync call (sets the capacity), ahead call within capacity, overflow
         for e in (sync, ahead):
             e.set_option('refine_thresh', thr)
         (es, ss, gs), (ea, sa, ga) = sync.local_energy(r, return_grad=True), ahead.local_energy(r, return_grad=True)
-        assert sync.last_refined() == ahead.last_refined() > 0
+        assert sync.last_refined() == ahead.last_refined() == n_expect
         np.testing.assert_array_equal(es.numpy(), ea.numpy())
         np.testing.assert_array_equal(gs.numpy(), ga.numpy())
         for k in ss:

@@ -48,12 +48,12 @@ BOUNDS = {
     'lih_paulinet_4096': (0.99, 1e-6, 1e-5, 2e-5, 1e-5),
     'lih_psiformer_256': (0.99, 2e-6, 1e-5, 2e-5, 2e-5),
     'n2_ferminet_512': (0.99, 2e-6, 1e-5, 2e-5, 1e-4),
-    'benzene_psiformer_8': (0.99, 1e-6, 1e-5, 1e-5, 5e-4),
+    'benzene_psiformer_8': (0.99, 3e-6, 1e-5, 1e-5, 5e-4),
     'c4h4_transpsiformer_64': (0.99, 1e-6, 1e-5, 1e-5, 1e-3),     # the probe sends this system to the direct float64 pass
     'lih_paulinet_raw_1024': (0.99, 1e-6, 1e-5, 5e-5, 5e-4),      # raw Gaussian walkers: log|psi| near nodes is not refined
     # round 3: BASELINE batch sizes
     'n2_ferminet_4096': (0.99, 2e-6, 1e-5, 5e-5, 1e-4),
-    'benzene_psiformer_256': (0.99, 1e-6, 1e-5, 2e-5, 1e-3),
+    'benzene_psiformer_256': (0.99, 3e-6, 1e-5, 2e-5, 1e-3),
     'c4h4_transpsiformer_512': (0.99, 1e-6, 1e-5, 2e-5, 1e-3),
     'benzene_ecp_psiformer_32': (0.99, 2e-6, 1e-5, 2e-5, 1e-3),   # + V_nl: 2 160 psi ratios per walker (float64 for refined walkers)
 }

@@ -159,14 +159,19 @@ def test_multi_geometry_batches_incl_nuclear_tokens():
         state, pc, stats = ms.sample(1, state, params, [1, 0])
         E, st = loss.compute_local_energy(None, h, wf, params, pc)
         assert E.shape == (2, S, B) and torch.isfinite(E).all()
+        # against the ORACLE at the geometry each sample belongs to (not against another HIP context)
+        from oracle import physics
+        from oracle import wf as owf
+        T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
         for k, m in enumerate([1, 0]):
-            mol = Molecule(coords=Rs[m].cpu().numpy(), charges=h.mol.charges, charge=h.mol.charge, spin=h.mol.spin)
+            Rm = T(Rs[m].cpu().numpy())
             for s in range(S):
-                eng = Engine(wf.spec, MolecularHamiltonian(mol=mol), params[s], dtype=torch.float64, device=DEV, norm_eps=geom.F32_EPS)
-                e_ref, _ = eng.local_energy(pc.r[k, s])
-                np.testing.assert_allclose(E[k, s].cpu().numpy(), e_ref.cpu().numpy(), rtol=1e-11, atol=1e-11)
-                sg, lg = eng.wf_eval(pc.r[k, s])
-                np.testing.assert_allclose(state['elec'][m][s]['psi'].log.cpu().numpy(), lg.cpu().numpy(), rtol=1e-11, atol=1e-11)
+                p = owf.to_torch(params[s])
+                rk = T(pc.r[k, s].cpu().numpy())
+                e_ref, _, _ = physics.batch_local_energy(p, wf.spec, rk, Rm, T(h.mol.charges), h.n_up, geom.F32_EPS)
+                np.testing.assert_allclose(E[k, s].cpu().numpy(), e_ref.numpy(), rtol=1e-8, atol=1e-8)
+                _, lg = physics.batch_wave_function(p, wf.spec, T(state['elec'][m][s]['r'].cpu().numpy()), Rm, h.n_up, geom.F32_EPS)
+                np.testing.assert_allclose(state['elec'][m][s]['psi'].log.cpu().numpy(), lg.numpy(), rtol=1e-9, atol=1e-9)
 
 
 def test_inlib_rccl_allgather_single_rank():
