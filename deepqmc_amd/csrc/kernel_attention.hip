@@ -101,15 +101,49 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
     __syncthreads();
     load_tile(q, t, qc); load_kv(k, k_const, t, kc); load_kv(v, v_const, t, vc);
     __syncthreads();
-    for (int e = tid; e < NN; e += nthr) {
-      const int i = e / M, j = e - i * M;
-      real s = 0, qk = 0;
-      for (int d = 0; d < hd; ++d) {
-        s += qc[i * S + d] * k0[j * S + d] + q0[i * S + d] * kc[j * S + d];
-        qk += qc[i * S + d] * kc[j * S + d];
+    // register tiles of TI x TJ logits per thread: the q / k rows of a tile are read once per d and feed TI * TJ * 3
+    // multiply-adds (one logit per thread meant 4 LDS reads per 3 multiply-adds: the loop ran at the LDS read rate)
+    {
+      constexpr int TI = 2, TJ = 4;
+      const int nti = (N + TI - 1) / TI, ntj = (M + TJ - 1) / TJ;
+      for (int e = tid; e < nti * ntj; e += nthr) {
+        const int ti = e / ntj, tj = e - ti * ntj;
+        int io[TI], jo[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a) { const int i = ti * TI + a; io[a] = (i < N ? i : N - 1) * S; }
+#pragma unroll
+        for (int c = 0; c < TJ; ++c) { const int j = tj * TJ + c; jo[c] = (j < M ? j : M - 1) * S; }
+        real s[TI][TJ], qk[TI][TJ];
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int c = 0; c < TJ; ++c) { s[a][c] = 0; qk[a][c] = 0; }
+        for (int d = 0; d < hd; ++d) {
+          real qa[TI], q0a[TI], kb[TJ], k0b[TJ];
+#pragma unroll
+          for (int a = 0; a < TI; ++a) { qa[a] = qc[io[a] + d]; q0a[a] = q0[io[a] + d]; }
+#pragma unroll
+          for (int c = 0; c < TJ; ++c) { kb[c] = kc[jo[c] + d]; k0b[c] = k0[jo[c] + d]; }
+#pragma unroll
+          for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int c = 0; c < TJ; ++c) {
+              s[a][c] += qa[a] * k0b[c] + q0a[a] * kb[c];
+              qk[a][c] += qa[a] * kb[c];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TI; ++a)
+#pragma unroll
+          for (int c = 0; c < TJ; ++c) {
+            const int i = ti * TI + a, j = tj * TJ + c;
+            if (i < N && j < M) {
+              const int o = i * M + j;
+              if (!lap) { dS[o] = s[a][c] * sc; QK[o] += qk[a][c]; }
+              else dS[o] = (s[a][c] + 2 * QK[o]) * sc;             // L_S
+            }
+          }
       }
-      if (!lap) { dS[e] = s * sc; QK[e] += qk; }
-      else dS[e] = (s + 2 * QK[e]) * sc;             // L_S
     }
     __syncthreads();
     if (tid < N) {
@@ -132,16 +166,44 @@ __global__ void __launch_bounds__(256) k_attention(const real* __restrict__ q, c
         for (int j = 0; j < M; ++j) s2 += dP[tid * M + j] * dS[tid * M + j];
         A2[tid] += s2;
       }
-      for (int e = tid; e < N * hd; e += nthr) {
-        const int i = e / hd, d = e - i * hd;
-        real o = 0, ol = 0;
-        for (int j = 0; j < M; ++j) {
-          const real dp = dP[i * M + j];
-          o += dp * v0[j * S + d] + P[i * M + j] * vc[j * S + d];
-          ol += dp * vc[j * S + d];
+      {     // TI queries x TD features per thread
+        constexpr int TI = 2, TD = 4;
+        const int nti = (N + TI - 1) / TI, ntd = hd / TD;
+        for (int e = tid; e < nti * ntd; e += nthr) {
+          const int ti = e / ntd, d0 = (e - ti * ntd) * TD;
+          int io[TI];
+#pragma unroll
+          for (int a = 0; a < TI; ++a) { const int i = ti * TI + a; io[a] = (i < N ? i : N - 1) * M; }
+          real o[TI][TD], ol[TI][TD];
+#pragma unroll
+          for (int a = 0; a < TI; ++a)
+#pragma unroll
+            for (int c = 0; c < TD; ++c) { o[a][c] = 0; ol[a][c] = 0; }
+          for (int j = 0; j < M; ++j) {
+            real dp[TI], pp[TI], v0d[TD], vcd[TD];
+#pragma unroll
+            for (int a = 0; a < TI; ++a) { dp[a] = dP[io[a] + j]; pp[a] = P[io[a] + j]; }
+#pragma unroll
+            for (int c = 0; c < TD; ++c) { v0d[c] = v0[j * S + d0 + c]; vcd[c] = vc[j * S + d0 + c]; }
+#pragma unroll
+            for (int a = 0; a < TI; ++a)
+#pragma unroll
+              for (int c = 0; c < TD; ++c) {
+                o[a][c] += dp[a] * v0d[c] + pp[a] * vcd[c];
+                ol[a][c] += dp[a] * vcd[c];
+              }
+          }
+#pragma unroll
+          for (int a = 0; a < TI; ++a) {
+            const int i = ti * TI + a;
+            if (i >= N) continue;
+#pragma unroll
+            for (int c = 0; c < TD; ++c) {
+              OL[i * S + d0 + c] += 2 * ol[a][c];
+              out[(qrow0 + (long)i * TP + t) * width + col0 + d0 + c] = o[a][c];
+            }
+          }
         }
-        OL[i * S + d] += 2 * ol;
-        out[(qrow0 + (long)i * TP + t) * width + col0 + d] = o;
       }
     } else {
       // L_P = A1 + P*(L_S - rowsum(P*L_S) - A2);  out_L = L_P v0 + P v_L + 2 sum_c dP_c v_c
