@@ -181,6 +181,14 @@ struct Engine : dqmc_ctx {
   // MFMA bound, so they run on a companion stream and the node stream waits (event) only where a convolution or an
   // edge sum consumes an edge buffer.  Option "dual_stream" (1).
   int dual_stream = 1;
+  // Laplacian pass of the small systems: its ~40 kernels are latency bound one by one (2-3 TB/s, 40 % of the MFMA peak at
+  // best), and a layer's node-MLP + convolution of one edge type, that of the other, and the spin means + their product
+  // are three INDEPENDENT branches that meet in the g layer.  Option "multi_stream" (1): those branches run on up to two
+  // more HIP streams (op_sid, analyse_streams), ordered by events per produced buffer.
+  int multi_stream = 1;
+  std::vector<int> op_sid;             // stream slot per op: 0 main, 1 edge stream, 2 / 3 node branches
+  hipStream_t st_extra[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> ms_events;   // event pool of one pass
   hipStream_t st2 = nullptr;
   std::vector<hipEvent_t> buf_ev;      // per buffer: last write on the companion stream (nullptr: none pending)
   hipEvent_t ev_fork = nullptr;
@@ -258,6 +266,8 @@ struct Engine : dqmc_ctx {
   ~Engine() override {
     delete twin;
     if (st2) (void)hipStreamDestroy(st2);
+    for (auto x : st_extra) if (x) (void)hipStreamDestroy(x);
+    for (auto e : ms_events) if (e) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto e : buf_ev) if (e) (void)hipEventDestroy(e);
     if (d_molz) (void)hipFree(d_molz);
@@ -314,6 +324,7 @@ struct Engine : dqmc_ctx {
     if (rc) return rc;
     analyse_lanes();
     analyse_chains();
+    analyse_streams();
     rc = set_weights(w, nw);
     if (rc) return rc;
     return build_fused_plan();
@@ -425,6 +436,55 @@ struct Engine : dqmc_ctx {
       if (!ok) continue;
       mlp_child[p] = c;
       mlp_skip[c] = 1;
+    }
+  }
+
+  // Stream slots of the Laplacian pass.  Edge-stream ops (pair-compact destination) keep slot 1.  Every other op goes, in
+  // program order, to a slot whose last op it depends on anyway (directly or through other ops) -- placing it there costs
+  // no concurrency -- preferring the main slot, then the slot of its most recent producer, then a free one; only if
+  // there is none does it queue behind unrelated work on the main slot.  A chained MLP pair counts as one op.
+  void analyse_streams() {
+    const int no = (int)ops.size(), nb = (int)bufs.size();
+    op_sid.assign(no, 0);
+    std::vector<int> rd, wr, rd2, wr2;
+    std::vector<std::vector<int>> writers(nb);
+    std::vector<std::vector<char>> dep(no, std::vector<char>(no, 0));
+    auto io = [&](int k) {
+      op_io(ops[k], rd, wr);
+      if (mlp_child.size() == (size_t)no && mlp_child[k] >= 0) {
+        op_io(ops[mlp_child[k]], rd2, wr2);
+        for (int b : rd2) if (b != ops[k].i[17]) rd.push_back(b);
+        for (int b : wr2) wr.push_back(b);
+      }
+    };
+    int last[4] = {-1, -1, -1, -1};
+    for (int k = 0; k < no; ++k) {
+      if (mlp_skip.size() == (size_t)no && mlp_skip[k]) { op_sid[k] = -1; continue; }
+      io(k);
+      int producer = -1;
+      for (int b : rd)
+        for (int w : writers[b]) {
+          if (w >= k) continue;
+          dep[k][w] = 1;
+          for (int x = 0; x < w; ++x) if (dep[w][x]) dep[k][x] = 1;
+          if (w > producer) producer = w;
+        }
+      const dqmc_op& o = ops[k];
+      const bool edge = (o.kind == DQMC_OP_FEAT_EE && compact[o.i[0]]) || (o.kind == DQMC_OP_LINEAR && compact[o.i[17]]);
+      int sid = 0;
+      if (edge) sid = 1;
+      else if (o.kind == DQMC_OP_SLOGDET || o.kind == DQMC_OP_FINAL || o.kind == DQMC_OP_ATTENTION) sid = 0;
+      else {
+        auto eligible = [&](int s_) { return last[s_] < 0 || dep[k][last[s_]]; };
+        if (eligible(0)) sid = 0;
+        else if (producer >= 0 && op_sid[producer] >= 2 && eligible(op_sid[producer])) sid = op_sid[producer];
+        else if (eligible(2)) sid = 2;
+        else if (eligible(3)) sid = 3;
+        else sid = 0;
+      }
+      op_sid[k] = sid;
+      last[sid] = k;
+      for (int b : wr) writers[b].push_back(k);
     }
   }
 
@@ -554,6 +614,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
+    if (s == "multi_stream") { multi_stream = value; return DQMC_OK; }
     if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
     if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
     if (s == "fused_prio") { fused_prio = value; return DQMC_OK; }
@@ -1214,36 +1275,60 @@ struct Engine : dqmc_ctx {
       dqmc::launch_ph_coeffs<real>(st, r, R, d_ph_nuc, ph_n, d_ph_loc, d_ph_l2, ph_grid, ph_rmax, B, N, q);
       phq = q;
     }
-    // edge-stream ops (destination carries pair-compact lanes) go to the companion stream in Laplacian mode
+    // edge-stream ops (destination carries pair-compact lanes) go to the companion stream in Laplacian mode, independent
+    // node branches to two more (analyse_streams); every op records an event, readers on other streams wait for the
+    // events of the buffers they read
     const bool dual = laplacian && dual_stream && !timing_serial() && std::any_of(compact.begin(), compact.end(), [](char c) { return c != 0; });
-    std::vector<char> pending_ev(bufs.size(), 0);
+    const bool multi = dual && multi_stream && (long)B * N * li.TP <= (1L << 20);      // (large batches fill the GPU kernel by kernel)
+    struct BufEv { hipEvent_t ev; int sid; };
+    std::vector<std::vector<BufEv>> buf_w(dual ? bufs.size() : 0);
+    size_t ev_next = 0;
+    hipStream_t sl[4] = {st, st, st, st};
+    hipEvent_t last_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t zb_reader = nullptr;                    // last reader of the per-walker pre-activation scratch
+    auto new_event = [&](hipEvent_t* out) -> int {
+      if (ev_next == ms_events.size()) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ms_events.push_back(e); }
+      *out = ms_events[ev_next++];
+      return DQMC_OK;
+    };
     if (dual) {
       if (!st2) HIP_TRY(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
       if (!ev_fork) HIP_TRY(hipEventCreate(&ev_fork));
-      if (buf_ev.size() != bufs.size()) buf_ev.assign(bufs.size(), nullptr);
+      sl[1] = st2;
       HIP_TRY(hipEventRecord(ev_fork, st));            // inputs ready, the previous evaluation's readers done
       HIP_TRY(hipStreamWaitEvent(st2, ev_fork, 0));
+      if (multi)
+        for (int x = 0; x < 2; ++x) {
+          if (!st_extra[x]) HIP_TRY(hipStreamCreateWithFlags(&st_extra[x], hipStreamNonBlocking));
+          sl[2 + x] = st_extra[x];
+          HIP_TRY(hipStreamWaitEvent(st_extra[x], ev_fork, 0));
+        }
     }
-    auto stream_of = [&](const dqmc_op& o) -> hipStream_t {
-      if (!dual) return st;
-      const bool edge = (o.kind == DQMC_OP_FEAT_EE && compact[o.i[0]]) || (o.kind == DQMC_OP_LINEAR && compact[o.i[17]]);
-      return edge ? st2 : st;
+    auto sid_of = [&](size_t opi) -> int {
+      if (!dual) return 0;
+      const int sid = op_sid[opi];
+      if (sid < 0) return 0;
+      return (sid >= 2 && !multi) ? 0 : sid;
     };
     std::vector<int> rd_b, wr_b;
-    auto before = [&](const dqmc_op& o, hipStream_t s) -> int {     // the main stream waits for edge buffers it is about to read
-      if (!dual || s != st) return DQMC_OK;
-      op_io(o, rd_b, wr_b);
-      for (int b : rd_b) if (pending_ev[b]) { HIP_TRY(hipStreamWaitEvent(st, buf_ev[b], 0)); pending_ev[b] = 0; }
+    auto wait_buf = [&](int b, int sid) -> int {        // stream slot `sid` is about to read buffer b
+      for (const BufEv& w : buf_w[b]) if (w.sid != sid) HIP_TRY(hipStreamWaitEvent(sl[sid], w.ev, 0));
       return DQMC_OK;
     };
-    auto after = [&](const dqmc_op& o, hipStream_t s) -> int {
-      if (!dual || s != st2) return DQMC_OK;
+    auto before = [&](const dqmc_op& o, int sid) -> int {
+      if (!dual) return DQMC_OK;
       op_io(o, rd_b, wr_b);
-      for (int b : wr_b) {
-        if (!buf_ev[b]) HIP_TRY(hipEventCreate(&buf_ev[b]));
-        HIP_TRY(hipEventRecord(buf_ev[b], st2));
-        pending_ev[b] = 1;
-      }
+      for (int b : rd_b) { const int rcw = wait_buf(b, sid); if (rcw) return rcw; }
+      return DQMC_OK;
+    };
+    auto after = [&](const dqmc_op& o, int sid) -> int {
+      if (!dual) return DQMC_OK;
+      op_io(o, rd_b, wr_b);
+      hipEvent_t e;
+      { const int rce = new_event(&e); if (rce) return rce; }
+      HIP_TRY(hipEventRecord(e, sl[sid]));
+      last_ev[sid] = e;
+      for (int b : wr_b) buf_w[b].push_back(BufEv{e, sid});
       return DQMC_OK;
     };
     size_t first_op = 0;
@@ -1256,12 +1341,13 @@ struct Engine : dqmc_ctx {
       const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
       if (mlp_skip[opi]) continue;                      // second layer of a chained MLP: ran with its parent
-      const hipStream_t so = stream_of(op);
-      { const int rcb = before(op, so); if (rcb) return rcb; }
+      const int sid = sid_of(opi);
+      const hipStream_t so = sl[sid];
+      { const int rcb = before(op, sid); if (rcb) return rcb; }
       switch (op.kind) {
         case DQMC_OP_FEAT_EN:
-          t_begin("feat", 0);
-          dqmc::launch_feat_en<real>(st, r, R, bptr(i[0]), B, sys.n_nuc, sys.n_up, bufs[i[0]].width, li, sys.norm_eps, i[1], i[2], phq);
+          t_begin("feat", 0, so);
+          dqmc::launch_feat_en<real>(so, r, R, bptr(i[0]), B, sys.n_nuc, sys.n_up, bufs[i[0]].width, li, sys.norm_eps, i[1], i[2], phq);
           t_end();
           break;
         case DQMC_OP_FEAT_EE:
@@ -1302,7 +1388,7 @@ struct Engine : dqmc_ctx {
             // hidden layer + output layer of a row-wise MLP in one launch (the hidden activations stay in LDS)
             const dqmc_op& ch = ops[mlp_child[opi]];
             const int32_t* c = ch.i;
-            { const int rcb = before(ch, so); if (rcb) return rcb; }
+            { const int rcb = before(ch, sid); if (rcb) return rcb; }
             a.W2 = d_w + c[22]; a.ldw2 = pad4(c[21]); a.bias2 = c[23] >= 0 ? d_w + c[23] : nullptr; a.act2 = c[24];
             a.dst = bptr(c[17]);
             a.ld_dst = bufs[c[17]].width; a.rpw_dst = bufs[c[17]].rows; a.r0_dst = c[18]; a.col0_dst = c[19];
@@ -1312,8 +1398,8 @@ struct Engine : dqmc_ctx {
             t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
             dqmc::launch_linear_chain<real>(so, a);
             t_end();
-            { const int rca = after(op, so); if (rca) return rca; }
-            { const int rca = after(ch, so); if (rca) return rca; }
+            { const int rca = after(op, sid); if (rca) return rca; }
+            { const int rca = after(ch, sid); if (rca) return rca; }
             continue;
           }
           if (split_bcast && n_bc > 0 && n_bc < i[0] && i[20] > 1 && !(li.TP > 1 && compact[i[17]])) {
@@ -1332,12 +1418,34 @@ struct Engine : dqmc_ctx {
             z.bias = nullptr; z.act = 0; z.res = nullptr; z.pre = nullptr;
             z.dst = zb; z.ld_dst = a.ldw; z.rpw_dst = 1; z.r0_dst = 0; z.col0_dst = 0; z.nrows = 1;
             m.pre = zb; m.ld_pre = a.ldw;
-            t_begin("linear", 0, so);
-            dqmc::launch_linear<real>(so, z);
+            // the per-walker product runs where its inputs (the spin means) were produced, i.e. beside whatever the main
+            // stream is still doing for this layer; the scratch row buffer is shared by all layers: its previous reader
+            // (the last g layer) must be done before it is overwritten
+            int zsid = sid;
+            if (dual) {
+              for (int p = 0; p < i[0]; ++p)
+                if (i[4 + 4 * p] && !buf_w[i[1 + 4 * p]].empty()) zsid = buf_w[i[1 + 4 * p]].back().sid;
+              for (int p = 0; p < i[0]; ++p)
+                if (i[4 + 4 * p]) { const int rcw = wait_buf(i[1 + 4 * p], zsid); if (rcw) return rcw; }
+              if (zb_reader && zsid != sid) HIP_TRY(hipStreamWaitEvent(sl[zsid], zb_reader, 0));
+            }
+            t_begin("linear", 0, sl[zsid]);
+            dqmc::launch_linear<real>(sl[zsid], z);
             t_end();
+            if (dual && zsid != sid) {
+              hipEvent_t ez;
+              { const int rce = new_event(&ez); if (rce) return rce; }
+              HIP_TRY(hipEventRecord(ez, sl[zsid]));
+              last_ev[zsid] = ez;
+              HIP_TRY(hipStreamWaitEvent(so, ez, 0));
+            }
             t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
             dqmc::launch_linear<real>(so, m);
             t_end();
+            if (dual) {
+              { const int rce = new_event(&zb_reader); if (rce) return rce; }
+              HIP_TRY(hipEventRecord(zb_reader, so));
+            }
             break;
           }
           t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
@@ -1346,19 +1454,19 @@ struct Engine : dqmc_ctx {
           break;
         }
         case DQMC_OP_SPIN_MEAN:
-          t_begin("graph", 0);
-          dqmc::launch_spin_mean<real>(st, bptr(i[0]), bptr(i[1]), B, i[2], bufs[i[0]].width, li);
+          t_begin("graph", 0, so);
+          dqmc::launch_spin_mean<real>(so, bptr(i[0]), bptr(i[1]), B, i[2], bufs[i[0]].width, li);
           t_end();
           break;
         case DQMC_OP_CONV:
-          t_begin("graph", 0);
-          dqmc::launch_conv<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].rows, bufs[i[1]].width, bptr(i[2]),
+          t_begin("graph", 0, so);
+          dqmc::launch_conv<real>(so, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[1]), bufs[i[1]].rows, bufs[i[1]].width, bptr(i[2]),
                                   bufs[i[2]].width, i[3], d_it + i[4], i[5], i[6], B, li, li.TP > 1 && compact[i[0]]);
           t_end();
           break;
         case DQMC_OP_EDGE_SUM:
-          t_begin("graph", 0);
-          dqmc::launch_edge_sum<real>(st, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[2]), bufs[i[2]].width, i[3],
+          t_begin("graph", 0, so);
+          dqmc::launch_edge_sum<real>(so, bptr(i[0]), bufs[i[0]].rows, bufs[i[0]].width, bptr(i[2]), bufs[i[2]].width, i[3],
                                       d_it + i[4], i[5], i[6], 1.0 / (double)(i[1] > 0 ? i[1] : 1), B, li,
                                       li.TP > 1 && compact[i[0]]);
           t_end();
@@ -1380,18 +1488,18 @@ struct Engine : dqmc_ctx {
           break;
         }
         case DQMC_OP_CONST:
-          t_begin("feat", 0);
-          dqmc::launch_const_rows<real>(st, d_w + i[1], bptr(i[0]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
+          t_begin("feat", 0, so);
+          dqmc::launch_const_rows<real>(so, d_w + i[1], bptr(i[0]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
           t_end();
           break;
         case DQMC_OP_ROW_SUM:
-          t_begin("graph", 0);
-          dqmc::launch_row_sum<real>(st, bptr(i[0]), bptr(i[1]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
+          t_begin("graph", 0, so);
+          dqmc::launch_row_sum<real>(so, bptr(i[0]), bptr(i[1]), B, bufs[i[0]].rows, bufs[i[0]].width, li);
           t_end();
           break;
         case DQMC_OP_ORBITALS:
-          t_begin("orbitals", 0);
-          dqmc::launch_orbitals<real>(st, r, R, bptr(i[0]), bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, d_w + i[2], d_w + i[3],
+          t_begin("orbitals", 0, so);
+          dqmc::launch_orbitals<real>(so, r, R, bptr(i[0]), bufs[i[0]].width, bptr(i[1]), bufs[i[1]].width, d_w + i[2], d_w + i[3],
                                       d_w + i[4], d_w + i[5], B, sys.n_up, sys.n_nuc, i[6] > 0 ? i[6] : 1, sys.n_det, li,
                                       sys.norm_eps, phq);
           t_end();
@@ -1432,10 +1540,10 @@ struct Engine : dqmc_ctx {
         default:
           return fail(DQMC_E_UNSUPPORTED, "op kind " + std::to_string(op.kind));
       }
-      { const int rca = after(op, so); if (rca) return rca; }
+      { const int rca = after(op, sid); if (rca) return rca; }
     }
-    if (dual)        // join: nothing of this evaluation may still run on the companion stream when the caller goes on
-      for (size_t b = 0; b < bufs.size(); ++b) if (pending_ev[b]) { HIP_TRY(hipStreamWaitEvent(st, buf_ev[b], 0)); pending_ev[b] = 0; }
+    if (dual)        // join: nothing of this evaluation may still run on another stream when the caller goes on
+      for (int x = 1; x < 4; ++x) if (last_ev[x]) HIP_TRY(hipStreamWaitEvent(st, last_ev[x], 0));
     HIP_TRY(hipGetLastError());
     return DQMC_OK;
   }

@@ -51,6 +51,8 @@ inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 #define hipStreamNonBlocking 1u
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new simt_event{0}; return hipSuccess; }
+#define hipEventDisableTiming 2u
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new simt_event{0}; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
   e->t = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();

@@ -9,6 +9,8 @@ h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
 wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cuda:0')
 params = wf.init(0, perturb_envelopes=0.05)
 eng = wf.engine(params); eng.set_option('refine', refine)
+if os.environ.get('DQMC_SERIAL'):      # one stream: clean per-kernel counters
+    eng.set_option('dual_stream', 0)
 smp = DecorrSampler(h, wf, length=30); st = smp.init(1, params, 4096)
 for k in range(5): st, pc, stats = smp.sample(k, st, params)
 r = st['r']

@@ -1,5 +1,5 @@
 """Per-kernel-family averages of the SQ counters collected by run_pmc.sh (rocprofv3 --pmc, csv)."""
-import csv, glob, json, re, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for d in sys.argv[1:]:
@@ -7,6 +7,9 @@ for d in sys.argv[1:]:
         for row in csv.DictReader(open(path)):
             m = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+)', row['Kernel_Name'])
             fam = m.group(1) if m else row['Kernel_Name'][:40]
+            if os.environ.get('PMC_FULLNAME'):          # keep the template arguments (one entry per instantiation)
+                m2 = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+(?:<[^>]*>)?)', row['Kernel_Name'])
+                fam = m2.group(1) if m2 else fam
             a = acc[fam][row['Counter_Name']]
             a[0] += 1; a[1] += float(row['Counter_Value'])
 out = {}
