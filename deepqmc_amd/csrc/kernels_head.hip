@@ -248,6 +248,140 @@ __global__ void __launch_bounds__(64) k_slogdet(const real* __restrict__ orb, in
   for (int t = li.T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
 }
 
+// Laplacian-mode variant for 5..16 electrons: ONE wave per matrix like k_slogdet, but the per-lane products
+// M_c = A^-1 dA_c (3N + 1 of them per matrix: what the kernel spends its time on) are single 16 x 16 x 16 tiles on the
+// float64 matrix cores: A^-1 (zero padded) sits in registers as the A operand for the whole lane loop, dA_c is read
+// straight from HBM in B-operand order (row j of dA_c = 16 consecutive columns per quarter wave: coalesced), and
+// four v_mfma_f64_16x16x4_f64 replace ~N^3 scalar multiply-adds fed from LDS.  tr(M_c) is one wave reduction per lane;
+// sum_c tr(M_c^2) -- M_c transposed through a 16 x 17 LDS tile -- is accumulated per thread and reduced once at the end.
+// N2 / FermiNet (14 electrons, 16 determinants, 4096 walkers): 3.2 ms -> see DESIGN.md section 4.
+template <typename real>
+__global__ void __launch_bounds__(64) k_slogdet_w16(const real* __restrict__ orb, int orb_width, double* __restrict__ logdet,
+                                                    int32_t* __restrict__ sign_k, LaneInfo li, double* __restrict__ cond) {
+  constexpr int NS = 17;
+  __shared__ double A[16 * NS];
+  __shared__ double Inv[16 * NS];
+  __shared__ double colp[16];
+  __shared__ int piv_s;
+  const int N = li.N, NN = N * N, T = li.T;
+  const int lane = threadIdx.x, l15 = lane & 15, l4 = lane >> 4;
+  const long bk = blockIdx.x;  // b*K + k
+  const real* base = orb + bk * li.TP * orb_width;
+  for (int e = lane; e < 16 * 16; e += 64) {
+    const int i = e >> 4, j = e & 15;
+    const bool in = i < N && j < N;
+    A[i * NS + j] = in ? (double)base[i * N + j] : 0.0;
+    Inv[i * NS + j] = (in && i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  double logabs = 0.0;
+  int sgn = 1;
+  for (int p = 0; p < N; ++p) {
+    if (lane == 0) {
+      int best = p;
+      double bv = fabs(A[p * NS + p]);
+      for (int i = p + 1; i < N; ++i) {
+        const double v = fabs(A[i * NS + p]);
+        if (v > bv) { bv = v; best = i; }   // first maximum, as LAPACK idamax
+      }
+      piv_s = best;
+    }
+    __syncthreads();
+    const int q = piv_s;
+    if (q != p) {
+      for (int j = lane; j < N; j += 64) {
+        double t0 = A[p * NS + j]; A[p * NS + j] = A[q * NS + j]; A[q * NS + j] = t0;
+        t0 = Inv[p * NS + j]; Inv[p * NS + j] = Inv[q * NS + j]; Inv[q * NS + j] = t0;
+      }
+      sgn = -sgn;
+    }
+    __syncthreads();
+    const double piv = A[p * NS + p];
+    logabs += log(fabs(piv));
+    if (piv < 0) sgn = -sgn;
+    if (piv == 0) sgn = 0;
+    __syncthreads();
+    const double ip = 1.0 / piv;
+    for (int j = lane; j < N; j += 64) { A[p * NS + j] *= ip; Inv[p * NS + j] *= ip; }
+    for (int i = lane; i < N; i += 64) colp[i] = A[i * NS + p];
+    __syncthreads();
+    for (int e = lane; e < NN; e += 64) {
+      const int i = e / N, j = e - i * N;
+      if (i != p) {
+        const double f = colp[i];
+        A[i * NS + j] -= f * A[p * NS + j];
+        Inv[i * NS + j] -= f * Inv[p * NS + j];
+      }
+    }
+    __syncthreads();
+  }
+  if (lane == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
+  if (T == 1) return;
+  if (cond) {      // kappa = sum |A_ij| |(A^-1)_ji| / N (comment above k_slogdet)
+    double c = 0.0;
+    for (int e = lane; e < NN; e += 64) {
+      const int i = e / N, j = e - i * N;
+      c += fabs((double)base[e]) * fabs(Inv[j * NS + i]);
+    }
+    c = wave_sum<double>(c);
+    if (lane == 0) cond[bk] = c / N;
+  }
+  typedef Mfma<double>::acc_t acc_t;
+  double fa[4];                                            // A^-1 as MFMA A fragments: row l15, k = kk*4 + l4
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) fa[kk] = Inv[l15 * NS + kk * 4 + l4];
+  double* Ms = A;                                          // the elimination is over: A's tile holds M_c (transposition)
+  // B fragments of dA_c: element (k = kk*4 + l4, n = l15) = dA_c[j = k][l = n]
+  int boff[4];
+  bool bok[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int j = kk * 4 + l4;
+    bok[kk] = j < N && l15 < N;
+    boff[kk] = bok[kk] ? j * N + l15 : 0;
+  }
+  real fbn[4];
+  auto issue = [&](int t) {
+    const real* At = base + (long)t * orb_width;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fbn[kk] = At[boff[kk]];
+  };
+  issue(1);
+  double t2_acc = 0.0;
+  for (int t = 1; t < T; ++t) {
+    double fb[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fb[kk] = bok[kk] ? (double)fbn[kk] : 0.0;
+    if (t + 1 < T) issue(t + 1);                           // next lane in flight during the products and reductions
+    acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = Mfma<double>::run(fa[kk], fb[kk], acc);
+    double tr = 0.0;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) if (Mfma<double>::row_of(lane, rg) == l15) tr += acc[rg];
+    const bool need2 = t < T - 1;
+    if (need2) {
+      wave_lds_fence();                                    // previous lane's reads of Ms are done
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) Ms[Mfma<double>::row_of(lane, rg) * NS + l15] = acc[rg];
+      wave_lds_fence();
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) t2_acc += acc[rg] * Ms[l15 * NS + Mfma<double>::row_of(lane, rg)];
+    }
+    tr = wave_sum<double>(tr);
+    if (need2) {
+      if (lane == 0) logdet[bk * li.TP + t] = tr;
+    } else {
+      const double tr2_sum = wave_sum<double>(t2_acc);
+      if (lane == 0) logdet[bk * li.TP + t] = tr - tr2_sum;
+    }
+  }
+  for (int t = T + lane; t < li.TP; t += 64) logdet[bk * li.TP + t] = 0.0;
+}
+
 // One 16 x 16 tile of A^-1 dA_c: the A fragments (a row block of A^-1, the same for every lane) live in
 // registers, the NK B fragments are requested from LDS before the first MFMA, so the chain of dependent
 // v_mfma_f64_16x16x4_f64 is not interleaved with LDS round trips.
@@ -470,6 +604,64 @@ __global__ void __launch_bounds__(64) k_slogdet_lu(const real* __restrict__ orb,
     __syncthreads();
   }
   if (lane == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
+}
+
+// Value-only variant for 5..16 electrons: SIXTEEN lanes per matrix (four matrices per wave), lane i keeps row i in
+// registers; no LDS, no barriers.  Per pivot: arg-max of |A[.][p]| over the unused rows by four xor-shuffles inside the
+// 16-lane group (larger value wins, ties go to the row that LAPACK's physically swapped order would meet first: the
+// smaller current POSITION, tracked per lane), the pivot row is broadcast column by column, every other unused row
+// eliminates in its own registers.  Rows are never moved: the position bookkeeping reproduces getrf's swap count, so
+// sign = (-1)^swaps * prod sign(pivot) is the same integer as from k_slogdet_lu (whose 64-lane, LDS-resident version
+// spent ~7 k cycles per pivot on barriers and a 64-wide reduction for a 14-row column).
+template <typename real>
+__global__ void __launch_bounds__(256) k_slogdet_lu16(const real* __restrict__ orb, int orb_width, double* __restrict__ logdet,
+                                                      int32_t* __restrict__ sign_k, long n_mat, LaneInfo li) {
+  const int N = li.N;
+  const int lane = threadIdx.x & 63, row = lane & 15, g0 = lane & 48;      // g0: first lane of this matrix's group
+  const long bk_raw = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const bool live = bk_raw < n_mat;
+  const long bk = live ? bk_raw : n_mat - 1;               // idle groups shadow the last matrix (all lanes stay in the shuffles)
+  const real* base = orb + bk * li.TP * orb_width;
+  double a[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) a[j] = (row < N && j < N) ? (double)base[row * N + j] : 0.0;
+  int pos = row;                                           // current position of this row in getrf's swapped order
+  bool used = row >= N;
+  double logabs = 0.0;
+  int sgn = 1;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    if (p < N) {                                           // (uniform over the launch)
+      double bv = used ? -1.0 : fabs(a[p]);
+      int bpos = used ? 1 << 20 : pos, bl = row;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const double ov = __shfl_xor(bv, m, 64);
+        const int op = __shfl_xor(bpos, m, 64), ol = __shfl_xor(bl, m, 64);
+        if (ov > bv || (ov == bv && op < bpos)) { bv = ov; bpos = op; bl = ol; }
+      }
+      const int ql = g0 + bl;                              // lane holding the pivot row
+      const double piv = __shfl(a[p], ql, 64);
+      if (bpos != p) sgn = -sgn;                           // getrf swaps rows p and bpos
+      if (pos == p && row != bl) pos = bpos;               // the row that sat at position p moves to where the pivot row was
+      if (row == bl) { pos = p; used = true; }
+      logabs += log(fabs(piv));
+      if (piv < 0) sgn = -sgn;
+      if (piv == 0) sgn = 0;
+      const double f = (used || piv == 0) ? 0.0 : a[p] / piv;
+#pragma unroll
+      for (int j = p + 1; j < 16; ++j) {
+        if (j < N) {
+          const double pj = __shfl(a[j], ql, 64);
+          a[j] -= f * pj;
+        }
+      }
+    }
+  }
+  if (live && row == 0) {
     logdet[bk * li.TP] = logabs;
     sign_k[bk] = sgn;
   }
@@ -783,8 +975,8 @@ void launch_orbitals(hipStream_t st, const real* r, const real* R, const real* b
                      bf, bf_width, orb, orb_width, pi_up, pi_dn, ze_up, ze_dn, B, n_up, n_nuc, n_env, K, li, eps, phq);
 }
 
-// use_mfma (engine option "slogdet_mfma"): 1 = f64-MFMA derivative traces where profitable (N > 16), 2 = from
-// N > 8 on, 0 = never
+// use_mfma (engine option "slogdet_mfma"): 1 = f64-MFMA derivative traces (N > 16: k_slogdet_mfma, 4 waves per matrix;
+// 5 <= N <= 16: k_slogdet_w16, one wave per matrix), 2 = k_slogdet_mfma from N > 8 on, 3 = as 1 without k_slogdet_w16, 0 = never
 template <typename real>
 void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logdet, int32_t* sign_k, int B, int K,
                     LaneInfo li, int use_mfma, double* cond) {
@@ -801,13 +993,18 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
   else if (li.N == 4)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_small<real, 4>), dim3(gsm), dim3(256), 0, st, orb, orb_width, logdet,
                        sign_k, n_mat, li, cond);
+  else if (li.T == 1 && li.N <= 16 && slogdet_use_mfma != 3)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu16<real>), dim3((unsigned)((n_mat * 16 + 255) / 256)), dim3(256), 0, st, orb, orb_width,
+                       logdet, sign_k, n_mat, li);
   else if (li.T == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu<real>), dim3(grid), dim3(64), sizeof(double) * li.N * (li.N | 1), st,
                        orb, orb_width, logdet, sign_k, li);
-  else if (li.N <= 48 && ((slogdet_use_mfma == 1 && li.N > 16) || (slogdet_use_mfma >= 2 && li.N > 8)))     // >= 2 x 2 tiles (14 x 14: the wave-per-matrix kernel is faster); N16 <= 48: 57 KB of LDS
+  else if (li.N <= 48 && ((slogdet_use_mfma == 1 && li.N > 16) || (slogdet_use_mfma == 2 && li.N > 8) || (slogdet_use_mfma == 3 && li.N > 16)))     // >= 2 x 2 tiles (14 x 14: the wave-per-matrix kernel is faster); N16 <= 48: 57 KB of LDS
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_mfma<real>), dim3(grid), dim3(256),
                        sizeof(double) * ((size_t)3 * (((li.N + 15) / 16) * 16) * ((((li.N + 15) / 16) * 16) + 1) + (((li.N + 15) / 16) * 16) + 16),
                        st, orb, orb_width, logdet, sign_k, li, cond);
+  else if (li.N <= 16 && slogdet_use_mfma >= 1 && slogdet_use_mfma != 3)     // one wave per matrix, derivative traces on the f64 matrix cores
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_w16<real>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet, sign_k, li, cond);
   else if (li.N <= 8)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet<real, 8>), dim3(grid), dim3(64), 0, st, orb, orb_width, logdet,
                        sign_k, K, li, cond);
