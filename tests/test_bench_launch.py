@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def run_bench(*extra, env=None):
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--emulated', '--walkers', '4', '--steps', '1', '--warmup', '0',
-           '--n-sub', '1', '--repeats', '1', '--no-cpu-baseline', *extra]
+           '--n-sub', '1', '--repeats', '1', '--no-cpu-baseline', '--equilibrate', '0', *extra]
     return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
 
 

@@ -192,11 +192,11 @@ def test_initial_walkers_follow_each_geometry_and_counters_are_functional():
     shift = np.array([[40.0, 0, 0], [40.0, 0, 0]])
     Rs = torch.as_tensor(np.stack([h.mol.coords, h.mol.coords + shift]))
     ms = MultiNuclearGeometrySampler(DecorrSampler(h, wf, length=1, tau=0.2), IdleNucleiSampler(), update_nuc_period=3)
-    state = ms.init(0, params, 64, Rs)
+    state = ms.init(0, params, 16, Rs)
     for m in range(2):
         centre = state['elec'][m]['r'].numpy().mean(axis=(0, 1))
-        np.testing.assert_allclose(centre, Rs[m].numpy().mean(0) * 0 + synthetic_walkers(h, 64, seed=0 * 2 + m, R=Rs[m]).mean(axis=(0, 1)), atol=1e-12)
-        assert abs(centre[0] - float(Rs[m][:, 0].mean())) < 2.0            # 40 bohr apart: each ensemble sits on its own molecule
+        np.testing.assert_allclose(centre, synthetic_walkers(h, 16, seed=0 * 2 + m, R=Rs[m]).mean(axis=(0, 1)), atol=1e-12)
+        assert abs(centre[0] - float(Rs[m][:, 0].mean())) < 3.0            # 40 bohr apart: each ensemble sits on its own molecule
         assert np.isfinite(state['elec'][m]['psi'].log.numpy()).all()
     counter0 = state['update_nuc_counter'].copy()
     new_state, _, _ = ms.sample(1, state, params, [0, 1])
