@@ -46,6 +46,24 @@ template <typename real> struct Vec2;   // 2 consecutive reals, naturally aligne
 template <> struct __attribute__((aligned(8))) Vec2<float> { float v[2]; };
 template <> struct __attribute__((aligned(16))) Vec2<double> { double v[2]; };
 
+// VW consecutive reals as a value (VW = 1 or 4): element-parallel kernels are written once for both widths
+template <typename real, int VW> struct VecN {
+  real v[VW];
+  static __device__ __forceinline__ VecN zero() { VecN r; for (int j = 0; j < VW; ++j) r.v[j] = 0; return r; }
+  static __device__ __forceinline__ VecN load(const real* p) {
+    VecN r;
+    if (VW == 4) { const Vec4<real> t = *reinterpret_cast<const Vec4<real>*>(p); for (int j = 0; j < VW; ++j) r.v[j] = t.v[j]; }
+    else for (int j = 0; j < VW; ++j) r.v[j] = p[j];
+    return r;
+  }
+  __device__ __forceinline__ void store(real* p) const {
+    if (VW == 4) { Vec4<real> t; for (int j = 0; j < 4; ++j) t.v[j] = v[j < VW ? j : 0]; *reinterpret_cast<Vec4<real>*>(p) = t; }
+    else for (int j = 0; j < VW; ++j) p[j] = v[j];
+  }
+  __device__ __forceinline__ void fma(const VecN& a, const VecN& b) { for (int j = 0; j < VW; ++j) v[j] += a.v[j] * b.v[j]; }
+  __device__ __forceinline__ void axpy(real s, const VecN& a) { for (int j = 0; j < VW; ++j) v[j] += s * a.v[j]; }
+};
+
 template <typename real> __device__ __forceinline__ real r_tanh(real x);
 // f32 tanh in ~15 VALU instructions (libm tanhf is ~100 and dominated the small layers of the
 // fused kernel): odd polynomial for |x| < 0.25 (truncation < 3e-9), (1 - e)/(1 + e) with

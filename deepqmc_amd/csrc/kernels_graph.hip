@@ -117,50 +117,91 @@ __global__ void __launch_bounds__(256) k_row_sum(const real* __restrict__ x, rea
 
 // Convolution feature, reference gnn/graph.py:226-335: out[i] = sum_s we[row(i,s)] * hx[send(i,s)]
 // with the product rule across lanes (value, d/dr_c, Laplacian).  tab: int [N][S][2].
-template <typename real>
+template <typename real, int VW>
 __global__ void __launch_bounds__(256) k_conv(const real* __restrict__ we, int we_rows, int we_width,
                                               const real* __restrict__ hx, int hx_rows, int hx_width, real* __restrict__ out,
                                               int out_width, int col0, const int32_t* __restrict__ tab, int S, int W,
                                               int B, LaneInfo li, int compact) {
   // `compact`: the edge operand carries the 8 pair lanes of common.h; lane t of edge (i, snd) is then lane
   // pair_lane(t) of its row, or zero.
-  // One thread per (walker, receiver, column) walks the lanes once: out_t = sum_s (a_t h_0 + a_0 h_t), and the
-  // Laplacian lane adds 2 sum_s sum_c a_c h_c from a running dot product -- every input element is read once
-  // and no thread carries the whole Laplacian sum alone.
+  // One thread per (walker, receiver, VW consecutive columns) walks the lanes once: out_t = sum_s (a_t h_0 + a_0 h_t),
+  // and the Laplacian lane adds 2 sum_s sum_c a_c h_c from a running dot product -- every input element is read once
+  // and no thread carries the whole Laplacian sum alone.  VW = 4: 16-byte loads and stores (the 4-byte version issued
+  // four times the memory instructions for the same bytes and ran at 2 TB/s).
+  typedef VecN<real, VW> vec;
+  const int Wv = W / VW;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * li.N * W;
+  const long total = (long)B * li.N * Wv;
   if (idx >= total) return;
-  const int c = (int)(idx % W);
-  const long q = idx / W;
+  const int c = (int)(idx % Wv) * VW;
+  const long q = idx / Wv;
   const int i = (int)(q % li.N);
   const int b = (int)(q / li.N);
   const int T = li.T;
   const int TPe = (compact && T > 1) ? PAIR_LANES : li.TP;
   real* o = out + (((long)b * li.N + i) * li.TP) * out_width + col0 + c;
-  real acc0 = 0, dot = 0;
-  for (int s = 0; s < S; ++s) {
-    const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
-    if (row < 0) continue;
-    const int hrow = snd >= 0 ? snd : -1 - snd;          // a negative sender is nucleus -1 - snd (row of a nuclear node buffer)
-    acc0 += we[(((long)b * we_rows + row) * TPe) * we_width + c] * hx[(((long)b * hx_rows + hrow) * li.TP) * hx_width + c];
-  }
-  o[0] = acc0;
-  for (int t = 1; t < T; ++t) {
-    real acc = 0;
+  constexpr int SMAX = 4;       // up to SMAX senders: their rows and value lanes stay in registers (static indices only)
+  if (S <= SMAX) {
+    const real* ap[SMAX];
+    const real* hp[SMAX];
+    int sndv[SMAX];
+    bool ok[SMAX];
+    vec a0[SMAX], h0[SMAX];
+    vec acc0 = vec::zero(), dot = vec::zero();
+#pragma unroll
+    for (int u = 0; u < SMAX; ++u) {
+      const int row = u < S ? tab[2 * (i * S + u)] : -1, snd = u < S ? tab[2 * (i * S + u) + 1] : 0;
+      ok[u] = row >= 0;
+      sndv[u] = snd;
+      const int hrow = snd >= 0 ? snd : -1 - snd;        // a negative sender is nucleus -1 - snd (row of a nuclear node buffer)
+      ap[u] = we + (((long)b * we_rows + (ok[u] ? row : 0)) * TPe) * we_width + c;
+      hp[u] = hx + (((long)b * hx_rows + (ok[u] ? hrow : 0)) * li.TP) * hx_width + c;
+      a0[u] = ok[u] ? vec::load(ap[u]) : vec::zero();
+      h0[u] = ok[u] ? vec::load(hp[u]) : vec::zero();
+      acc0.fma(a0[u], h0[u]);
+    }
+    acc0.store(o);
+    for (int t = 1; t < T; ++t) {
+      vec acc = vec::zero();
+#pragma unroll
+      for (int u = 0; u < SMAX; ++u) {
+        if (!ok[u]) continue;
+        const int ta = (compact && T > 1) ? pair_lane(t, T, i, sndv[u]) : t;
+        const vec at = ta >= 0 ? vec::load(ap[u] + (long)ta * we_width) : vec::zero(), ht = vec::load(hp[u] + (long)t * hx_width);
+        acc.fma(at, h0[u]);
+        acc.fma(a0[u], ht);
+        if (t < T - 1) dot.fma(at, ht);
+      }
+      if (t == T - 1) acc.axpy((real)2, dot);
+      acc.store(o + (long)t * out_width);
+    }
+  } else {
+    vec acc0 = vec::zero(), dot = vec::zero();
     for (int s = 0; s < S; ++s) {
       const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
       if (row < 0) continue;
-      const real* a = we + (((long)b * we_rows + row) * TPe) * we_width + c;
-      const real* h = hx + (((long)b * hx_rows + (snd >= 0 ? snd : -1 - snd)) * li.TP) * hx_width + c;
-      const int ta = (compact && T > 1) ? pair_lane(t, T, i, snd) : t;
-      const real at = ta >= 0 ? a[(long)ta * we_width] : (real)0, ht = h[(long)t * hx_width];
-      acc += at * h[0] + a[0] * ht;
-      if (t < T - 1) dot += at * ht;
+      const int hrow = snd >= 0 ? snd : -1 - snd;
+      acc0.fma(vec::load(we + (((long)b * we_rows + row) * TPe) * we_width + c), vec::load(hx + (((long)b * hx_rows + hrow) * li.TP) * hx_width + c));
     }
-    if (t == T - 1) acc += 2 * dot;
-    o[(long)t * out_width] = acc;
+    acc0.store(o);
+    for (int t = 1; t < T; ++t) {
+      vec acc = vec::zero();
+      for (int s = 0; s < S; ++s) {
+        const int row = tab[2 * (i * S + s)], snd = tab[2 * (i * S + s) + 1];
+        if (row < 0) continue;
+        const real* a = we + (((long)b * we_rows + row) * TPe) * we_width + c;
+        const real* h = hx + (((long)b * hx_rows + (snd >= 0 ? snd : -1 - snd)) * li.TP) * hx_width + c;
+        const int ta = (compact && T > 1) ? pair_lane(t, T, i, snd) : t;
+        const vec at = ta >= 0 ? vec::load(a + (long)ta * we_width) : vec::zero(), ht = vec::load(h + (long)t * hx_width);
+        acc.fma(at, vec::load(h));
+        acc.fma(vec::load(a), ht);
+        if (t < T - 1) dot.fma(at, ht);
+      }
+      if (t == T - 1) acc.axpy((real)2, dot);
+      acc.store(o + (long)t * out_width);
+    }
   }
-  for (int t = T; t < li.TP; ++t) o[(long)t * out_width] = 0;
+  for (int t = T; t < li.TP; ++t) vec::zero().store(o + (long)t * out_width);
 }
 
 // Edge sum/mean feature, reference gnn/update_features.py:109-159 (linear in the lanes).
@@ -264,9 +305,15 @@ void launch_row_sum(hipStream_t st, const real* x, real* s, int B, int rows, int
 template <typename real>
 void launch_conv(hipStream_t st, const real* we, int we_rows, int we_width, const real* hx, int hx_rows, int hx_width, real* out,
                  int out_width, int col0, const int32_t* tab, int S, int W, int B, LaneInfo li, int compact) {
-  const long total = (long)B * li.N * W;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx, hx_rows,
-                     hx_width, out, out_width, col0, tab, S, W, B, li, compact);
+  if ((W & 3) == 0 && (col0 & 3) == 0 && (we_width & 3) == 0 && (hx_width & 3) == 0 && (out_width & 3) == 0) {
+    const long total = (long)B * li.N * (W / 4);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real, 4>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx, hx_rows,
+                       hx_width, out, out_width, col0, tab, S, W, B, li, compact);
+  } else {
+    const long total = (long)B * li.N * W;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_conv<real, 1>), dim3(nblk(total)), dim3(256), 0, st, we, we_rows, we_width, hx, hx_rows,
+                       hx_width, out, out_width, col0, tab, S, W, B, li, compact);
+  }
 }
 template <typename real>
 void launch_edge_sum(hipStream_t st, const real* e, int e_rows, int e_width, real* out, int out_width, int col0,

@@ -70,11 +70,11 @@ def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
     for m in range(M):
         sign = torch.empty(S, S, B, dtype=torch.float64, device=r.device)
         log = torch.empty(S, S, B, dtype=torch.float64, device=r.device)
-        for i in range(S):                       # wave function i ...
-            eng = ansatz.engine(params[i], Rs[m])
-            for j in range(S):                   # ... on the samples of state j
-                sg, lg = eng.wf_eval(r[m, j].contiguous(), Rs[m])
-                sign[i, j], log[i, j] = sg.double(), lg.double()
+        r_all = r[m].reshape(S * B, *r.shape[3:]).contiguous()      # the samples of ALL states as one batch
+        for i in range(S):                       # wave function i on the samples of every state j: ONE evaluation of
+            eng = ansatz.engine(params[i], Rs[m])                     # S * B walkers per parameter set instead of S
+            sg, lg = eng.wf_eval(r_all, Rs[m])                        # (the reference vmaps over both axes, overlap.py:40-49)
+            sign[i], log[i] = sg.double().reshape(S, B), lg.double().reshape(S, B)
         mean_log = log.mean(dim=(1, 2))                                   # overlap.py:92-94
         shifted = log - mean_log[:, None, None]
         diag = torch.diagonal(shifted, dim1=0, dim2=1).permute(1, 0)     # [S(j), B]
