@@ -38,6 +38,50 @@ template <> struct Mfma<double> {
   static __device__ __forceinline__ int row_of(int lane, int reg) { return (lane >> 4) + (reg << 2); }
 };
 
+// ---- float32 products on the bf16 matrix pipe ----
+// gfx950 has no fast f32 MFMA (v_mfma_f32_16x16x4_f32 runs at the VALU rate, 1/16 of the bf16 rate).  A float is
+// EXACTLY the sum of three bf16 numbers (8 + 8 + 8 significand bits, round-to-nearest residuals), so
+//   a b = sum_{i,j} a_i b_j,   a = a_0 + a_1 + a_2,  b = b_0 + b_1 + b_2,
+// and the six products with i + j <= 2 carry everything above 2^-24 |a b| (the dropped ones are <= 2^-24, 2^-24,
+// 2^-32 |a b| with random signs: the same order as the rounding of an f32 accumulation).  Six
+// v_mfma_f32_16x16x32_bf16 (K = 32 each, 16 cycles) replace eight v_mfma_f32_16x16x4_f32 (K = 4 each, 32 cycles):
+// 96 instead of 256 matrix-pipe cycles per 16 x 16 x 32 block, accumulated in f32 as before.
+// Operand layout of v_mfma_f32_16x16x32_bf16: lane l holds row (A) / column (B) l & 15 and the eight k values
+// 8 (l >> 4) .. 8 (l >> 4) + 7, two per register, even k in the low half; C/D as the 16x16x4 f32 form.
+struct BfFrag { uint32_t w[4]; };
+#if defined(__HIPCC__)
+typedef __bf16 dqmc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 dqmc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float dqmc_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf_pack2(float lo, float hi) {       // v_cvt_pk_bf16_f32 (round to nearest even)
+  const dqmc_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, dqmc_bf16x2));
+}
+__device__ __forceinline__ f32x4 mfma_bf16(const BfFrag& a, const BfFrag& b, f32x4 c) {
+  typedef float cvec __attribute__((ext_vector_type(4)));
+  const cvec r = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dqmc_bf16x8, a), __builtin_bit_cast(dqmc_bf16x8, b),
+                                                        __builtin_bit_cast(cvec, c), 0, 0, 0);
+  return __builtin_bit_cast(f32x4, r);
+}
+#else
+// (SIMT emulator build: bf_pack2 and the MFMA come from tests/simt/hip/hip_runtime.h)
+inline f32x4 mfma_bf16(const BfFrag& a, const BfFrag& b, f32x4 c) { return simt_mfma_f32_16x16x32_bf16(a.w, b.w, c); }
+#endif
+__device__ __forceinline__ float bf_lo_as_float(uint32_t w) { uint32_t u = w << 16; float f; __builtin_memcpy(&f, &u, 4); return f; }
+__device__ __forceinline__ float bf_hi_as_float(uint32_t w) { uint32_t u = w & 0xffff0000u; float f; __builtin_memcpy(&f, &u, 4); return f; }
+// eight consecutive floats -> the three bf16 pieces of each (44 VALU instructions)
+__device__ __forceinline__ void bf_split8(const float (&a)[8], BfFrag& p0, BfFrag& p1, BfFrag& p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = a[2 * j], a1 = a[2 * j + 1];
+    const uint32_t h = bf_pack2(a0, a1);
+    const float r0 = a0 - bf_lo_as_float(h), r1 = a1 - bf_hi_as_float(h);
+    const uint32_t m = bf_pack2(r0, r1);
+    const float s0 = r0 - bf_lo_as_float(m), s1 = r1 - bf_hi_as_float(m);
+    p0.w[j] = h; p1.w[j] = m; p2.w[j] = bf_pack2(s0, s1);
+  }
+}
+
 template <typename real> struct Vec4;   // 4 consecutive reals, naturally aligned
 template <> struct __attribute__((aligned(16))) Vec4<float> { float v[4]; };
 template <> struct __attribute__((aligned(32))) Vec4<double> { double v[4]; };

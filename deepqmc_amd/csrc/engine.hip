@@ -196,6 +196,8 @@ struct Engine : dqmc_ctx {
   int fused_stagger = 0;         // option "fused_stagger": start delay between the co-resident workgroups of a CU (x 8128 cycles)
   int fused_prio = 1;            // option "fused_prio": issue priority rotates among the tiles that share a CU (1: per level, 2: per unit, 0: off)
   int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
+  int fused_bf = 1;              // option "fused_bf": float32 layers of the value path on the bf16 matrix pipe (three-piece split, six products; float engines only)
+  std::vector<char> op_bf;       // per scheduled op: packed in the bf16 plane layout
   int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
   std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
@@ -621,6 +623,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
+    if (s == "fused_bf") { fused_bf = value; return build_fused_plan(); }
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
       fused2_lds_quarter = (size_t)160 * 1024 / value;
@@ -1025,17 +1028,27 @@ struct Engine : dqmc_ctx {
         dqmc::FDesc t{};
         t.kind = 1; t.op = j; t.n_pieces = i[0]; t.rtot = Rtot; t.ldw = ldw;
         long kq = 0;
+        bool bf = op_bf[j] != 0;
         for (int p = 0; p < i[0]; ++p) {
           const dqmc::FusedBuf& sb = fb[i[1 + 4 * p]];
           if (sb.is_global) { fused2_WT = 0; return DQMC_OK; }
           t.a_base[p] = sb.off + i[2 + 4 * p] * WT * sb.stride;
           t.a_stride[p] = sb.stride;
-          t.a_ks[p] = pad4(i[3 + 4 * p]) / 4;
-          t.a_nq[p] = (t.a_ks[p] + 3) / 4;
+          if ((t.a_base[p] | t.a_stride[p]) & 1) bf = false;        // (8-byte LDS reads of the A octets)
+        }
+        if (op_bf[j] && !bf) return fail(DQMC_E_UNSUPPORTED, "fused plan: odd LDS offset under a bf16-packed layer");
+        for (int p = 0; p < i[0]; ++p) {
+          if (bf) {       // bf16 matrix pipe: octets of k, chunks of 32 k
+            t.a_ks[p] = i[3 + 4 * p] / 8;
+            t.a_nq[p] = (i[3 + 4 * p] + 31) / 32;
+          } else {
+            t.a_ks[p] = pad4(i[3 + 4 * p]) / 4;
+            t.a_nq[p] = (t.a_ks[p] + 3) / 4;
+          }
           if (i[4 + 4 * p]) t.bcast |= 1 << p;
           kq += t.a_nq[p];
         }
-        t.qstride = NCB * 64;
+        t.qstride = bf ? NCB * 192 : NCB * 64;
         t.bias_off = i[23];
         const dqmc::FusedBuf& db = fb[i[17]];
         t.flags = (i[24] & 3) | (i[27] ? 4 : 0);
@@ -1054,19 +1067,21 @@ struct Engine : dqmc_ctx {
             u.d.ma = (NRB - rb0) < rpu ? (NRB - rb0) : rpu;
             u.d.row0 = rb0 * 16;
             u.d.col0 = cg * 32;
-            u.d.w_off = words[2 * j] / 4 + (cg * 2) * 64;
-            u.d.w_cb1 = (cg * 2 + 1 < NCB) ? 64 : 0;
+            u.d.w_off = words[2 * j] / 4 + (cg * 2) * (bf ? 192 : 64);
+            u.d.w_cb1 = (cg * 2 + 1 < NCB) ? (bf ? 192 : 64) : 0;
             if ((rb0 + u.d.ma) * 16 <= Rtot && cg * 32 + 32 <= ldw) u.d.flags |= 16;
-            // small layers take the lean unit body (kernel_fused2.hip: fused2_unit_lean)
-            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= dqmc::FUSED_GROUP_QUADS && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = 5;
-            u.cost = 12 + (long)u.d.ma * (4 * kq + 6);     // ~ fixed setup + MFMA quads + epilogue, in 100-cycle units
+            if (bf) u.d.kind = 6;
+            // small layers take the lean unit body (kernel_fused2.hip: fused2_unit_lean / FusedBfUnit::lean)
+            if (fused_lean && u.d.ma == 1 && i[0] == 1 && !u.d.bcast && t.a_nq[0] <= (bf ? 1 : dqmc::FusedGroup<real>::P) && !(t.flags & 8) && (i[24] & 3) <= 1) u.d.kind = bf ? 7 : 5;
+            u.cost = 12 + (long)u.d.ma * ((bf ? 3 : 4) * kq + 6);     // ~ fixed setup + MFMA quads / chunks + epilogue, in 100-cycle units
             level_units.push_back(u);
           }
       }
       if (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) flush_level();
     }
     fused2_ma1 = true;
-    for (auto& l : lists) for (auto& dd : l) if ((dd.kind == 1 || dd.kind == 5) && dd.ma != 1) fused2_ma1 = false;
+    auto is_unit = [](int k) { return k == 1 || k == 5 || k == 6 || k == 7; };
+    for (auto& l : lists) for (auto& dd : l) if (is_unit(dd.kind) && dd.ma != 1) fused2_ma1 = false;
     std::vector<dqmc::FDesc> flat;
     int32_t begin[8];
     // (plan_lists is recorded after the chaining below)
@@ -1075,16 +1090,17 @@ struct Engine : dqmc_ctx {
       begin[4 + w] = -1;
       int last_unit = -1;                          // chain the units of the list: each prefetches the next one's first weights
       for (size_t k = 0; k < lists[w].size(); ++k) {
-        if (lists[w][k].kind != 1 && lists[w][k].kind != 5) continue;
+        if (!is_unit(lists[w][k].kind)) continue;
         if (last_unit < 0) begin[4 + w] = begin[w] + (int32_t)k;
         last_unit = (int)k;
       }
       last_unit = -1;
       for (size_t k = lists[w].size(); k-- > 0;) {     // every unit carries the first-group parameters of the unit after it
         dqmc::FDesc& u = lists[w][k];
-        if (u.kind != 1 && u.kind != 5) continue;
+        if (!is_unit(u.kind)) continue;
         const dqmc::FDesc& nx = last_unit < 0 ? u : lists[w][last_unit];
-        u.nx_w_off = nx.w_off; u.nx_cb1 = nx.w_cb1; u.nx_qstride = nx.qstride; u.nx_nq = nx.a_nq[0];
+        const bool nx_bf = nx.kind == 6 || nx.kind == 7;          // (its first group: the three planes of its first chunk)
+        u.nx_w_off = nx.w_off; u.nx_cb1 = nx.w_cb1; u.nx_qstride = nx_bf ? 64 : nx.qstride; u.nx_nq = nx_bf ? 3 : nx.a_nq[0];
         last_unit = (int)k;
       }
       flat.insert(flat.end(), lists[w].begin(), lists[w].end());
@@ -1157,12 +1173,39 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
+  // piece pl (0..2) of the three-bf16 split of a float (round to nearest even, residuals exact: common.h bf_split8)
+  static uint16_t bf16_piece(float v, int pl) {
+    auto rne = [](float f) -> uint16_t {
+      uint32_t u; memcpy(&u, &f, 4);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    auto up = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    uint16_t h = rne(v);
+    for (int k = 0; k < pl; ++k) { v = v - up(h); h = rne(v); }
+    return h;
+  }
   // Fragment-major copy of the Linear weights: [k/4][column block][lane] so that one wave load
   // of 64 consecutive elements is exactly the MFMA B operand (B[k = l>>4][col = l&15]).
   // Per scheduled op two words go to the device: packed-weight offset and "barrier after".
   int pack_fused_weights() {
     std::vector<int32_t> words(2 * (size_t)fused_n_ops, 0);
     std::vector<real> pk;
+    op_bf.assign((size_t)fused_n_ops, 0);
+    for (int j = 0; j < fused_n_ops && fused_bf && sizeof(real) == 4; ++j) {
+      // a layer goes to the bf16 matrix pipe when every piece is whole octets wide and the chunks of 32 k
+      // (12 MFMAs of 16 cycles + the operand split) cost less than its k-steps of 4 (2 MFMAs of 32 cycles)
+      const dqmc_op& op = ops[f_order[j]];
+      if (op.kind != DQMC_OP_LINEAR) continue;
+      bool ok = true;
+      int chunks = 0, ksteps = 0;
+      for (int p = 0; p < op.i[0]; ++p) {
+        const int K = op.i[3 + 4 * p];
+        if (K % 8 != 0 || K == 0 || (bufs[op.i[1 + 4 * p]].width & 1)) ok = false;      // (even LDS row stride: 8-byte reads of the A octets)
+        chunks += (K + 31) / 32; ksteps += (K + 3) / 4;
+      }
+      op_bf[j] = ok && 9 * chunks < 2 * ksteps;
+    }
     for (int j = 0; j < fused_n_ops; ++j) {
       const dqmc_op& op = ops[f_order[j]];
       words[2 * j + 1] = (j + 1 == fused_n_ops || f_level[j + 1] > f_level[j]) ? 1 : 0;
@@ -1174,6 +1217,30 @@ struct Engine : dqmc_ctx {
       words[2 * j] = (int32_t)pk.size();
       const real* W = wtmp.data() + i[22];
       int row0 = 0;
+      if (op_bf[j]) {
+        // bf16 plane layout: [piece][chunk of 32 k][column block][plane][lane][4 words]; word jj of lane l holds
+        // k = 32 c + 8 (l >> 4) + 2 jj (low half) and + 1 (high half) of column cb 16 + (l & 15)
+        for (int p = 0; p < i[0]; ++p) {
+          const int K = i[3 + 4 * p], NC = (K + 31) / 32;
+          for (int c = 0; c < NC; ++c)
+            for (int cb = 0; cb < NCB; ++cb)
+              for (int pl = 0; pl < 3; ++pl)
+                for (int l = 0; l < 64; ++l)
+                  for (int jj = 0; jj < 4; ++jj) {
+                    uint32_t word = 0;
+                    for (int h = 0; h < 2; ++h) {
+                      const int k = 32 * c + 8 * (l >> 4) + 2 * jj + h, col = cb * 16 + (l & 15);
+                      const float wv = (k < K && col < ldw) ? (float)W[(size_t)(row0 + k) * ldw + col] : 0.0f;
+                      word |= (uint32_t)bf16_piece(wv, pl) << (16 * h);
+                    }
+                    real as_real;
+                    memcpy(&as_real, &word, 4);       // (float engines only: sizeof(real) == 4)
+                    pk.push_back(as_real);
+                  }
+          row0 += K;
+        }
+        continue;
+      }
       for (int p = 0; p < i[0]; ++p) {
         const int KS = pad4(i[3 + 4 * p]) / 4, NQ = (KS + 3) / 4;
         for (int q = 0; q < NQ; ++q)

@@ -66,16 +66,18 @@ template <typename real> __device__ __forceinline__ real act2_value(int act, rea
 // with clamped quad indices (a conditional load makes the compiler copy the loaded registers at the join, which needs
 // the data at once: the earlier four-deep ring waited for every quad it had just requested -- the 448-wide layers ran at
 // 19 k cycles against 7 k of MFMA work).  Quads past the end of a piece re-read its last quad and are not multiplied.
-template <typename real> struct BSet { typename RVec4<real>::type b[FUSED_GROUP_QUADS][2]; };
+template <typename real> struct BSet { typename RVec4<real>::type b[2][FusedGroup<real>::P]; };      // [column block][quad of the group | bf16 plane]
 
+// pstride: Vec4 distance between the slots of one column block -- the quad stride of an f32 unit, the plane stride (64)
+// of a bf16 unit (whose group is one K = 32 chunk: planes 0..2, n_left = 3)
 template <typename real>
-__device__ __forceinline__ void fused2_load_group(BSet<real>& s, const typename RVec4<real>::type* w, int cb1, int qstride, int n_left) {
+__device__ __forceinline__ void fused2_load_group(BSet<real>& s, const typename RVec4<real>::type* w, int cb1, int pstride, int n_left) {
   const int last = n_left - 1;
 #pragma unroll
-  for (int dd = 0; dd < FUSED_GROUP_QUADS; ++dd) {
-    const int qi = (dd < last ? dd : last) * qstride;      // wave-uniform clamp
-    s.b[dd][0] = w[qi];
-    s.b[dd][1] = w[qi + cb1];
+  for (int dd = 0; dd < FusedGroup<real>::P; ++dd) {
+    const int qi = (dd < last ? dd : last) * pstride;      // wave-uniform clamp
+    s.b[0][dd] = w[qi];
+    s.b[1][dd] = w[qi + cb1];
   }
 }
 // first group of the unit described by nd (w_off, w_cb1, qstride, quads of its first piece)
@@ -249,7 +251,7 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
 #pragma unroll
       for (int x = 0; x < MA; ++x) fan[kk][x] = smem[ao[x] + ks * 4];
     }
-    constexpr int G = FUSED_GROUP_QUADS;
+    constexpr int G = FusedGroup<real>::P;
     for (int q = 0; q < NQ; q += G) {
       BSet<real> cur = nxt;                                 // arrived long ago: register moves, no wait
       {
@@ -278,8 +280,8 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
           for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int x = 0; x < MA; ++x) {
-              acc[x][0] = Mfma<real>::run(fa[kk][x], cur.b[dd][0][kk], acc[x][0]);
-              acc[x][1] = Mfma<real>::run(fa[kk][x], cur.b[dd][1][kk], acc[x][1]);
+              acc[x][0] = Mfma<real>::run(fa[kk][x], cur.b[0][dd][kk], acc[x][0]);
+              acc[x][1] = Mfma<real>::run(fa[kk][x], cur.b[1][dd][kk], acc[x][1]);
             }
         }
       }
@@ -290,7 +292,7 @@ __device__ __forceinline__ void fused2_unit(const Fused2Args<real>& a, DescPtr d
 }
 
 // Lean unit for the many SMALL layers (edge MLPs, second layers of the node MLPs): one piece, one row block, at most
-// FUSED_GROUP_QUADS quads of k-steps, LDS destination, tanh or no activation.  Its whole B operand arrived with the previous
+// FusedGroup::P quads of k-steps, LDS destination, tanh or no activation.  Its whole B operand arrived with the previous
 // unit (`nxt`); the next unit's first group is requested first thing, all A fragments are read up front (clamped
 // addresses, so the loads need no branches and their latency is paid once), then up to 32 MFMAs and the epilogue.
 template <typename real>
@@ -315,7 +317,7 @@ __device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, Desc
   }
   const int m = row0 + l15;
   const int ao = d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + l4;
-  constexpr int G = FUSED_GROUP_QUADS;
+  constexpr int G = FusedGroup<real>::P;
   real fa[G][4];
 #pragma unroll
   for (int dd = 0; dd < G; ++dd)
@@ -331,13 +333,142 @@ __device__ __forceinline__ void fused2_unit_lean(const Fused2Args<real>& a, Desc
     if (dd < NQ) {                                          // wave-uniform
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        acc[0][0] = Mfma<real>::run(fa[dd][kk], cur.b[dd][0][kk], acc[0][0]);
-        acc[0][1] = Mfma<real>::run(fa[dd][kk], cur.b[dd][1][kk], acc[0][1]);
+        acc[0][0] = Mfma<real>::run(fa[dd][kk], cur.b[0][dd][kk], acc[0][0]);
+        acc[0][1] = Mfma<real>::run(fa[dd][kk], cur.b[1][dd][kk], acc[0][1]);
       }
     }
   }
   fused2_epilogue<real, 1>(a, d, acc, bias_v);
 }
+
+// ---- float32 layers on the bf16 matrix pipe (common.h: "float32 products on the bf16 matrix pipe") ----
+// Same unit shape (MA row blocks x 2 column blocks), same accumulators and epilogue; the K loop runs in chunks of 32:
+// a lane reads its eight consecutive A values of the chunk from LDS (four 8-byte reads), splits them into three bf16
+// pieces in registers, and six MFMAs per column block multiply them with the three pre-split weight planes
+// (engine.hip: pack_fused_weights lays the planes out fragment-major, [chunk][column block][plane][lane] x 16 bytes).
+// One group of B operands = one chunk (3 planes x 2 column blocks = 24 registers), prefetched one chunk ahead like the
+// f32 groups.  Pieces are whole octets wide (K % 8 == 0); the lanes of a partial last chunk re-read the last valid
+// octet against zero weights.
+__device__ __forceinline__ void fused2_read_octet(const float* smem, int off, float (&v)[8]) {
+  const Vec2<float>* p = reinterpret_cast<const Vec2<float>*>(smem + off);       // off is even: 8-byte LDS reads
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const Vec2<float> t = p[j]; v[2 * j] = t.v[0]; v[2 * j + 1] = t.v[1]; }
+}
+__device__ __forceinline__ void fused2_bf_chunk(const float (&av)[8], const BSet<float>& cur, f32x4& acc0, f32x4& acc1) {
+  BfFrag a0, a1, a2;
+  bf_split8(av, a0, a1, a2);
+  const BfFrag* b0 = reinterpret_cast<const BfFrag*>(&cur.b[0][0]);
+  const BfFrag* b1 = reinterpret_cast<const BfFrag*>(&cur.b[1][0]);
+  // small terms first; the two column blocks interleave (independent accumulators)
+  acc0 = mfma_bf16(a2, b0[0], acc0); acc1 = mfma_bf16(a2, b1[0], acc1);
+  acc0 = mfma_bf16(a1, b0[1], acc0); acc1 = mfma_bf16(a1, b1[1], acc1);
+  acc0 = mfma_bf16(a0, b0[2], acc0); acc1 = mfma_bf16(a0, b1[2], acc1);
+  acc0 = mfma_bf16(a1, b0[0], acc0); acc1 = mfma_bf16(a1, b1[0], acc1);
+  acc0 = mfma_bf16(a0, b0[1], acc0); acc1 = mfma_bf16(a0, b1[1], acc1);
+  acc0 = mfma_bf16(a0, b0[0], acc0); acc1 = mfma_bf16(a0, b1[0], acc1);
+}
+template <typename real, int MA> struct FusedBfUnit {
+  static __device__ __forceinline__ void run(const Fused2Args<real>&, DescPtr, BSet<real>&) {}
+  static __device__ __forceinline__ void lean(const Fused2Args<real>&, DescPtr, BSet<real>&) {}
+};
+template <int MA> struct FusedBfUnit<float, MA> {
+  static __device__ __forceinline__ void run(const Fused2Args<float>& a, DescPtr d, BSet<float>& nxt) {
+    HIP_DYNAMIC_SHARED(char, smem_raw)
+    const float* smem = reinterpret_cast<const float*>(smem_raw);
+    typedef f32x4 rv4;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
+    const int wtm1 = a.WT - 1;
+    int mrow[MA];
+#pragma unroll
+    for (int x = 0; x < MA; ++x) {
+      const int m = row0 + x * 16 + l15;
+      mrow[x] = m < rtot ? m : row0;
+    }
+    f32x4 acc[MA][2];
+#pragma unroll
+    for (int x = 0; x < MA; ++x) { acc[x][0] = f32x4{0, 0, 0, 0}; acc[x][1] = f32x4{0, 0, 0, 0}; }
+    const int bias_off = d->bias_off;
+    float bias_v[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int col = col_u + y * 16 + l15;
+      bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : 0.0f;
+    }
+    const rv4* wbase = reinterpret_cast<const rv4*>(a.wpk) + d->w_off + lane;
+    const int cb1 = d->w_cb1, cstride = d->qstride, bcast = d->bcast, n_pieces = d->n_pieces;
+    const rv4* nu_w = reinterpret_cast<const rv4*>(a.wpk) + d->nx_w_off + lane;
+    const int nu_cb1 = d->nx_cb1, nu_ps = d->nx_qstride, nu_nq = d->nx_nq;
+    int c0 = 0;
+    for (int p = 0; p < n_pieces; ++p) {
+      const int base = d->a_base[p], stride = d->a_stride[p], K8 = d->a_ks[p], NC = d->a_nq[p];
+      const bool bc = (bcast >> p) & 1;
+      const bool last_piece = p + 1 == n_pieces;
+      int ao[MA];
+#pragma unroll
+      for (int x = 0; x < MA; ++x) ao[x] = base + (bc ? (mrow[x] & wtm1) : mrow[x]) * stride;
+      float an[MA][8];                                       // A octets (LDS) run one chunk ahead
+      {
+        const int o = l4 < K8 ? l4 : K8 - 1;
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
+      }
+      for (int c = 0; c < NC; ++c) {
+        const BSet<float> cur = nxt;
+        {
+          const bool more = c + 1 < NC;                      // wave-uniform selects, then ONE unconditional load sequence
+          const bool own = more || !last_piece;
+          const rv4* gw = own ? wbase + (long)(c0 + c + 1) * cstride : nu_w;
+          fused2_load_group<float>(nxt, gw, own ? cb1 : nu_cb1, own ? 64 : nu_ps, own ? 3 : nu_nq);
+        }
+        float ac[MA][8];
+#pragma unroll
+        for (int x = 0; x < MA; ++x)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ac[x][j] = an[x][j];
+        {
+          int o = (c + 1) * 4 + l4;
+          o = o < K8 ? o : K8 - 1;
+#pragma unroll
+          for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
+        }
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], cur, acc[x][0], acc[x][1]);
+      }
+      c0 += NC;
+    }
+    fused2_epilogue<float, MA>(a, d, acc, bias_v);
+  }
+  // one piece, one chunk, one row block, LDS destination: everything the unit needs arrived with the previous unit
+  static __device__ __forceinline__ void lean(const Fused2Args<float>& a, DescPtr d, BSet<float>& nxt) {
+    HIP_DYNAMIC_SHARED(char, smem_raw)
+    const float* smem = reinterpret_cast<const float*>(smem_raw);
+    typedef f32x4 rv4;
+    const int lane = threadIdx.x & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int row0 = d->row0, rtot = d->rtot, ldw = d->ldw, col_u = d->col0;
+    const int K8 = d->a_ks[0];
+    const int bias_off = d->bias_off;
+    float bias_v[2];
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int col = col_u + y * 16 + l15;
+      bias_v[y] = (bias_off >= 0 && col < ldw) ? a.w[bias_off + col] : 0.0f;
+    }
+    const BSet<float> cur = nxt;
+    {
+      const rv4* nb = reinterpret_cast<const rv4*>(a.wpk) + d->nx_w_off + lane;
+      fused2_load_group<float>(nxt, nb, d->nx_cb1, d->nx_qstride, d->nx_nq);
+    }
+    const int m = row0 + l15;
+    const int o = l4 < K8 ? l4 : K8 - 1;
+    float av[8];
+    fused2_read_octet(smem, d->a_base[0] + (m < rtot ? m : row0) * d->a_stride[0] + 8 * o, av);
+    f32x4 acc[1][2];
+    acc[0][0] = f32x4{0, 0, 0, 0}; acc[0][1] = f32x4{0, 0, 0, 0};
+    fused2_bf_chunk(av, cur, acc[0][0], acc[0][1]);
+    fused2_epilogue<float, 1>(a, d, acc, bias_v);
+  }
+};
 
 // Slater-matrix entries A[(wl, k)][el][mu] = envelope(el; k, mu) * backflow(el; k, mu) for the tile (the arithmetic of
 // k_orbitals, value lane).  One thread per (electron, orbital k*N + mu): the envelope weights pi / zeta of that pair are
@@ -812,6 +943,18 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
       wave_lds_fence();          // chained MLP layer: the rows this wave just stored are the rows it reads next
     } else if (kind == 5) {
       fused2_unit_lean<real>(a, d, nxt);
+    } else if (kind == 7) {
+      FusedBfUnit<real, 1>::lean(a, d, nxt);
+    } else if (kind == 6) {
+      if (MA1) {
+        FusedBfUnit<real, 1>::run(a, d, nxt);
+      } else {
+        const int ma = d->ma;
+        if (ma == 1) FusedBfUnit<real, 1>::run(a, d, nxt);
+        else if (ma == 2) FusedBfUnit<real, 2>::run(a, d, nxt);
+        else if (ma == 3) FusedBfUnit<real, 3>::run(a, d, nxt);
+        else FusedBfUnit<real, 4>::run(a, d, nxt);
+      }
     } else if (kind == 1) {
       if (MA1) {
         fused2_unit<real, 1>(a, d, nxt);

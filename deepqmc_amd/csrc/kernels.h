@@ -79,9 +79,10 @@ struct FusedBuf {
 };
 // One entry of a wave's work list; built on the host (engine.hip: build_fused2_plan), read through scalar loads.
 // quads of k-steps per B-operand group of the fused kernel (kernel_fused2.hip: BSet); lean units hold at most one group
-constexpr int FUSED_GROUP_QUADS = 2;
+// (float: three slots per column block, which are also the three bf16 planes of a K = 32 chunk of a bf16 unit)
+template <typename real> struct FusedGroup { static constexpr int P = sizeof(real) == 4 ? 3 : 2; };
 struct FDesc {
-  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, at most FUSED_GROUP_QUADS quads of k-steps, LDS destination)
+  int32_t kind;         // 0 end of list, 1 linear unit, 2 workgroup barrier, 3 structured op (all waves), 4 wave-local LDS fence, 5 lean linear unit (one piece, at most FusedGroup::P quads of k-steps, LDS destination), 6 / 7 linear unit / lean unit on the bf16 matrix pipe (float only; a_ks = octets of k, a_nq = chunks of 32 k, qstride = Vec4 per chunk)
   int32_t op;           // scheduled op index (FusedArgs::ops)
   int32_t ma;           // row blocks of the unit (1..4); column blocks are always 2
   int32_t n_pieces;

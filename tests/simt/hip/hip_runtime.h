@@ -122,6 +122,33 @@ inline simt_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, simt_f3
   simt::wave_gather_end();
   return c;
 }
+// v_cvt_pk_bf16_f32 (round to nearest even) and v_mfma_f32_16x16x32_bf16: lane l holds row / column l&15 and
+// k = 8*(l>>4) .. +7 (two per word, even k low); products of bf16 numbers are exact in f32, the sum is taken in double
+// and rounded once (the hardware's internal order is not documented; the kernels do not depend on it).
+namespace dqmc {
+inline uint32_t bf_pack2(float lo, float hi) {
+  auto cv = [](float f) -> uint32_t {
+    uint32_t u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  };
+  return cv(lo) | (cv(hi) << 16);
+}
+}
+inline simt_f32x4 simt_mfma_f32_16x16x32_bf16(const uint32_t (&a)[4], const uint32_t (&b)[4], simt_f32x4 c) {
+  simt::wave_gather_begin(a, b, 16);
+  const int l = simt::lane_id(), col = l & 15;
+  auto val = [](const char* slot, int i) { uint32_t w; memcpy(&w, slot + 4 * (i >> 1), 4); uint32_t u = (i & 1) ? (w & 0xffff0000u) : (w << 16); float f; memcpy(&f, &u, 4); return f; };
+  for (int reg = 0; reg < 4; ++reg) {
+    const int row = (l >> 4) * 4 + reg;
+    double acc = c[reg];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int i = 0; i < 8; ++i) acc += (double)val(simt::wave_slot_a(kg * 16 + row), i) * (double)val(simt::wave_slot_b(kg * 16 + col), i);
+    c[reg] = (float)acc;
+  }
+  simt::wave_gather_end();
+  return c;
+}
 // v_mfma_f64_16x16x4_f64: same A/B maps; D col=l&15 row=(l>>4)+4*reg.
 inline simt_f64x4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, simt_f64x4 c, int, int, int) {
   simt::wave_gather_begin(&a, &b, sizeof(double));
