@@ -1204,7 +1204,7 @@ struct Engine : dqmc_ctx {
         if (K % 8 != 0 || K == 0 || (bufs[op.i[1 + 4 * p]].width & 1)) ok = false;      // (even LDS row stride: 8-byte reads of the A octets)
         chunks += (K + 31) / 32; ksteps += (K + 3) / 4;
       }
-      op_bf[j] = ok && 9 * chunks < 2 * ksteps;
+      op_bf[j] = ok && (fused_bf >= 2 ? 9 * chunks < 2 * ksteps : 4 * chunks <= ksteps);     // (option value 2: the stricter rule; measured 110.8 vs 108.8 us)
     }
     for (int j = 0; j < fused_n_ops; ++j) {
       const dqmc_op& op = ops[f_order[j]];

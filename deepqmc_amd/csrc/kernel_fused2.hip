@@ -413,27 +413,46 @@ template <int MA> struct FusedBfUnit<float, MA> {
 #pragma unroll
         for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
       }
-      for (int c = 0; c < NC; ++c) {
-        const BSet<float> cur = nxt;
-        {
-          const bool more = c + 1 < NC;                      // wave-uniform selects, then ONE unconditional load sequence
-          const bool own = more || !last_piece;
-          const rv4* gw = own ? wbase + (long)(c0 + c + 1) * cstride : nu_w;
-          fused2_load_group<float>(nxt, gw, own ? cb1 : nu_cb1, own ? 64 : nu_ps, own ? 3 : nu_nq);
-        }
+      // chunks in pairs over two register sets (`nxt` and `alt`) that swap roles, so no set is ever copied: while
+      // chunk c multiplies from one set, chunk c + 1 is in flight into the other; as soon as the MFMAs of chunk c are
+      // issued its set is refilled with chunk c + 2 (or the first group of the next piece / of the wave's next unit)
+      auto next_octets = [&](int c_next) {
+        int o = c_next * 4 + l4;
+        o = o < K8 ? o : K8 - 1;
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
+      };
+      auto request = [&](BSet<float>& into, int c_next) {      // group of chunk c_next of this piece, or what follows the piece
+        const bool own = c_next < NC || !last_piece;           // wave-uniform selects, then ONE unconditional load sequence
+        const rv4* gw = own ? wbase + (long)(c0 + c_next) * cstride : nu_w;
+        fused2_load_group<float>(into, gw, own ? cb1 : nu_cb1, own ? 64 : nu_ps, own ? 3 : nu_nq);
+      };
+      int c = 0;
+      for (; c + 1 < NC; c += 2) {
+        BSet<float> alt;
+        request(alt, c + 1);
         float ac[MA][8];
 #pragma unroll
         for (int x = 0; x < MA; ++x)
 #pragma unroll
           for (int j = 0; j < 8; ++j) ac[x][j] = an[x][j];
-        {
-          int o = (c + 1) * 4 + l4;
-          o = o < K8 ? o : K8 - 1;
+        next_octets(c + 1);
 #pragma unroll
-          for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
-        }
+        for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], nxt, acc[x][0], acc[x][1]);
+        request(nxt, c + 2);
 #pragma unroll
-        for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], cur, acc[x][0], acc[x][1]);
+        for (int x = 0; x < MA; ++x)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ac[x][j] = an[x][j];
+        next_octets(c + 2);
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], alt, acc[x][0], acc[x][1]);
+      }
+      if (c < NC) {                                            // odd last chunk: the one copy
+        const BSet<float> cur = nxt;
+        request(nxt, c + 1);
+#pragma unroll
+        for (int x = 0; x < MA; ++x) fused2_bf_chunk(an[x], cur, acc[x][0], acc[x][1]);
       }
       c0 += NC;
     }
