@@ -624,6 +624,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_bf") { fused_bf = value; return build_fused_plan(); }
+    if (s == "linear_bf") { dqmc::set_linear_bf(value); return DQMC_OK; }      // (process-wide A/B hook of kernel_linear.hip)
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
       fused2_lds_quarter = (size_t)160 * 1024 / value;

@@ -408,6 +408,271 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink);
 }
 
+// ---- float32 layers on the bf16 matrix pipe (common.h: "float32 products on the bf16 matrix pipe") ----
+// Same tiling, row mapping and epilogue as k_linear<float, ...>; the K loop runs in chunks of 32:
+//   * the A tile stays float32 in LDS (row stride 34 words: the eight consecutive values a lane needs are four
+//     conflict-free 8-byte reads) and is split into its three bf16 pieces in registers, once per row block and chunk
+//     (44 VALU instructions against NR x NP MFMAs);
+//   * the weights are split while they are staged: a thread takes two k rows x four columns, and writes one 16-byte
+//     row segment per plane into Bs[plane][k pair][column] (row stride BN + 4 words: the four k groups of a fragment
+//     read fall on distinct banks);
+//   * NP = 9: all products of the pieces, the result is a float32 product sum with FEWER roundings than the
+//     v_mfma_f32_16x16x4_f32 chain (144 instead of 256 matrix-pipe cycles per 16 x 16 x 32 block) -- the Laplacian
+//     pass, whose derivative lanes cancel; NP = 6 (96 cycles) drops the three terms below 2^-24: value-only rows.
+__device__ __forceinline__ void sched_fence() {
+#if defined(__HIPCC__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <int MR, int NR, int GPW, int WN, int NP>
+__global__ void __launch_bounds__(256 * WN) k_linear_bf(const LinArgs<float> a) {
+  typedef float real;
+  constexpr int NT = 256 * WN;
+  constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 32;
+  constexpr int AS = BK + 2, BSTR = BN + 4;
+  constexpr bool HALF = GPW < 0;
+  constexpr int GB = GPW > 0 ? MR / GPW : 1;
+  constexpr int APT = MR / WN;                                  // A rows per thread and chunk (two 16-byte loads each)
+  constexpr int NBI = ((BK / 2) * (BN / 4) + NT - 1) / NT;       // B items (2 k rows x 4 columns) per thread and chunk
+  constexpr bool HOLD_A = MR <= NR;                              // which operand's pieces stay in registers across the other's loop
+  static_assert(MR % WN == 0, "MR must be a multiple of WN");
+  typedef Mfma<float>::acc_t acc_t;
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  float* As = reinterpret_cast<float*>(smem_raw);                                  // [BM][AS]
+  uint32_t* Bs = reinterpret_cast<uint32_t*>(smem_raw + (size_t)BM * AS * 4);     // [3][16][BSTR]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int n_groups = a.B * a.nrows;
+  const int col_blk0 = blockIdx.y * BN;
+  const int kg = lane >> 4, l15 = lane & 15;
+
+  int a_row[APT], a_g[APT], a_t[APT];
+  const int a_kq = tid & 3;
+#pragma unroll
+  for (int j = 0; j < APT; ++j) {
+    const int row = (tid >> 2) + (NT / 4) * j;
+    a_row[j] = row;
+    int g, t;
+    if (HALF) {
+      const int w = row / (16 * MR), rb = (row >> 4) % MR;
+      g = ((blockIdx.x * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
+      t = row & 7;
+    } else if (GPW > 0) {
+      const int w = row / (16 * MR), rb = (row >> 4) % MR;
+      g = (blockIdx.x * 4 + w) * GPW + rb / GB;
+      t = (rb % GB) * 16 + (row & 15);
+    } else {
+      g = blockIdx.x * BM + row;
+      t = 0;
+    }
+    a_g[j] = g < n_groups ? g : -1;
+    a_t[j] = t;
+  }
+
+  acc_t acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+
+  for (int p = 0; p < a.n_pieces; ++p) {
+    const LinPiece<real> pc = a.piece[p];
+    const int w_row0 = pc.w_row;
+    const real* a_src[APT];
+#pragma unroll
+    for (int j = 0; j < APT; ++j) {
+      if (a_g[j] >= 0) {
+        const int b = a_g[j] / a.nrows, rr = a_g[j] - b * a.nrows;
+        const long srow = ((long)b * pc.rpw + pc.r0 + (pc.bcast ? 0 : rr)) * a.TP + a_t[j];
+        a_src[j] = pc.src + srow * pc.ld;
+      } else {
+        a_src[j] = nullptr;
+      }
+    }
+    const int n_chunks = (pc.K + BK - 1) / BK;
+    Vec4<real> ra[APT][2], rb_[NBI][2];
+    auto load_chunk = [&](int kc) {
+#pragma unroll
+      for (int j = 0; j < APT; ++j)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          const int k0 = kc * BK + 16 * x + 4 * a_kq;
+          if (a_src[j] != nullptr && k0 < pc.K) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
+          else ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
+        }
+#pragma unroll
+      for (int j = 0; j < NBI; ++j) {
+        const int f = tid + NT * j;
+        const int kp = f / (BN / 4), n4 = f % (BN / 4);
+        const int kk = kc * BK + 2 * kp, col = col_blk0 + 4 * n4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (f < (BK / 2) * (BN / 4) && kk + h < pc.K && col < a.ldw)
+            rb_[j][h] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk + h) * a.ldw + col);
+          else
+            rb_[j][h] = Vec4<real>{{0, 0, 0, 0}};
+        }
+      }
+    };
+    load_chunk(0);
+    for (int kc = 0; kc < n_chunks; ++kc) {
+      __syncthreads();  // previous chunk's fragments have been read
+#pragma unroll
+      for (int j = 0; j < APT; ++j)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          Vec2<real>* dst = reinterpret_cast<Vec2<real>*>(&As[a_row[j] * AS + 16 * x + 4 * a_kq]);
+          dst[0] = Vec2<real>{{ra[j][x].v[0], ra[j][x].v[1]}};
+          dst[1] = Vec2<real>{{ra[j][x].v[2], ra[j][x].v[3]}};
+        }
+#pragma unroll
+      for (int j = 0; j < NBI; ++j) {
+        const int f = tid + NT * j;
+        if (f < (BK / 2) * (BN / 4)) {
+          const int kp = f / (BN / 4), n4 = f % (BN / 4);
+          uint32_t w0[4], w1[4], w2[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {                          // column c of the item: k (low half) and k + 1 (high half)
+            const float x0 = rb_[j][0].v[c], x1 = rb_[j][1].v[c];
+            const uint32_t h = bf_pack2(x0, x1);
+            const float r0 = x0 - bf_lo_as_float(h), r1 = x1 - bf_hi_as_float(h);
+            const uint32_t m = bf_pack2(r0, r1);
+            w0[c] = h; w1[c] = m; w2[c] = bf_pack2(r0 - bf_lo_as_float(m), r1 - bf_hi_as_float(m));
+          }
+          BfFrag* d0 = reinterpret_cast<BfFrag*>(&Bs[(0 * 16 + kp) * BSTR + 4 * n4]);
+          BfFrag* d1 = reinterpret_cast<BfFrag*>(&Bs[(1 * 16 + kp) * BSTR + 4 * n4]);
+          BfFrag* d2 = reinterpret_cast<BfFrag*>(&Bs[(2 * 16 + kp) * BSTR + 4 * n4]);
+          *d0 = BfFrag{{w0[0], w0[1], w0[2], w0[3]}};
+          *d1 = BfFrag{{w1[0], w1[1], w1[2], w1[3]}};
+          *d2 = BfFrag{{w2[0], w2[1], w2[2], w2[3]}};
+        }
+      }
+      __syncthreads();
+      if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
+      auto read_a = [&](int i, BfFrag& p0, BfFrag& p1, BfFrag& p2) {
+        float av[8];
+        const Vec2<real>* src = reinterpret_cast<const Vec2<real>*>(&As[(wm * (16 * MR) + i * 16 + l15) * AS + 8 * kg]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const Vec2<real> t = src[q]; av[2 * q] = t.v[0]; av[2 * q + 1] = t.v[1]; }
+        bf_split8(av, p0, p1, p2);
+      };
+      auto read_b = [&](int j, BfFrag& p0, BfFrag& p1, BfFrag& p2) {
+        const int col = wn * (16 * NR) + j * 16 + l15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          p0.w[q] = Bs[(0 * 16 + 4 * kg + q) * BSTR + col];
+          p1.w[q] = Bs[(1 * 16 + 4 * kg + q) * BSTR + col];
+          p2.w[q] = Bs[(2 * 16 + 4 * kg + q) * BSTR + col];
+        }
+      };
+      if (HOLD_A) {
+        BfFrag fa[MR][3];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) read_a(i, fa[i][0], fa[i][1], fa[i][2]);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          BfFrag b0, b1, b2;
+          read_b(j, b0, b1, b2);
+          if (NP == 9) {
+#pragma unroll
+            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b2, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b1, acc[i][j]);
+#pragma unroll
+            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b2, acc[i][j]);
+          }
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b0, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b1, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b2, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b0, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b1, acc[i][j]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b0, acc[i][j]);
+          sched_fence();       // (keeps the scheduler from hoisting every column block's fragment reads: registers)
+        }
+      } else {
+        BfFrag fb[NR][3];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) read_b(j, fb[j][0], fb[j][1], fb[j][2]);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          BfFrag a0, a1, a2;
+          read_a(i, a0, a1, a2);
+          if (NP == 9) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][2], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][1], acc[i][j]);
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][2], acc[i][j]);
+          }
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][0], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][1], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][2], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][0], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][1], acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][0], acc[i][j]);
+          sched_fence();
+        }
+      }
+    }
+  }
+  HbmSink<real> sink(a);
+  lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink);
+}
+
+// "linear_bf" (dqmc_set_option): 0 = float32 MFMAs everywhere (default), 1 = float32 layers of sufficient depth on the
+// bf16 pipe.  OFF by default: measured SLOWER end to end (MI355X, same-call A/B, ms per step): LiH / PauliNet 5.46 vs
+// 5.46, N2 / FermiNet 52.9 -> 54.4, benzene / Psiformer (256 walkers) 264 -> 284, although the matrix pipe does 44 % less
+// work.  What the counters say for the 128 x 128 tiles of LiH (K = 192): 7 VALU instructions per MFMA -- the forward-
+// Laplacian epilogue (activation derivatives, 64-bit addressing of pre / residual / destination per element) plus the
+// operand splits now outweigh the MFMAs (12 k VALU cycles against 6.9 k matrix-pipe cycles per wave), LDS bank conflicts
+// on a third of the LDS cycles, and 116 registers against 78 (2 instead of 3 workgroups per CU); the taller tiles of
+// the larger systems lose a wave per SIMD (172 against 148 registers).  What it does buy is accuracy: the nine-product
+// sum rounds less often than the f32 MFMA chain (refined walkers 4.3 % -> 4.0 % on LiH, 5.5 % -> 4.9 % on N2).
+static int g_linear_bf = 0;
+void set_linear_bf(int v) { g_linear_bf = v; }
+// a layer goes to the bf16 pipe when its chunks of 32 k (NP MFMAs of 16 cycles per block) cost less than its k-steps of
+// 4 (one MFMA of 32 cycles): pieces of a few k would multiply mostly padding
+static bool bf_pays(const LinArgs<float>& a, int np) {
+  long chunks = 0, ksteps = 0;
+  for (int p = 0; p < a.n_pieces; ++p) { chunks += (a.piece[p].K + 31) / 32; ksteps += (a.piece[p].K + 3) / 4; }
+  return g_linear_bf != 0 && chunks * np * 16 + chunks * 12 < ksteps * 32;
+}
+template <int MR, int NR, int GPW, int WN> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
+  constexpr int BM = 64 * MR, BN = 16 * NR * WN;
+  constexpr size_t lds = (size_t)BM * 34 * 4 + (size_t)3 * 16 * (BN + 4) * 4;
+  constexpr int NP = GPW == 0 ? 6 : 9;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_bf<MR, NR, GPW, WN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_bf<MR, NR, GPW, WN, NP>), dim3(gx, gy), dim3(256 * WN), lds, st, a);
+}
+template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
+  static bool run(hipStream_t, const LinArgs<real>&, unsigned, unsigned) { return false; }
+};
+template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
+  static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
+    if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
+    launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
+    return true;
+  }
+};
+
 // A/B hook (dqmc_set_option "linear_bkx"): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
 // 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
 static int g_linear_bkx = 3;
@@ -429,6 +694,7 @@ template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg
   const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
+  if (BfLaunch<real, MR, NR, GPW, WN>::run(st, a, gx, gy)) return;
   if (MR == 1 && WN == 1 && GPW != 0 && wide_chunks(a))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW != 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
   else

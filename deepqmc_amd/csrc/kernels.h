@@ -66,6 +66,7 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
 void set_linear_bkx(int v);
+void set_linear_bf(int v);          // 0: float32 MFMAs only; 1: float32 layers on the bf16 matrix pipe where that pays (kernel_linear.hip)
 void set_linear_f64_nr1(int v);
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----

@@ -260,3 +260,41 @@ def test_emu_conditioning_record(spec_fn, molname):
     det = cc[None, :K] * sign * np.exp(logabs - logabs.max(1, keepdims=True))
     p = det / det.sum(1, keepdims=True)
     np.testing.assert_allclose(eng.debug_read('kappa', B), (np.abs(p) * kap).sum(1), rtol=1e-9)
+
+
+def test_linear_layers_on_the_bf16_pipe_match_float64():
+    """Option 'linear_bf' = 1 (kernel_linear.hip: k_linear_bf, float32 operands split into three bf16 pieces, nine
+    products per K = 32 chunk): the Laplacian pass must stay within float32 accuracy of the float64 engine -- in fact it
+    rounds less often than the f32 MFMA chain -- and the value path (six products) must give the same signs."""
+    import torch
+    from deepqmc_amd.engine import Engine
+    from deepqmc_amd.hamil import MolecularHamiltonian
+    from deepqmc_amd.molecule import Molecule
+    from deepqmc_amd.params import init_params
+    from deepqmc_amd.spec import paulinet
+    from oracle import geom
+    from simt_util import emu_lib
+    from test_program_interp import make_walkers
+    spec = paulinet()
+    mol = Molecule.from_name('LiH')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=3, perturb_envelopes=0.1)
+    r = make_walkers(mol, h.n_elec, 12)
+    e64 = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    ref = e64.local_energy(torch.as_tensor(r.astype(np.float32).astype(np.float64)))[0].numpy()
+    s64, l64 = e64.wf_eval(torch.as_tensor(r.astype(np.float32).astype(np.float64)))
+    eng = Engine(spec, h, tree, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    eng.set_option('refine', 0)
+    eng.set_option('fused', 0)                     # the layered value path: k_linear / k_linear_bf with value-only rows
+    err = {}
+    try:
+        for bf in (0, 1):
+            eng.set_option('linear_bf', bf)
+            e = eng.local_energy(torch.as_tensor(r.astype(np.float32)))[0].numpy().astype(np.float64)
+            err[bf] = np.abs(e - ref) / np.maximum(1.0, np.abs(ref))
+            s, l = eng.wf_eval(torch.as_tensor(r.astype(np.float32)))
+            np.testing.assert_array_equal(s.numpy(), s64.numpy())
+            np.testing.assert_allclose(l.numpy(), l64.numpy(), rtol=2e-5, atol=2e-5)
+    finally:
+        eng.set_option('linear_bf', 0)             # (process-wide switch)
+    assert np.median(err[1]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 1e-7

@@ -9,6 +9,8 @@ h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
 wf = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cuda:0')
 params = wf.init(0, perturb_envelopes=0.05)
 eng = wf.engine(params); eng.set_option('refine', refine)
+for kv in filter(None, os.environ.get('DQMC_OPTS', '').split(',')):      # extra library options: DQMC_OPTS=linear_bf=0,multi_stream=0
+    eng.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 if os.environ.get('DQMC_SERIAL'):      # one stream: clean per-kernel counters
     eng.set_option('dual_stream', 0)
 smp = DecorrSampler(h, wf, length=30); st = smp.init(1, params, 4096)
