@@ -39,6 +39,7 @@ from deepqmc_amd.sampling import DecorrSampler  # noqa: E402
 from deepqmc_amd.wf import NeuralNetworkWaveFunction  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: v_mfma_f32_16x16x32_bf16 / 32x32x16, dense (no 2:1 sparsity)
 
 
 def _cpu_eloc_fns(molname, spec_name, dtype_name):
@@ -462,9 +463,11 @@ def main():
         rep = eng.timing_report()
         eng.timing(False)
         names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
-                 'fused_psi': 'k_fused2_value (LDS-resident psi evaluation, v_mfma_f32_16x16x4_f32)',
-                 'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + '
-                                  'determinants + accept, v_mfma_f32_16x16x4_f32)'}
+                 'fused_psi': 'k_fused2_value (LDS-resident psi evaluation; float32 layers as v_mfma_f32_16x16x32_bf16 x6 on '
+                              'three-piece bf16 splits, shallow layers v_mfma_f32_16x16x4_f32)',
+                 'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + determinants + '
+                                  'accept; float32 layers as v_mfma_f32_16x16x32_bf16 x6 on three-piece bf16 splits of the operands, '
+                                  'shallow layers v_mfma_f32_16x16x4_f32)'}
         cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
         dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
         lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
@@ -481,6 +484,14 @@ def main():
             'share_of_kernel_time': lin['ms'] / total_ms,
             'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items()},
         }
+        if dom.startswith('fused') and args.dtype == 'f32':
+            # `achieved` counts ALGORITHMIC float32 flops and `peak` is the float32 MFMA peak (the arithmetic the path
+            # delivers).  The fused kernel executes most of them on the bf16 pipe at six bf16 MFMA flops per float32 flop:
+            roofline['matrix_pipe'] = {
+                'note': 'float32 products as six bf16 MFMAs per 16x16x32 block (operands split into three bf16 pieces); '
+                        'executed bf16-pipe flops <= 6 x algorithmic',
+                'bf16_dense_peak_tflops': BF16_MFMA_PEAK_TFLOPS,
+                'executed_tflops_upper': 6 * achieved, 'pipe_frac_upper': 6 * achieved / BF16_MFMA_PEAK_TFLOPS}
 
     if rank == 0:
         out = {
