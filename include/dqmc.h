@@ -282,7 +282,11 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 32; "fused_chain" (0): second layers
  * of row-wise MLPs in the same wave as the first (measured slower); "fused_wg_per_cu" (4): LDS share a tile is planned for;
  * "fused_prio" (1): the co-resident tiles of a CU take turns at the highest issue priority, level by level, instead of the
- * hardware's oldest-wave-first order (2: unit by unit, 0: off); "dual_stream" (1): edge stream of the Laplacian pass on a
+ * hardware's oldest-wave-first order (2: unit by unit, 0: off); "fused_bf" (float32 contexts; 1: the float32 layers of the
+ * fused kernel whose pieces are whole octets wide run on the bf16 matrix pipe -- operands split into three bf16 pieces,
+ * six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, float32-class results; 2: only the layers deep enough to pay by
+ * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (0; process-wide): the same split with nine
+ * products for the per-op linear kernel (measured slower end to end, kept for its accuracy); "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
