@@ -89,3 +89,32 @@ def test_plan_variants_agree():
     np.testing.assert_array_equal(s2.numpy(), s0.numpy())
     np.testing.assert_allclose(l2.numpy(), l0.numpy(), rtol=1e-12, atol=1e-12)
     eng.set_option('fused', 1)
+
+
+@pytest.mark.parametrize('spec_fn,molname,wt', [(paulinet, 'LiH', 4), (ferminet, 'LiH', 2), (paulinet, 'H2O', 2)])
+def test_bf16_pipe_units_match_float64(spec_fn, molname, wt):
+    """Option 'fused_bf' (float32 contexts): the linear units of the fused kernel split their float32 operands into three
+    bf16 pieces and multiply them with six bf16 MFMAs per K = 32 chunk (kernel_fused2.hip: FusedBfUnit).  Against the
+    float64 oracle the result must be in the same accuracy class as the f32-MFMA units (option value 0), with identical
+    signs; a batch that leaves the last tile ragged, tiles with several row blocks per unit (FermiNet / H2O)."""
+    spec = spec_fn()
+    mol = Molecule.from_name(molname)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=7, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 13
+    r = make_walkers(mol, h.n_elec, B).astype(np.float32)
+    ref = Interp(eng.program, mol.charges, geom.F32_EPS).run(r.astype(np.float64), mol.coords.astype(np.float32).astype(np.float64), laplacian=False)
+    eng.set_option('fused_wt', wt)
+    eng.set_option('fused', 2)
+    err = {}
+    for bf in (0, 1, 2):
+        eng.set_option('fused_bf', bf)
+        s, l = eng.wf_eval(torch.as_tensor(r))
+        np.testing.assert_array_equal(s.numpy(), ref['sign'])
+        err[bf] = np.abs(l.numpy().astype(np.float64) - ref['log'])
+    # (a walker next to a node of psi carries 1e-4 .. 1e-3 in float32 whichever instructions multiply: compare the classes)
+    for bf in (1, 2):
+        assert np.median(err[bf]) < 3 * np.median(err[0]) + 2e-7, (bf, np.median(err[0]), np.median(err[bf]))
+        assert err[bf].max() < 5 * err[0].max() + 3e-5, (bf, err[0].max(), err[bf].max())
+    assert np.median(err[0]) < 1e-5

@@ -158,6 +158,41 @@ def test_device_rng_and_sampler_f32():
     assert np.abs(moved).max() > 0
 
 
+def test_bf16_pipe_sub_steps_against_f32_mfma_and_float64():
+    """The Metropolis hot loop at BASELINE size with its float32 layers on the bf16 matrix pipe (option 'fused_bf' 1, the
+    default: three-piece split, six bf16 MFMAs per block) and with v_mfma_f32_16x16x4_f32 (0): log|psi| of 4096 walkers
+    against the float64 engine must be in the same accuracy class (median, 99th percentile), signs bit-exact for every walker
+    whose float64 |psi| is not at a node, and a sampler run from the same state and noise must agree in its accept
+    decisions except where the float32 ratio sits within round-off of the uniform number."""
+    spec, mol, h, tree, eng, it = setup(paulinet, 'LiH', torch.float32)
+    e64 = Engine(spec, h, tree, dtype=torch.float64, device=DEV, norm_eps=geom.F32_EPS)
+    B = 4096
+    r0 = synthetic_walkers(h, B, seed=11).astype(np.float32)
+    s64, l64 = e64.wf_eval(torch.as_tensor(r0.astype(np.float64), device=DEV))
+    l64 = l64.cpu().numpy()
+    err, acc = {}, {}
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    noise = torch.randn(6, B, h.n_elec, 3, generator=gen).to(DEV)
+    unif = torch.rand(6, B, generator=gen).to(DEV)
+    try:
+        for bf in (0, 1):
+            eng.set_option('fused_bf', bf)
+            s, l = eng.wf_eval(torch.as_tensor(r0, device=DEV))
+            np.testing.assert_array_equal(s.cpu().numpy(), s64.cpu().numpy())
+            err[bf] = np.abs(l.cpu().numpy().astype(np.float64) - l64)
+            st = {'r': torch.as_tensor(r0, device=DEV).clone(), 'log': l.clone(), 'sign': s.clone(),
+                  'age': torch.zeros(B, dtype=torch.int32, device=DEV), 'tau': torch.full((1,), 0.2, dtype=torch.float32, device=DEV)}
+            out = eng.mcmc_steps(st, 6, seed=3, noise=noise, unif=unif, return_accept=True, target_acceptance=None)
+            acc[bf] = out[1].cpu().numpy() if isinstance(out, tuple) else None
+    finally:
+        eng.set_option('fused_bf', 1)
+    assert np.median(err[0]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 2e-7, (np.median(err[0]), np.median(err[1]))
+    assert np.quantile(err[1], 0.99) < 3 * np.quantile(err[0], 0.99) + 1e-5, (np.quantile(err[0], 0.99), np.quantile(err[1], 0.99))
+    if acc[0] is not None:
+        # the first sub-step starts from identical state: its decisions differ only for ratios within float32 round-off of u
+        assert (acc[0][0] != acc[1][0]).mean() < 2e-3
+
+
 def test_full_size_properties():
     """BASELINE size (4096 walkers): determinism, batch-split invariance, and fermionic
     antisymmetry (swapping two same-spin electrons flips the sign, keeps log|psi| and E_loc)."""
