@@ -407,20 +407,11 @@ template <int MA> struct FusedBfUnit<float, MA> {
       int ao[MA];
 #pragma unroll
       for (int x = 0; x < MA; ++x) ao[x] = base + (bc ? (mrow[x] & wtm1) : mrow[x]) * stride;
-      float an[MA][8];                                       // A octets (LDS) run one chunk ahead
-      {
-        const int o = l4 < K8 ? l4 : K8 - 1;
-#pragma unroll
-        for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
-      }
-      // chunks in pairs over two register sets (`nxt` and `alt`) that swap roles, so no set is ever copied: while
-      // chunk c multiplies from one set, chunk c + 1 is in flight into the other; as soon as the MFMAs of chunk c are
-      // issued its set is refilled with chunk c + 2 (or the first group of the next piece / of the wave's next unit)
-      auto next_octets = [&](int c_next) {
-        int o = c_next * 4 + l4;
+      auto octets = [&](int c_now, float (&av)[MA][8]) {
+        int o = c_now * 4 + l4;
         o = o < K8 ? o : K8 - 1;
 #pragma unroll
-        for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, an[x]);
+        for (int x = 0; x < MA; ++x) fused2_read_octet(smem, ao[x] + 8 * o, av[x]);
       };
       auto request = [&](BSet<float>& into, int c_next) {      // group of chunk c_next of this piece, or what follows the piece
         const bool own = c_next < NC || !last_piece;           // wave-uniform selects, then ONE unconditional load sequence
@@ -432,27 +423,21 @@ template <int MA> struct FusedBfUnit<float, MA> {
         BSet<float> alt;
         request(alt, c + 1);
         float ac[MA][8];
-#pragma unroll
-        for (int x = 0; x < MA; ++x)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ac[x][j] = an[x][j];
-        next_octets(c + 1);
+        octets(c, ac);
 #pragma unroll
         for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], nxt, acc[x][0], acc[x][1]);
         request(nxt, c + 2);
-#pragma unroll
-        for (int x = 0; x < MA; ++x)
-#pragma unroll
-          for (int j = 0; j < 8; ++j) ac[x][j] = an[x][j];
-        next_octets(c + 2);
+        octets(c + 1, ac);
 #pragma unroll
         for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], alt, acc[x][0], acc[x][1]);
       }
       if (c < NC) {                                            // odd last chunk: the one copy
         const BSet<float> cur = nxt;
         request(nxt, c + 1);
+        float ac[MA][8];
+        octets(c, ac);
 #pragma unroll
-        for (int x = 0; x < MA; ++x) fused2_bf_chunk(an[x], cur, acc[x][0], acc[x][1]);
+        for (int x = 0; x < MA; ++x) fused2_bf_chunk(ac[x], cur, acc[x][0], acc[x][1]);
       }
       c0 += NC;
     }
