@@ -237,6 +237,37 @@ struct Engine : dqmc_ctx {
   // 6.3 ms step on LiH / PauliNet against the synchronous path, measured in one call)
   int twin_full_budget = 1;      // the twin's activation workspace may be as large as this context's (option "twin_full_budget")
   int refine_ahead = 0;
+  // option "pass_graph" (1): a forward-Laplacian pass that fits one workspace chunk is captured ONCE per (buffers, batch
+  // size) into a hipGraph -- its ~40 launches, and the event records / waits that spread them over four streams -- and
+  // replayed with one hipGraphLaunch per call.  The pass is launch-bound at the batch sizes it is used for (LiH, 4096
+  // walkers: 140 us of a 1.7 ms float32 pass are gaps between kernels, 206 of the 690 us of the float64 twin's pass over
+  // ~190 walkers: profiles/r03_eloc_pass_timeline.txt).  The first pass at a batch size runs eagerly (workspace, streams,
+  // events, kernel attributes get created), the second one is captured on a stream of the context's own (the caller's
+  // may be the legacy default stream, which cannot be captured) fenced by two events.  Everything a kernel of the pass
+  // receives by value is a function of the key; what is not (the score threshold) is read from device memory.
+  int pass_graph = 1;
+  bool graph_broken = false;
+  hipStream_t st_g = nullptr;
+  hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
+  struct PassGraph { const void* p[7]; int B; bool flag; const void* ws; const void* flagp; uint64_t epoch, used; void* exec; };
+  std::vector<PassGraph> pgraphs;
+  uint64_t graph_epoch = 0, graph_clock = 0, graph_captures = 0, graph_hits = 0;
+  std::vector<int> graph_warm;          // batch sizes that have run eagerly
+  double* d_thresh = nullptr;           // device copy of refine_thresh (read by k_final: graphs must not bake it in)
+  double thresh_uploaded = -1.0;
+  bool graphs_active() const {
+#if defined(__HIPCC__)
+    return pass_graph && !graph_broken && !timing && !fused_dbg && ph_n == 0 && ecp_n_nl == 0;
+#else
+    return false;                         // (the SIMT emulation harness has no graph API)
+#endif
+  }
+  void drop_graphs() {
+#if defined(__HIPCC__)
+    for (auto& g : pgraphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
+#endif
+    pgraphs.clear();
+  }
   int ahead_cap = 0, ahead_pos = 0;
   int ahead_hist[4] = {0, 0, 0, 0};
   int calls_since_probe = -1;    // -1: never probed
@@ -267,6 +298,11 @@ struct Engine : dqmc_ctx {
 
   ~Engine() override {
     delete twin;
+    drop_graphs();
+    if (st_g) (void)hipStreamDestroy(st_g);
+    if (ev_g0) (void)hipEventDestroy(ev_g0);
+    if (ev_g1) (void)hipEventDestroy(ev_g1);
+    if (d_thresh) (void)hipFree(d_thresh);
     if (st2) (void)hipStreamDestroy(st2);
     for (auto x : st_extra) if (x) (void)hipStreamDestroy(x);
     for (auto e : ms_events) if (e) (void)hipEventDestroy(e);
@@ -582,6 +618,7 @@ struct Engine : dqmc_ctx {
 
   int set_weights(const double* w, size_t n) override {
     if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
+    ++graph_epoch;
     wtmp.resize(n);
     for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
     if (sizeof(real) == 4) {
@@ -603,6 +640,8 @@ struct Engine : dqmc_ctx {
       twin_opts.emplace_back(s.substr(5), value);
       return twin ? twin->option(s.c_str() + 5, value) : DQMC_OK;
     }
+    ++graph_epoch;                             // (any switch may change what a captured pass would launch)
+    if (s == "pass_graph") { pass_graph = value; if (!value) drop_graphs(); if (twin) twin->option("pass_graph", value); twin_opts.emplace_back(s, value); return DQMC_OK; }
     if (s == "fused") { fused_enabled = value; return DQMC_OK; }
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ_req = value; return DQMC_OK; }
@@ -1316,7 +1355,13 @@ struct Engine : dqmc_ctx {
     const size_t per = ws_bytes_per_walker(TP);
     long chunk = per ? (long)(ws_budget / per) : B;
     if (chunk < 1) chunk = 1;
-    if (chunk >= B) return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
+    if (chunk >= B) {
+#if defined(__HIPCC__)
+      if (laplacian && graphs_active())
+        return run_graphed(r, R, B, logpsi, sign, e_loc, stats, grad);
+#endif
+      return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
+    }
     for (int b0 = 0; b0 < B; b0 += (int)chunk) {
       const int nb = (B - b0) < chunk ? (B - b0) : (int)chunk;
       const int rc = run_chunk(r + (size_t)b0 * N * 3, R, nb, laplacian, logpsi ? logpsi + b0 : nullptr, sign ? sign + b0 : nullptr,
@@ -1325,6 +1370,75 @@ struct Engine : dqmc_ctx {
     }
     return DQMC_OK;
   }
+
+#if defined(__HIPCC__)
+  // one forward-Laplacian pass through its captured graph (see pass_graph above)
+  int run_graphed(const real* r, const real* R, int B, real* logpsi, int32_t* sign, real* e_loc, real* stats, real* grad) {
+    if (std::find(graph_warm.begin(), graph_warm.end(), B) == graph_warm.end()) {
+      graph_warm.push_back(B);
+      return run_chunk(r, R, B, true, logpsi, sign, e_loc, stats, B, grad, 0);
+    }
+    const void* key[7] = {r, R, logpsi, sign, e_loc, stats, grad};
+    PassGraph* hit = nullptr;
+    for (auto& g : pgraphs)
+      if (g.B == B && g.flag == flag_on && g.ws == d_ws && g.flagp == d_flag && g.epoch == graph_epoch && !memcmp(g.p, key, sizeof(key))) hit = &g;
+    if (!hit) {
+      // a caller that hands over different buffers on every call would pay a capture (milliseconds) per pass: once captures
+      // clearly outnumber replays, the context goes back to eager launches for good
+      if (graph_captures >= 8 && graph_hits < graph_captures) {
+        graph_broken = true;
+        drop_graphs();
+        return run_chunk(r, R, B, true, logpsi, sign, e_loc, stats, B, grad, 0);
+      }
+      ++graph_captures;
+      if (!st_g) {
+        HIP_TRY(hipStreamCreateWithFlags(&st_g, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_g0, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_g1, hipEventDisableTiming));
+      }
+      hipStream_t caller = st;
+      hipGraph_t graph = nullptr;
+      if (hipStreamBeginCapture(st_g, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        graph_broken = true;
+        return run_chunk(r, R, B, true, logpsi, sign, e_loc, stats, B, grad, 0);
+      }
+      st = st_g;                                   // (run_chunk launches on `st` and forks its side streams from it)
+      const int rc = run_chunk(r, R, B, true, logpsi, sign, e_loc, stats, B, grad, 0);
+      st = caller;
+      const hipError_t ee = hipStreamEndCapture(st_g, &graph);
+      hipGraphExec_t exec = nullptr;
+      if (rc || ee != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        graph_broken = true;                       // this program / runtime does not capture: eager from now on
+        if (rc) return rc;
+        return run_chunk(r, R, B, true, logpsi, sign, e_loc, stats, B, grad, 0);
+      }
+      (void)hipGraphDestroy(graph);
+      if (pgraphs.size() >= 12) {                  // (a handful of batch sizes x output buffers; evict the least recently used)
+        size_t old = 0;
+        for (size_t k = 1; k < pgraphs.size(); ++k) if (pgraphs[k].used < pgraphs[old].used) old = k;
+        if (pgraphs[old].exec) (void)hipGraphExecDestroy((hipGraphExec_t)pgraphs[old].exec);
+        pgraphs.erase(pgraphs.begin() + (long)old);
+      }
+      PassGraph g{};
+      memcpy(g.p, key, sizeof(key));
+      g.B = B; g.flag = flag_on; g.ws = d_ws; g.flagp = d_flag; g.epoch = graph_epoch; g.exec = exec;
+      pgraphs.push_back(g);
+      hit = &pgraphs.back();
+    }
+    else ++graph_hits;
+    hit->used = ++graph_clock;
+    HIP_TRY(hipEventRecord(ev_g0, st));
+    HIP_TRY(hipStreamWaitEvent(st_g, ev_g0, 0));
+    HIP_TRY(hipGraphLaunch((hipGraphExec_t)hit->exec, st_g));
+    HIP_TRY(hipEventRecord(ev_g1, st_g));
+    HIP_TRY(hipStreamWaitEvent(st, ev_g1, 0));
+    { dqmc::LaneInfo li; li.N = N; li.T = 3 * N + 2; li.TP = (li.T + 15) / 16 * 16; last_TP = li.TP; }
+    return DQMC_OK;
+  }
+#endif
 
   int run_chunk(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
                 long stats_ld, real* grad, int b_offset) {
@@ -1597,7 +1711,7 @@ struct Engine : dqmc_ctx {
           a.phq = phq;
           if (laplacian) { a.cond = reinterpret_cast<double*>(d_ws + off_cond); a.kappa_out = reinterpret_cast<double*>(d_ws + off_kappa); }
           if (flag_on && laplacian) {
-            a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.b_offset = b_offset;
+            a.flag_count = d_flag; a.flag_idx = d_flag + 1; a.refine_thresh = refine_thresh; a.thresh_dev = d_thresh; a.b_offset = b_offset;
             a.score_out = d_score;
           }
           t_begin("final", 0);
@@ -1768,6 +1882,12 @@ struct Engine : dqmc_ctx {
         return refine_listed(r, R, B, B, e_loc, stats, grad, logpsi, sign);
       }
       HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int32_t), st));
+      if (!d_thresh) HIP_TRY(hipMalloc((void**)&d_thresh, sizeof(double)));
+      if (thresh_uploaded != refine_thresh) {      // (k_final reads the threshold from here: a captured pass must follow a re-calibration)
+        HIP_TRY(hipMemcpyAsync(d_thresh, &refine_thresh, sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        thresh_uploaded = refine_thresh;
+      }
       flag_on = true;
       rc = pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
       flag_on = false;
@@ -1823,6 +1943,17 @@ struct Engine : dqmc_ctx {
           rc = upload_list(iota);
           if (rc) return rc;
           n = B;
+        }
+        if (graphs_active() && n < B) {
+          // the twin's pass replays a captured graph per batch size: round the count up to a multiple of 64 (the surplus
+          // rows re-evaluate the first flagged walker and are not written back: k_refine_gather / scatter read the count
+          // on the device), so that a handful of sizes serve every step
+          int n_pad = (n + 63) / 64 * 64;
+          if (n_pad > B) n_pad = B;
+          rc = refine_listed(r, R, B, n_pad, e_loc, stats, grad, logpsi, sign, d_flag);
+          last_refined = n;
+          HIP_TRY(hipGetLastError());
+          return rc;
         }
         rc = refine_listed(r, R, B, n, e_loc, stats, grad, logpsi, sign);
         HIP_TRY(hipGetLastError());

@@ -227,6 +227,7 @@ struct FinalArgs {
   int32_t* flag_count;
   int32_t* flag_idx;
   double refine_thresh;
+  const double* thresh_dev;  // when set: the threshold is read from here (a replayed hipGraph of the pass follows re-calibrations)
   int b_offset;
   const double* cond;     // [B][K] conditioning record of the determinant kernels, or nullptr
   double* score_out;

@@ -952,7 +952,7 @@ __global__ void __launch_bounds__(256) k_final(const FinalArgs a) {
     // float32 error predictor (engine.hip: lap_refined): node cancellation x conditioning of the determinants
     const double score = (fabs(lap) + qf2) / fmax(1.0, fabs(e_loc)) * fmax(1.0, kappa);
     if (a.score_out) a.score_out[a.b_offset + b] = score;
-    if (!(score <= a.refine_thresh)) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;     // NaN / inf land here too
+    if (!(score <= (a.thresh_dev ? *a.thresh_dev : a.refine_thresh))) a.flag_idx[atomicAdd(a.flag_count, 1)] = a.b_offset + b;     // NaN / inf land here too
   }
   if (a.kappa_out) a.kappa_out[b] = kappa;
   if (a.stats) {

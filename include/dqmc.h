@@ -288,6 +288,11 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (0; process-wide): the same split with nine
  * products for the per-op linear kernel (measured slower end to end, kept for its accuracy); "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
+ * "pass_graph" (1): a forward-Laplacian pass that fits one workspace chunk is captured into a hipGraph on its second call
+ * with the same buffers and batch size and replayed afterwards (one hipGraphLaunch instead of ~40 launches and their
+ * cross-stream events; contexts without a non-local ECP / pseudo-Hamiltonian, timing off); the float64 twin's batch is
+ * rounded up to a multiple of 64 walkers so that a few graphs serve every call; a context whose captures outnumber its
+ * replays (callers passing fresh buffers every time) returns to eager launches; 0: always eager;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
  * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set),

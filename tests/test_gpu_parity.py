@@ -193,6 +193,33 @@ def test_bf16_pipe_sub_steps_against_f32_mfma_and_float64():
         assert (acc[0][0] != acc[1][0]).mean() < 2e-3
 
 
+def test_captured_pass_replays_bit_exactly():
+    """Option 'pass_graph' (default 1): the forward-Laplacian pass of a batch size is launched eagerly once, captured into a
+    hipGraph on its second call and replayed afterwards -- the float32 pass and the float64 twin's pass over the flagged
+    walkers (count rounded up to a multiple of 64, the surplus rows not written back).  Every call must give bit-identical
+    local energies to the eager launches ('pass_graph' 0), for the same walkers and for walkers that change between calls,
+    and the count of refined walkers must be the flagged count, not the padded one."""
+    spec, mol, h, tree, eng, it = setup(paulinet, 'LiH', torch.float32)
+    B = 1536
+    rs = [torch.as_tensor(synthetic_walkers(h, B, seed=20 + k).astype(np.float32), device=DEV) for k in range(3)]
+    seq = [0, 0, 0, 1, 2, 1, 0, 2]
+    out = {}
+    for mode in (0, 1):
+        eng.set_option('pass_graph', mode)
+        eng.set_option('refine_probe', 0)              # (fixed threshold: both runs flag the same walkers)
+        res, ref = [], []
+        for k in seq:
+            e, _ = eng.local_energy(rs[k])
+            res.append(e.clone()); ref.append(eng.last_refined())
+        out[mode] = (res, ref)
+    eng.set_option('pass_graph', 1)
+    for a, b in zip(out[0][0], out[1][0]):
+        assert torch.equal(a, b)
+    assert out[0][1] == out[1][1] and min(out[1][1]) > 0 and max(out[1][1]) < B // 2
+    for k, e in zip(seq, out[1][0]):                   # the same walkers give the same energies whenever they come back
+        assert torch.equal(e, out[1][0][seq.index(k)])
+
+
 def test_full_size_properties():
     """BASELINE size (4096 walkers): determinism, batch-split invariance, and fermionic
     antisymmetry (swapping two same-spin electrons flips the sign, keeps log|psi| and E_loc)."""
