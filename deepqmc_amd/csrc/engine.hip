@@ -262,6 +262,14 @@ struct Engine : dqmc_ctx {
     return false;                         // (the SIMT emulation harness has no graph API)
 #endif
   }
+  // ... and only passes that are launch-bound: up to 2 GiB of activations per pass (LiH / PauliNet: 4096 walkers in
+  // float32, the twin's few hundred in float64).  The passes of the larger systems run for milliseconds per kernel: a
+  // replay gains nothing there, and rounding the twin's batch up would cost real work (benzene, 87 flagged walkers -> 128:
+  // 266 -> 338 ms per step when it was tried)
+  bool graph_fits(int B) const {
+    const int TP = (3 * N + 2 + 15) / 16 * 16;
+    return graphs_active() && (double)ws_bytes_per_walker(TP) * (double)B <= 2147483648.0;
+  }
   void drop_graphs() {
 #if defined(__HIPCC__)
     for (auto& g : pgraphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
@@ -1357,7 +1365,7 @@ struct Engine : dqmc_ctx {
     if (chunk < 1) chunk = 1;
     if (chunk >= B) {
 #if defined(__HIPCC__)
-      if (laplacian && graphs_active())
+      if (laplacian && graph_fits(B))
         return run_graphed(r, R, B, logpsi, sign, e_loc, stats, grad);
 #endif
       return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
@@ -1944,7 +1952,7 @@ struct Engine : dqmc_ctx {
           if (rc) return rc;
           n = B;
         }
-        if (graphs_active() && n < B) {
+        if (n < B && static_cast<Engine<double>*>(twin)->graph_fits((n + 63) / 64 * 64)) {
           // the twin's pass replays a captured graph per batch size: round the count up to a multiple of 64 (the surplus
           // rows re-evaluate the first flagged walker and are not written back: k_refine_gather / scatter read the count
           // on the device), so that a handful of sizes serve every step
