@@ -272,6 +272,7 @@ struct Engine : dqmc_ctx {
   }
   void drop_graphs() {
 #if defined(__HIPCC__)
+    if (st_g && !pgraphs.empty()) (void)hipStreamSynchronize(st_g);      // (a replay may still be running)
     for (auto& g : pgraphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
 #endif
     pgraphs.clear();
@@ -2051,6 +2052,7 @@ struct Engine : dqmc_ctx {
   //   nl [n_nuc][n_l][2][n_t_nl] channels l = 0..n_l-1; nuclei whose block is all zero have no non-local part
   int set_ecp(int n_t_loc, const double* loc, int n_l, int n_t_nl, const double* nl) override {
     if (n_t_loc < 0 || n_l < 0 || n_t_nl < 0) return fail(DQMC_E_ARG, "negative ECP table size");
+    ++graph_epoch; drop_graphs();          // (captured passes hold the table pointers)
     if (ph_n && nl && n_l > 0 && n_t_nl > 0) return fail(DQMC_E_ARG, "a pseudo-Hamiltonian and a non-local Gaussian ECP cannot both be set");
     HIP_TRY(hipStreamSynchronize(st));
     if (d_ecp_loc) { HIP_TRY(hipFree(d_ecp_loc)); d_ecp_loc = nullptr; }
@@ -2095,6 +2097,7 @@ struct Engine : dqmc_ctx {
   // linspace(0, r_max, n_grid), one row per nucleus; rows of nuclei with mask 0 are ignored.  An all-zero mask
   // (or n_grid 0) switches the PH off.
   int set_ph(int n_grid, double r_max, const double* rv_loc, const double* rv_l2, const int32_t* mask) override {
+    ++graph_epoch; drop_graphs();
     HIP_TRY(hipStreamSynchronize(st));
     if (d_ph_loc) { HIP_TRY(hipFree(d_ph_loc)); d_ph_loc = nullptr; }
     if (d_ph_l2) { HIP_TRY(hipFree(d_ph_l2)); d_ph_l2 = nullptr; }
