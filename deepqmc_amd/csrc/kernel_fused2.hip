@@ -16,6 +16,11 @@
 //     as an affine function (broadcast pieces: m & (WT-1)), and stride = width + 2 keeps the 16 rows x 2 k
 //     of a half-wave fragment read on 32 distinct banks.
 //
+//   * float32 layers run on the bf16 matrix pipe (FusedBfUnit below): gfx950 multiplies float32 matrices at the VALU rate
+//     and bf16 matrices 16 x faster; a float is exactly the sum of three bf16 numbers, so six bf16 MFMAs per
+//     16 x 16 x 32 block (96 matrix-pipe cycles instead of 256) give a float32-class product sum.  Weights are pre-split
+//     on the host, activations are split in registers after the LDS read.
+//
 // The SQ counters and clock stamps of the first fused kernel (profiles/r01_pmc_sq_counters_fused_wt4.json,
 // DESIGN.md section 4) showed ~3.4 k cycles of such setup per unit against ~1.2 k cycles of MFMA work.
 #include "common.h"
