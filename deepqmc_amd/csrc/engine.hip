@@ -1844,7 +1844,7 @@ struct Engine : dqmc_ctx {
     int mx = 0;
     for (int k = 0; k < 4; ++k) mx = ahead_hist[k] > mx ? ahead_hist[k] : mx;
     const long step = B >= 512 ? 32 : 8;
-    long cap = ((long)mx * 3 / 2 + step - 1) / step * step;
+    long cap = refine_ahead >= 2 ? ((long)mx + mx / 8 + 63) / 64 * 64 : ((long)mx * 3 / 2 + step - 1) / step * step;      // (2: tight capacity in the steps the captured twin passes use)
     if (cap < step) cap = step;
     ahead_cap = (2 * cap > B) ? 0 : (int)cap;        // a large share of the batch: the plain path decides (direct float64 mode)
   }
