@@ -424,8 +424,10 @@ __device__ __forceinline__ void sched_fence() {
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// (second launch bound = waves per SIMD the register allocation must leave room for: the 48-row x 64-column wave tiles of
+// the 48-lane groups need 172 registers unconstrained -- two waves per SIMD -- and fit three with 168)
 template <int MR, int NR, int GPW, int WN, int NP>
-__global__ void __launch_bounds__(256 * WN) k_linear_bf(const LinArgs<float> a) {
+__global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_linear_bf(const LinArgs<float> a) {
   typedef float real;
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 32;
@@ -633,16 +635,18 @@ __global__ void __launch_bounds__(256 * WN) k_linear_bf(const LinArgs<float> a) 
   lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink);
 }
 
-// "linear_bf" (dqmc_set_option): 0 = float32 MFMAs everywhere (default), 1 = float32 layers of sufficient depth on the
-// bf16 pipe.  OFF by default: measured SLOWER end to end (MI355X, same-call A/B, ms per step): LiH / PauliNet 5.46 vs
-// 5.46, N2 / FermiNet 52.9 -> 54.4, benzene / Psiformer (256 walkers) 264 -> 284, although the matrix pipe does 44 % less
-// work.  What the counters say for the 128 x 128 tiles of LiH (K = 192): 7 VALU instructions per MFMA -- the forward-
-// Laplacian epilogue (activation derivatives, 64-bit addressing of pre / residual / destination per element) plus the
-// operand splits now outweigh the MFMAs (12 k VALU cycles against 6.9 k matrix-pipe cycles per wave), LDS bank conflicts
-// on a third of the LDS cycles, and 116 registers against 78 (2 instead of 3 workgroups per CU); the taller tiles of
-// the larger systems lose a wave per SIMD (172 against 148 registers).  What it does buy is accuracy: the nine-product
-// sum rounds less often than the f32 MFMA chain (refined walkers 4.3 % -> 4.0 % on LiH, 5.5 % -> 4.9 % on N2).
-static int g_linear_bf = 0;
+// "linear_bf" (dqmc_set_option): 0 = float32 MFMAs everywhere, 1 = every float32 layer of sufficient depth on the bf16
+// pipe, 2 (default) = only the Laplacian tiles of the 48-lane groups (11-15 electrons), the one place where it measured
+// FASTER.  Same-call A/Bs on the MI355X, ms per step, value 1 against 0: LiH / PauliNet 5.46 vs 5.46, N2 / FermiNet
+// 52.9 -> 54.4, benzene / Psiformer (256 walkers) 264 -> 284, although the matrix pipe does 44 % less work.  What the
+// counters say for the 128 x 128 tiles of LiH (K = 192): 7 VALU instructions per MFMA -- the forward-Laplacian epilogue
+// plus the operand splits outweigh the MFMAs (12 k VALU cycles against 6.9 k matrix-pipe cycles per wave), LDS bank
+// conflicts on a third of the LDS cycles, and 116 registers against 78 (2 instead of 3 workgroups per CU).  The N2 tiles
+// (K = 256 .. 768, 133 TF/s = 85 % of the float32 MFMA peak with f32 MFMAs) needed 172 registers -- two waves per SIMD,
+// 3.12 against 2.71 ms per launch; held to 168 (three waves) they come out ahead: N2 53.1 -> 52.1 ms per step with value
+// 2, helped by the accuracy of the nine-product sum, which rounds less often than the f32 MFMA chain (refined walkers
+// 5.4 % -> 3.9 % on N2; 4.3 % -> 4.0 % on LiH with value 1).  The value-row tiles stay slower with the split (63 -> 68 us).
+static int g_linear_bf = 2;
 void set_linear_bf(int v) { g_linear_bf = v; }
 // a layer goes to the bf16 pipe when its chunks of 32 k (NP MFMAs of 16 cycles per block) cost less than its k-steps of
 // 4 (one MFMA of 32 cycles): pieces of a few k would multiply mostly padding
@@ -668,6 +672,7 @@ template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
 template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
   static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
     if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
+    if (g_linear_bf == 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
     launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
     return true;
   }

@@ -285,8 +285,9 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * hardware's oldest-wave-first order (2: unit by unit, 0: off); "fused_bf" (float32 contexts; 1: the float32 layers of the
  * fused kernel whose pieces are whole octets wide run on the bf16 matrix pipe -- operands split into three bf16 pieces,
  * six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, float32-class results; 2: only the layers deep enough to pay by
- * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (0; process-wide): the same split with nine
- * products for the per-op linear kernel (measured slower end to end, kept for its accuracy); "dual_stream" (1): edge stream of the Laplacian pass on a
+ * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (2; process-wide): the same split with nine
+ * products for the per-op linear kernel -- 2: only the Laplacian tiles of the 48-lane groups (11-15 electrons), where it is
+ * faster; 1: every layer deep enough (measured slower elsewhere); 0: never; "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
  * "pass_graph" (1): a forward-Laplacian pass that fits one workspace chunk is captured into a hipGraph on its second call
  * with the same buffers and batch size and replayed afterwards (one hipGraphLaunch instead of ~40 launches and their

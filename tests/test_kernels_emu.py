@@ -296,5 +296,5 @@ def test_linear_layers_on_the_bf16_pipe_match_float64():
             np.testing.assert_array_equal(s.numpy(), s64.numpy())
             np.testing.assert_allclose(l.numpy(), l64.numpy(), rtol=2e-5, atol=2e-5)
     finally:
-        eng.set_option('linear_bf', 0)             # (process-wide switch)
+        eng.set_option('linear_bf', 2)             # (process-wide switch: back to the default)
     assert np.median(err[1]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 1e-7
