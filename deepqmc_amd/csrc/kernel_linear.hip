@@ -51,6 +51,31 @@ template <typename real> __device__ __forceinline__ void act_derivs(int act, rea
   }
 }
 
+// Row tile / column tile of the calling workgroup.  A layer wider than the column tile launches gy > 1 column tiles per row
+// tile, and each of them streams the same A rows; in plain (x, y) order those workgroups are gx dispatches apart and land on
+// different XCDs (block b runs on XCD b % 8, each XCD has its own L2), so A is fetched from HBM gy times -- N2 / FermiNet,
+// 256-wide layers with 64-column tiles: 11 GB per launch, the launch is HBM-bound at 4 TB/s.  The remap puts the gy column
+// tiles of a row tile on ONE XCD, eight dispatches apart, so they run together and share the rows through that XCD's L2.
+// Bijective: the first (gx / 8) * 8 row tiles are dealt out as described, the remainder keeps a plain order.
+struct TileId { int bx, by; };
+__device__ __forceinline__ TileId tile_of_block() {
+  const int gx = (int)gridDim.x, gy = (int)gridDim.y;
+  TileId t{(int)blockIdx.x, (int)blockIdx.y};
+  if (gy == 1) return t;
+  const int b = (int)blockIdx.y * gx + (int)blockIdx.x;      // dispatch order
+  const int full = gx >> 3, region = full * 8 * gy;
+  if (b < region) {
+    const int xcd = b & 7, s_ = b >> 3;
+    t.by = s_ % gy;
+    t.bx = (s_ / gy) * 8 + xcd;
+  } else {
+    const int r = b - region;
+    t.by = r % gy;
+    t.bx = full * 8 + r / gy;
+  }
+  return t;
+}
+
 template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
 
 // Where the epilogue puts its results.  HbmSink: the layer's output buffer (+ residual).  LdsSink: the hidden tile of a
@@ -83,7 +108,7 @@ template <typename real> struct LdsSink {
 // `sink`.  MR x NR accumulator tiles; wave `wm` of the workgroup's M stack; col_w0 = first column of the wave's tile.
 template <typename real, int MR, int NR, int GPW, typename Sink>
 __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[MR][NR], const LinArgs<real>& a, const real* bias, int act,
-                                             int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink) {
+                                             int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink, int bx) {
   constexpr bool HALF = GPW < 0;
   constexpr int GB = GPW > 0 ? MR / GPW : 1;
   constexpr int BM = 64 * MR;
@@ -97,7 +122,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
       bool g_ok[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const int g = ((blockIdx.x * 4 + wm) * MR + i) * 2 + h;
+        const int g = ((bx * 4 + wm) * MR + i) * 2 + h;
         g_ok[h] = g < n_groups;
         sink.group(h, g_ok[h] ? g : 0);
       }
@@ -139,7 +164,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
   } else if (GPW > 0) {
 #pragma unroll
     for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
-      const int g = (blockIdx.x * 4 + wm) * GPW + gj;
+      const int g = (bx * 4 + wm) * GPW + gj;
       const bool g_ok = g < n_groups;        // wave-uniform
       const int b = (g_ok ? g : 0) / a.nrows;
       sink.group(0, g_ok ? g : 0);
@@ -198,7 +223,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int tile_row = wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
-        const int m = blockIdx.x * BM + tile_row;
+        const int m = bx * BM + tile_row;
         const bool m_ok = m < n_groups;
         const int b = (m_ok ? m : 0) / a.nrows;
         sink.group(0, m_ok ? m : 0);
@@ -255,7 +280,9 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int n_groups = a.B * a.nrows;            // (walker,row) groups == value-mode rows
-  const int col_blk0 = blockIdx.y * BN;
+  const TileId tile = tile_of_block();
+  const int bx = tile.bx;
+  const int col_blk0 = tile.by * BN;
 
   // ---- per-thread A rows ----
   int a_row[APT];         // row inside the tile
@@ -268,14 +295,14 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
     int g, t;
     if (HALF) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
-      g = ((blockIdx.x * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
+      g = ((bx * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
       t = row & 7;
     } else if (GPW > 0) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
-      g = (blockIdx.x * 4 + w) * GPW + rb / GB;
+      g = (bx * 4 + w) * GPW + rb / GB;
       t = (rb % GB) * 16 + (row & 15);
     } else {
-      g = blockIdx.x * BM + row;
+      g = bx * BM + row;
       t = 0;
     }
     a_g[j] = g < n_groups ? g : -1;
@@ -363,13 +390,13 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 
   if (!CHAIN) {
     HbmSink<real> sink(a);
-    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink);
+    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx);
     return;
   }
   // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there ----
   {
     LdsSink<real> hsink{Hs, HS};
-    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink);
+    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink, bx);
   }
   acc_t acc2[MR][NR2];
 #pragma unroll
@@ -405,7 +432,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
     }
   }
   HbmSink<real> sink(a);
-  lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink);
+  lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink, bx);
 }
 
 // ---- float32 layers on the bf16 matrix pipe (common.h: "float32 products on the bf16 matrix pipe") ----
@@ -446,7 +473,9 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
   const int n_groups = a.B * a.nrows;
-  const int col_blk0 = blockIdx.y * BN;
+  const TileId tile = tile_of_block();
+  const int bx = tile.bx;
+  const int col_blk0 = tile.by * BN;
   const int kg = lane >> 4, l15 = lane & 15;
 
   int a_row[APT], a_g[APT], a_t[APT];
@@ -458,14 +487,14 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
     int g, t;
     if (HALF) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
-      g = ((blockIdx.x * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
+      g = ((bx * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
       t = row & 7;
     } else if (GPW > 0) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
-      g = (blockIdx.x * 4 + w) * GPW + rb / GB;
+      g = (bx * 4 + w) * GPW + rb / GB;
       t = (rb % GB) * 16 + (row & 15);
     } else {
-      g = blockIdx.x * BM + row;
+      g = bx * BM + row;
       t = 0;
     }
     a_g[j] = g < n_groups ? g : -1;
@@ -632,7 +661,7 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
     }
   }
   HbmSink<real> sink(a);
-  lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink);
+  lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx);
 }
 
 // "linear_bf" (dqmc_set_option): 0 = float32 MFMAs everywhere, 1 = every float32 layer of sufficient depth on the bf16

@@ -298,3 +298,16 @@ def test_linear_layers_on_the_bf16_pipe_match_float64():
     finally:
         eng.set_option('linear_bf', 2)             # (process-wide switch: back to the default)
     assert np.median(err[1]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 1e-7
+
+
+def test_emu_column_tiles_share_an_xcd_mapping():
+    """k_linear deals the column tiles of a row tile to one XCD (kernel_linear.hip: tile_of_block -- block b runs on XCD
+    b % 8, so tiles 8 dispatches apart share an L2 and the A rows are fetched once).  The remap must be a bijection of
+    (row tile, column tile): FermiNet's 256-wide layers in float64 are 8 column tiles of 32, and 9 walkers x 4 electrons are
+    9 row tiles -- 8 of them in the swizzled region, one in the plain remainder."""
+    B = 9
+    spec, mol, h, eng, r, it = _setup(ferminet, 'LiH', torch.float64, B, seed=2)
+    ref = it.run(r, mol.coords, laplacian=True)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-9, atol=1e-9)
