@@ -203,6 +203,8 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (dqmc_set_option), repeatable')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
     ap.add_argument('--min-seconds', type=float, default=10.0, help='steady-state time the timed blocks must cover')
+    ap.add_argument('--torch-reduce', action='store_true', help='reduce the energy statistics through torch.distributed on the host '
+                    '(default: one ncclAllGather inside the library on the context\'s stream)')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
                     'launch / shard / reduce path without a GPU; the numbers mean nothing)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='internal: print the cpu_baseline JSON object and exit')
@@ -296,7 +298,7 @@ def main():
         assert n == hi - lo
         return synthetic_walkers(hamil_, B * world, seed=seed)[lo:hi]
 
-    sampler = DecorrSampler(hamil, wf, length=args.n_sub, sample_initializer=shard_initializer)
+    sampler = DecorrSampler(hamil, wf, length=args.n_sub, sample_initializer=shard_initializer, in_place=not args.overlap)
     state = sampler.init(1000, params, B)
     loc_ene = hamil.local_energy(wf)
     if args.refine >= 0:
@@ -314,7 +316,34 @@ def main():
             for p_ in params_s:
                 wf.engine(p_).set_option('refine', args.refine)
         ones = torch.ones(1, S, B, dtype=torch.float64, device=device)
-    n_ranks_seen = len(parallel.all_gather_records(np.zeros(7), device if not args.emulated else 'cpu'))   # one real collective
+    # Energy reduction: inside the library -- record + ONE ncclAllGather on the context's stream over an RCCL
+    # communicator of the library's own + one D2H of the gathered records (dqmc_energy_stats_allgather).  The host path
+    # (record D2H -> torch.distributed.all_gather -> merge) remains for the emulated test harness and as the fallback if the
+    # communicator cannot be created; the JSON line says which one ran (`config.reduction`).
+    comm = None
+    if not args.emulated and not args.torch_reduce:
+        try:
+            comm = parallel.RcclCommunicator(rank, world, device)
+        except Exception as exc:       # noqa: BLE001 -- whatever RCCL / ctypes raises: report and fall back
+            log(f'in-library RCCL communicator unavailable ({exc!r}); reducing through torch.distributed')
+    if world > 1:                      # every rank must take the same path
+        ok = torch.tensor([1 if comm is not None or args.emulated or args.torch_reduce else 0], dtype=torch.int32,
+                          device=device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+
+    def reduce_stats(engine, e):
+        if comm is not None:
+            return parallel.energy_stats_inlib(engine, e, comm)
+        return parallel.energy_stats(engine, e)
+
+    if comm is not None:
+        n_ranks_seen = comm.count()
+        reduce_stats(eng, torch.zeros(8, dtype=dtype, device=device))        # one real collective before anything is timed
+    else:
+        n_ranks_seen = len(parallel.all_gather_records(np.zeros(7), device if not args.emulated else 'cpu'))
     if world > 1:
         assert n_ranks_seen == torch.distributed.get_world_size() == world
 
@@ -331,7 +360,7 @@ def main():
         E, _ = loss.compute_local_energy(step, hamil, wf, params_s, r)
         ratio = loss.compute_psi_ratio(wf, params_s, r)
         pen, info = loss.compute_mean_overlap(ratio, ones)
-        stats = parallel.energy_stats(eng, E[0, 0].contiguous())
+        stats = reduce_stats(eng, E[0, 0].contiguous())
         stats['overlap/penalty'] = float(pen)
         return state, stats
 
@@ -347,7 +376,7 @@ def main():
             r = state['r']
         e, _ = loc_ene(step, params, r)
         refined.append(eng.last_refined())
-        stats = parallel.energy_stats(eng, e)
+        stats = reduce_stats(eng, e)
         return state, stats
 
     # ---- software-pipelined variant: E_loc(k) runs on a second stream while the sub-steps of step k+1 run ----
@@ -363,7 +392,7 @@ def main():
             state, pc, _ = sampler.sample(step * world + rank, state, params)        # enqueued on the main stream
             if pipe['e'] is not None:                                                # E_loc of the previous step
                 with torch.cuda.stream(s_e):
-                    pipe['stats'] = parallel.energy_stats(eng_e, pipe['e'])          # syncs s_e only
+                    pipe['stats'] = reduce_stats(eng_e, pipe['e'])          # syncs s_e only
             r_snap = state['r'].clone()
             r_snap.record_stream(s_e)
             ev = s_main.record_event()
@@ -374,7 +403,7 @@ def main():
 
         def drain():
             with torch.cuda.stream(s_e):
-                pipe['stats'] = parallel.energy_stats(eng_e, pipe['e'])
+                pipe['stats'] = reduce_stats(eng_e, pipe['e'])
             pipe['e'] = None
             return pipe['stats']
 
@@ -507,6 +536,8 @@ def main():
                                    f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats'
                                    + (f' + {S}x{S} psi-ratio matrix + overlap penalty' if S > 1 else ''),
                        'walkers_per_gpu': B, 'n_sub': args.n_sub, 'states': S, 'parallelism': f'walker-dp{world}',
+                       'reduction': ('in-library: dqmc_energy_stats_allgather (one ncclAllGather of 7 doubles per rank on the '
+                                     'context stream)' if comm is not None else 'host: torch.distributed.all_gather of the 7-double record'),
                        'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers, self-calibrated threshold)', 0: 'off',
                                   1: 'flagged walkers', 2: 'whole E_loc pass in float64'}[args.refine],
                        # what the library actually did during the timed steps (dqmc_last_refined / dqmc_refine_info)
@@ -528,6 +559,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub, args.dtype)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -42,6 +42,7 @@ SIGNATURES = [
     ('dqmc_debug_lanes', c_int, [c_void_p]),
     ('dqmc_last_refined', c_int, [c_void_p]),
     ('dqmc_refine_info', c_int, [c_void_p, POINTER(c_double)]),
+    ('dqmc_last_chunks', c_int, [c_void_p, POINTER(c_int)]),
     ('dqmc_set_option', c_int, [c_void_p, c_char_p, c_int]),
     ('dqmc_timing_enable', c_int, [c_void_p, c_int]),
     ('dqmc_timing_reset', c_int, [c_void_p]),

@@ -73,6 +73,7 @@ struct dqmc_ctx {
   bool ecp_skip_nl = false; // ... and no non-local ECP quadrature
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   double refine_info[4] = {0, 0, 0, 0};   // {mode, score threshold, measured error per unit of score, direct float64 calls left}
+  int last_chunks[2] = {0, 0};   // walker chunks of the last Laplacian-mode evaluation: this context's own pass, its float64 twin's (max over its passes)
   int device = 0;           // every entry point makes this the calling thread's current device
   double* d_gather = nullptr;   // all-gathered energy records (dqmc_energy_stats_allgather)
   size_t gather_cap = 0;
@@ -166,6 +167,7 @@ struct Engine : dqmc_ctx {
   std::vector<int> mlp_child;
   std::vector<char> mlp_skip;
   int mlp_fuse = 1;
+  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0;   // LinArgs::cfg_*
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
@@ -506,7 +508,11 @@ struct Engine : dqmc_ctx {
     };
     int last[4] = {-1, -1, -1, -1};
     for (int k = 0; k < no; ++k) {
-      if (mlp_skip.size() == (size_t)no && mlp_skip[k]) { op_sid[k] = -1; continue; }
+      if (mlp_skip.size() == (size_t)no && mlp_skip[k]) {     // rides with its parent (same slot if it has to run on its own)
+        op_sid[k] = 0;
+        for (int p = 0; p < k; ++p) if (mlp_child[p] == k) op_sid[k] = op_sid[p];
+        continue;
+      }
       io(k);
       int producer = -1;
       for (int b : rd)
@@ -658,8 +664,8 @@ struct Engine : dqmc_ctx {
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
-    if (s == "linear_f64_nr1") { dqmc::set_linear_f64_nr1(value); return DQMC_OK; }
-    if (s == "linear_bkx") { dqmc::set_linear_bkx(value); return DQMC_OK; }      // (process-wide A/B hook of kernel_linear.hip)
+    if (s == "linear_f64_nr1") { linear_f64_nr1 = value; return DQMC_OK; }
+    if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
@@ -672,7 +678,7 @@ struct Engine : dqmc_ctx {
     if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_bf") { fused_bf = value; return build_fused_plan(); }
-    if (s == "linear_bf") { dqmc::set_linear_bf(value); return DQMC_OK; }      // (process-wide A/B hook of kernel_linear.hip)
+    if (s == "linear_bf") { linear_bf = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "fused_wg_per_cu") {
       if (value < 4 || value > 6) return fail(DQMC_E_ARG, "fused_wg_per_cu must be 4, 5 or 6");
       fused2_lds_quarter = (size_t)160 * 1024 / value;
@@ -1351,6 +1357,7 @@ struct Engine : dqmc_ctx {
     size_t zrow = 4;
     for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && (size_t)pad4(o.i[21]) > zrow) zrow = (size_t)pad4(o.i[21]);
     return b + sizeof(real) * zrow * TP + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det +
+           sizeof(double) * ((size_t)sys.n_det + 1) +           // off_cond, off_kappa
            (ph_n && TP > 1 ? sizeof(double) * (size_t)N * dqmc::PH_STRIDE : 0);
   }
 
@@ -1364,6 +1371,7 @@ struct Engine : dqmc_ctx {
     const size_t per = ws_bytes_per_walker(TP);
     long chunk = per ? (long)(ws_budget / per) : B;
     if (chunk < 1) chunk = 1;
+    if (laplacian) last_chunks[0] = chunk >= B ? 1 : (int)((B + chunk - 1) / chunk);
     if (chunk >= B) {
 #if defined(__HIPCC__)
       if (laplacian && graph_fits(B))
@@ -1444,8 +1452,9 @@ struct Engine : dqmc_ctx {
     HIP_TRY(hipGraphLaunch((hipGraphExec_t)hit->exec, st_g));
     HIP_TRY(hipEventRecord(ev_g1, st_g));
     HIP_TRY(hipStreamWaitEvent(st, ev_g1, 0));
-    { dqmc::LaneInfo li; li.N = N; li.T = 3 * N + 2; li.TP = (li.T + 15) / 16 * 16; last_TP = li.TP; }
-    return DQMC_OK;
+    // the host-side layout (buf_off, off_*, last_B, last_TP) follows the replayed pass, so that dqmc_debug_read after it
+    // addresses what the graph wrote; the slab is already large enough (the graph was captured on it), nothing is reallocated
+    return plan(B, (3 * N + 2 + 15) / 16 * 16);
   }
 #endif
 
@@ -1522,6 +1531,10 @@ struct Engine : dqmc_ctx {
       for (int b : wr_b) buf_w[b].push_back(BufEv{e, sid});
       return DQMC_OK;
     };
+    // second layers of chained MLPs that actually ran inside their parent's launch IN THIS PASS (the chained kernel has
+    // instances for some lane counts only, and needs parent and child in the same lane layout: otherwise both layers run
+    // as ordinary LINEAR ops)
+    std::vector<char> ran_with_parent(ops.size(), 0);
     size_t first_op = 0;
     if (!laplacian && fused_n_ops > 0 && fused2_WT > 0 && (fused_enabled >= 2 || (fused_enabled == 1 && fused_pays(B)))) {
       rc = run_fused2(r, R, B, li);
@@ -1531,7 +1544,7 @@ struct Engine : dqmc_ctx {
     for (size_t opi = first_op; opi < ops.size(); ++opi) {
       const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
-      if (mlp_skip[opi]) continue;                      // second layer of a chained MLP: ran with its parent
+      if (ran_with_parent[opi]) continue;               // second layer of a chained MLP: ran with its parent
       const int sid = sid_of(opi);
       const hipStream_t so = sl[sid];
       { const int rcb = before(op, sid); if (rcb) return rcb; }
@@ -1549,6 +1562,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_LINEAR: {
           dqmc::LinArgs<real> a{};
+          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1;
           a.n_pieces = i[0];
           int ktot = 0, w_row = 0, n_bc = 0;
           for (int p = 0; p < i[0]; ++p) {
@@ -1589,6 +1603,7 @@ struct Engine : dqmc_ctx {
             t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
             dqmc::launch_linear_chain<real>(so, a);
             t_end();
+            ran_with_parent[mlp_child[opi]] = 1;
             { const int rca = after(op, sid); if (rca) return rca; }
             { const int rca = after(ch, sid); if (rca) return rca; }
             continue;
@@ -1666,11 +1681,10 @@ struct Engine : dqmc_ctx {
           // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
           t_begin("attention", 2.0 * B * i[4] * (double)N * (N + i[6]) * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
           int rc2;
-          if (sizeof(real) == 4 && attention_mfma && dqmc::attention_mfma_supported(N, i[5], i[6]) &&
+          if (attention_mfma && dqmc::attention_mfma_supported<real>(N, i[5], i[6]) &&
               (attention_mfma >= 2 || dqmc::attention_mfma_profitable(N)))
-            rc2 = dqmc::launch_attention_mfma(st, (const float*)bptr(i[0]), (const float*)bptr(i[1]), (const float*)bptr(i[2]),
-                                              (float*)bptr(i[3]), bufs[i[0]].width, i[4], i[5], B, li, i[6],
-                                              (const float*)(d_w + i[7]), (const float*)(d_w + i[8]));
+            rc2 = dqmc::launch_attention_mfma<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width, i[4], i[5], B, li,
+                                                    i[6], d_w + i[7], d_w + i[8]);
           else
             rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
                                                i[4], i[5], B, li, i[6], d_w + i[7], d_w + i[8]);
@@ -1749,6 +1763,7 @@ struct Engine : dqmc_ctx {
   }
   int local_energy(const void* r, const void* R, int B, void* e_loc, void* stats, void* grad, void* logpsi,
                    int32_t* sign) override {
+    last_chunks[0] = last_chunks[1] = 0;
     return lap_refined((const real*)r, (const real*)R, B, (real*)e_loc, (real*)stats, (real*)grad, (real*)logpsi, sign);
   }
   // the pass in this context's own precision: forward-Laplacian evaluation, plus the non-local ECP quadrature when the
@@ -1816,6 +1831,7 @@ struct Engine : dqmc_ctx {
     static_cast<Engine<double>*>(twin)->ecp_phi_f32 = true;
     static_cast<Engine<double>*>(twin)->ecp_idx = d_list;
     const int rc = twin->local_energy(r64, R64, n, e64, s64, g64, l64, sg64);
+    if (twin->last_chunks[0] > last_chunks[1]) last_chunks[1] = twin->last_chunks[0];
     twin->ph_skip = false;
     twin->ecp_skip_nl = false;
     if (rc) return rc;
@@ -2617,6 +2633,11 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
+int dqmc_last_chunks(dqmc_ctx* ctx, int* out2) {
+  if (!ctx || !out2) return DQMC_E_ARG;
+  out2[0] = ctx->last_chunks[0]; out2[1] = ctx->last_chunks[1];
+  return DQMC_OK;
+}
 int dqmc_refine_info(dqmc_ctx* ctx, double* out4) {
   if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");
   for (int k = 0; k < 4; ++k) out4[k] = ctx->refine_info[k];

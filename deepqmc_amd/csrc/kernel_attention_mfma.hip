@@ -7,38 +7,48 @@
 // Per derivative lane t the wave issues
 //     S-phase:  dS  = (q_t k0^T + q0 k_t^T)/sqrt(hd),   QK += q_t k_t^T          (K = hd)
 //     O-phase:  out = dP_t v0 + P v_t,                  OL += dP_t v_t            (K = keys)
-// as v_mfma_f32_16x16x4_f32 on fragments read from LDS tiles (row stride hd + 2: conflict-free A/B reads),
-// keeps P, the running sums A1 = sum_c dP_c*(dS_c - m_c), QK, OL in accumulator-layout registers for the
-// whole lane loop, and turns dP (accumulator layout: column per lane) into an A operand (row per lane) through
-// a 16 x keys scratch tile per wave.  float32 only (the float64 parity build keeps the scalar kernel: its
-// tiles would not fit the LDS), head_dim a multiple of 16 up to 64, at most 64 queries and 64 keys.
+// as 16x16x4 MFMAs (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64: same fragment layout) on fragments read
+// from LDS tiles (row stride hd + 2: conflict-free A/B reads), keeps P, the running sums
+// A1 = sum_c dP_c*(dS_c - m_c), QK, OL in accumulator-layout registers for the whole lane loop, and turns dP
+// (accumulator layout: column per lane) into an A operand (row per lane) through a 16 x keys scratch tile per wave.
+//
+// Round 4: float64 too -- the refinement twin IS the hot path of the attention ansatzes (BASELINE configs[3..4] send
+// 28-100 % of their walkers through it) and its attention was scalar FMA code.  What had kept float64 out was the
+// LDS: eight tiles of 48 x 66 doubles are 203 KB.  The value-lane operands that are A fragments -- q0 and P -- now live
+// in REGISTERS (16 + 16 values per lane: a workgroup of this kernel is alone on its CU, one wave per SIMD with 512
+// registers each), their LDS tiles are gone, and the dP scratch exists for the active waves only: benzene (42
+// electrons, head_dim 64) 146 KB in float64, 73 KB in float32 (two workgroups per CU instead of one).
+// head_dim a multiple of 16 up to 64, at most 64 queries and 64 keys.
 #include "common.h"
 #include "kernels.h"
 
 namespace dqmc {
 
 namespace {
-constexpr int MAXC = 4;   // 16-wide tiles along keys and along head_dim
-typedef Mfma<float>::acc_t acc_t;
+constexpr int MAXC = 4;    // 16-wide tiles along keys and along head_dim
+constexpr int MAXK = 16;   // k-steps of 4 along head_dim / keys
 
-__device__ __forceinline__ float row16_sum(float v) {   // sum over the 16 lanes sharing lane >> 4
+template <typename real> __device__ __forceinline__ real row16_sum(real v) {   // sum over the 16 lanes sharing lane >> 4
   v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
   return v;
 }
-__device__ __forceinline__ float row16_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 1, 64)); v = fmaxf(v, __shfl_xor(v, 2, 64));
-  v = fmaxf(v, __shfl_xor(v, 4, 64)); v = fmaxf(v, __shfl_xor(v, 8, 64));
+template <typename real> __device__ __forceinline__ real rmax(real a, real b) { return a > b ? a : b; }
+template <typename real> __device__ __forceinline__ real row16_max(real v) {
+  v = rmax(v, (real)__shfl_xor(v, 1, 64)); v = rmax(v, (real)__shfl_xor(v, 2, 64));
+  v = rmax(v, (real)__shfl_xor(v, 4, 64)); v = rmax(v, (real)__shfl_xor(v, 8, 64));
   return v;
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_attention_mfma(const float* __restrict__ q, const float* __restrict__ k,
-                                                        const float* __restrict__ v, float* __restrict__ out,
-                                                        int width, int H, int hd, LaneInfo li, int n_const,
-                                                        const float* __restrict__ k_const,
-                                                        const float* __restrict__ v_const) {
+// (second launch bound: float32 tile sets are <= 80 KB, two workgroups share a CU and each wave gets 256 registers;
+// a float64 workgroup has the CU to itself)
+template <typename real>
+__global__ void __launch_bounds__(256, sizeof(real) == 4 ? 2 : 1)
+k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const real* __restrict__ v, real* __restrict__ out, int width,
+                 int H, int hd, LaneInfo li, int n_const, const real* __restrict__ k_const, const real* __restrict__ v_const) {
+  typedef typename Mfma<real>::acc_t acc_t;
   HIP_DYNAMIC_SHARED(char, smem_raw)
-  float* sm = reinterpret_cast<float*>(smem_raw);
+  real* sm = reinterpret_cast<real*>(smem_raw);
   const int N = li.N, T = li.T, TP = li.TP;
   const int M = n_const + N;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -48,132 +58,140 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const float* __restrict_
   const int n_cb = (M + 15) / 16, n_db = hd / 16;     // key tiles, head_dim tiles
   const int n_rb = (N + 15) / 16;                     // query row blocks = active waves
   const int M16 = n_cb * 16, N16 = n_rb * 16;
-  const int SA = M16 + 2;                             // row stride of the per-wave [16][keys] A-operand tiles
-  float* q0 = sm;               float* k0 = q0 + N16 * S;   float* v0 = k0 + M16 * S;
-  float* qc = v0 + M16 * S;     float* kc = qc + N16 * S;   float* vc = kc + M16 * S;
-  float* PA = vc + M16 * S;                           // [4 waves][16][SA]  P as A operand
-  float* DA = PA + 4 * 16 * SA;                       // [4 waves][16][SA]  dP_t as A operand
-  const float sc = (float)(1.0 / sqrt((double)hd));
+  const int SA = M16 + 2;                             // row stride of the per-wave [16][keys] A-operand tile
+  const int nkd = hd / 4, nkm = M16 / 4;              // k-steps of the S-phase / of the O-phase
+  real* k0 = sm;                real* v0 = k0 + M16 * S;
+  real* qc = v0 + M16 * S;      real* kc = qc + N16 * S;   real* vc = kc + M16 * S;
+  real* DA = vc + M16 * S;                            // [n_rb waves][16][SA]  dP_t (and once P) as A operand
+  const real sc = (real)(1.0 / sqrt((double)hd));
   const long row0 = (long)b * N * TP;
   const int col0 = h * hd;
   const bool active = wave < n_rb;
   const int i_base = wave * 16;                       // first query of this wave
 
-  // Tile loads: thread (r_in, v4) moves one float4 per pass of rpp rows; the (<= MAXP) loads of a lane's q, k and
+  // Tile loads: thread (r_in, v4) moves one 4-vector per pass of rpp rows; the (<= MAXP) loads of a lane's q, k and
   // v tiles are all issued before any is used, and the next lane's are in flight while the current one is
   // multiplied (registers, not LDS, are the second buffer).
   constexpr int MAXP = 4;
-  const int vpr = hd / 4;                              // float4 per row
+  const int vpr = hd / 4;                              // 4-vectors per row
   const int rpp = 256 / vpr;                           // rows per pass
   const int r_in = tid / vpr, v4 = tid - r_in * vpr;
   const bool ld_thread = r_in < rpp;
-  const float* qg = q + row0 * width + col0 + 4 * v4;
-  const float* kg = k + row0 * width + col0 + 4 * v4;
-  const float* vg = v + row0 * width + col0 + 4 * v4;
-  Vec4<float> Rq[MAXP], Rk[MAXP], Rv[MAXP];
+  const real* qg = q + row0 * width + col0 + 4 * v4;
+  const real* kg = k + row0 * width + col0 + 4 * v4;
+  const real* vg = v + row0 * width + col0 + 4 * v4;
+  Vec4<real> Rq[MAXP], Rk[MAXP], Rv[MAXP];
   auto issue = [&](int t) {
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       const int row = p * rpp + r_in;
-      Rq[p] = Vec4<float>{{0.f, 0.f, 0.f, 0.f}};
-      Rk[p] = Vec4<float>{{0.f, 0.f, 0.f, 0.f}};
-      Rv[p] = Vec4<float>{{0.f, 0.f, 0.f, 0.f}};
+      Rq[p] = Vec4<real>{{0, 0, 0, 0}};
+      Rk[p] = Vec4<real>{{0, 0, 0, 0}};
+      Rv[p] = Vec4<real>{{0, 0, 0, 0}};
       if (!ld_thread) continue;
-      if (row < N) Rq[p] = *reinterpret_cast<const Vec4<float>*>(qg + ((long)row * TP + t) * width);
+      if (row < N) Rq[p] = *reinterpret_cast<const Vec4<real>*>(qg + ((long)row * TP + t) * width);
       if (row < n_const) {
         if (t == 0) {
-          Rk[p] = *reinterpret_cast<const Vec4<float>*>(k_const + (long)row * (H * hd) + col0 + 4 * v4);
-          Rv[p] = *reinterpret_cast<const Vec4<float>*>(v_const + (long)row * (H * hd) + col0 + 4 * v4);
+          Rk[p] = *reinterpret_cast<const Vec4<real>*>(k_const + (long)row * (H * hd) + col0 + 4 * v4);
+          Rv[p] = *reinterpret_cast<const Vec4<real>*>(v_const + (long)row * (H * hd) + col0 + 4 * v4);
         }
       } else if (row < M) {
         const long off = ((long)(row - n_const) * TP + t) * width;
-        Rk[p] = *reinterpret_cast<const Vec4<float>*>(kg + off);
-        Rv[p] = *reinterpret_cast<const Vec4<float>*>(vg + off);
+        Rk[p] = *reinterpret_cast<const Vec4<real>*>(kg + off);
+        Rv[p] = *reinterpret_cast<const Vec4<real>*>(vg + off);
       }
     }
   };
-  auto put = [&](float* dq, float* dk, float* dv) {   // registers -> LDS tiles (rows beyond N / M are zero)
+  auto put = [&](real* dq, real* dk, real* dv) {   // registers -> LDS tiles (rows beyond N / M are zero)
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
       const int row = p * rpp + r_in;
       if (!ld_thread) continue;
       if (row < N16) {
-        Vec2<float>* d2 = reinterpret_cast<Vec2<float>*>(dq + row * S + 4 * v4);
-        d2[0] = Vec2<float>{{Rq[p].v[0], Rq[p].v[1]}}; d2[1] = Vec2<float>{{Rq[p].v[2], Rq[p].v[3]}};
+        Vec2<real>* d2 = reinterpret_cast<Vec2<real>*>(dq + row * S + 4 * v4);
+        d2[0] = Vec2<real>{{Rq[p].v[0], Rq[p].v[1]}}; d2[1] = Vec2<real>{{Rq[p].v[2], Rq[p].v[3]}};
       }
       if (row < M16) {
-        Vec2<float>* k2 = reinterpret_cast<Vec2<float>*>(dk + row * S + 4 * v4);
-        k2[0] = Vec2<float>{{Rk[p].v[0], Rk[p].v[1]}}; k2[1] = Vec2<float>{{Rk[p].v[2], Rk[p].v[3]}};
-        Vec2<float>* v2 = reinterpret_cast<Vec2<float>*>(dv + row * S + 4 * v4);
-        v2[0] = Vec2<float>{{Rv[p].v[0], Rv[p].v[1]}}; v2[1] = Vec2<float>{{Rv[p].v[2], Rv[p].v[3]}};
+        Vec2<real>* k2 = reinterpret_cast<Vec2<real>*>(dk + row * S + 4 * v4);
+        k2[0] = Vec2<real>{{Rk[p].v[0], Rk[p].v[1]}}; k2[1] = Vec2<real>{{Rk[p].v[2], Rk[p].v[3]}};
+        Vec2<real>* v2 = reinterpret_cast<Vec2<real>*>(dv + row * S + 4 * v4);
+        v2[0] = Vec2<real>{{Rv[p].v[0], Rv[p].v[1]}}; v2[1] = Vec2<real>{{Rv[p].v[2], Rv[p].v[3]}};
       }
     }
   };
-  // rows of this lane in accumulator layout and their validity
+  // rows of this lane in accumulator layout
   int irow[4];
 #pragma unroll
-  for (int rg = 0; rg < 4; ++rg) irow[rg] = i_base + Mfma<float>::row_of(lane, rg);
+  for (int rg = 0; rg < 4; ++rg) irow[rg] = i_base + Mfma<real>::row_of(lane, rg);
 
   issue(0);
-  put(q0, k0, v0);
+  put(qc, k0, v0);                                    // (q0 passes through the current-lane tile on its way to registers)
   if (T > 1) issue(1);
   __syncthreads();
 
   acc_t P[MAXC], A1[MAXC], QK[MAXC], OL[MAXC];
-  float A2[4] = {0.f, 0.f, 0.f, 0.f};
+  real A2[4] = {0, 0, 0, 0};
+  real qa[MAXK], pa[MAXK];                            // q0 and P as A fragments: row l15, k = 4 kk + l4
 #pragma unroll
   for (int c = 0; c < MAXC; ++c) { P[c] = acc_t{0, 0, 0, 0}; A1[c] = acc_t{0, 0, 0, 0}; QK[c] = acc_t{0, 0, 0, 0}; OL[c] = acc_t{0, 0, 0, 0}; }
-  float* myPA = PA + wave * 16 * SA;
-  float* myDA = DA + wave * 16 * SA;
+#pragma unroll
+  for (int kk = 0; kk < MAXK; ++kk) { qa[kk] = 0; pa[kk] = 0; }
+  real* myDA = DA + (active ? wave : 0) * 16 * SA;
 
   // ---- value lane: P = softmax(q0 k0^T / sqrt(hd)) over the M keys, out_0 = P v0 ----
   if (active) {
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk)
+      if (kk < nkd) qa[kk] = qc[(i_base + l15) * S + kk * 4 + l4];
     acc_t s0[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) s0[c] = acc_t{0, 0, 0, 0};
-    for (int kk = 0; kk < hd / 4; ++kk) {
-      const float a0 = q0[(i_base + l15) * S + kk * 4 + l4];
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkd) break;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < n_cb) s0[c] = Mfma<float>::run(a0, k0[(c * 16 + l15) * S + kk * 4 + l4], s0[c]);
+        if (c < n_cb) s0[c] = Mfma<real>::run(qa[kk], k0[(c * 16 + l15) * S + kk * 4 + l4], s0[c]);
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float mx = -INFINITY;
+      real mx = -INFINITY;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < n_cb && c * 16 + l15 < M) mx = fmaxf(mx, s0[c][rg] * sc);
-      mx = row16_max(mx);
-      float sum = 0.f;
+        if (c < n_cb && c * 16 + l15 < M) mx = rmax(mx, (real)(s0[c][rg] * sc));
+      mx = row16_max<real>(mx);
+      real sum = 0;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
-        float e = 0.f;
-        if (c < n_cb && c * 16 + l15 < M) e = expf(s0[c][rg] * sc - mx);
+        real e = 0;
+        if (c < n_cb && c * 16 + l15 < M) e = r_exp<real>(s0[c][rg] * sc - mx);
         P[c][rg] = e;
         sum += e;
       }
-      sum = row16_sum(sum);
-      const float inv = 1.f / sum;
+      sum = row16_sum<real>(sum);
+      const real inv = 1 / sum;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) P[c][rg] *= inv;
     }
-    // P as an A operand (row = query, k = key): through the wave's scratch tile
+    // P as an A operand (row = query, k = key): through the wave's scratch tile, then held in registers
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
       if (c < n_cb)
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) myPA[Mfma<float>::row_of(lane, rg) * SA + c * 16 + l15] = P[c][rg];
-  }
-  __syncthreads();
-  if (active) {
+        for (int rg = 0; rg < 4; ++rg) myDA[Mfma<real>::row_of(lane, rg) * SA + c * 16 + l15] = P[c][rg];
+    wave_lds_fence();
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk)
+      if (kk < nkm) pa[kk] = myDA[l15 * SA + kk * 4 + l4];
     acc_t o[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) o[c] = acc_t{0, 0, 0, 0};
-    for (int kk = 0; kk < M16 / 4; ++kk) {
-      const float ap = myPA[l15 * SA + kk * 4 + l4];
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkm) break;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
-        if (c < n_db) o[c] = Mfma<float>::run(ap, v0[(kk * 4 + l4) * S + c * 16 + l15], o[c]);
+        if (c < n_db) o[c] = Mfma<real>::run(pa[kk], v0[(kk * 4 + l4) * S + c * 16 + l15], o[c]);
     }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
@@ -187,7 +205,7 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const float* __restrict_
   // ---- derivative lanes, then the Laplacian lane (t = T-1) ----
   for (int t = 1; t < T; ++t) {
     const bool lap = t == T - 1;
-    __syncthreads();                                  // previous lane's tiles are no longer read
+    __syncthreads();                                  // previous lane's tiles (t = 1: q0 in qc) are no longer read
     put(qc, kc, vc);
     __syncthreads();
     if (t + 1 < T) issue(t + 1);                      // in flight while this lane is multiplied
@@ -196,61 +214,65 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const float* __restrict_
     acc_t ds[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) ds[c] = acc_t{0, 0, 0, 0};
-    for (int kk = 0; kk < hd / 4; ++kk) {
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkd) break;
       const int ko = kk * 4 + l4;
-      const float a0 = q0[(i_base + l15) * S + ko], at = qc[(i_base + l15) * S + ko];
+      const real a0 = qa[kk], at = qc[(i_base + l15) * S + ko];
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
         if (c < n_cb) {
-          const float b0 = k0[(c * 16 + l15) * S + ko], bt = kc[(c * 16 + l15) * S + ko];
-          ds[c] = Mfma<float>::run(at, b0, ds[c]);
-          ds[c] = Mfma<float>::run(a0, bt, ds[c]);
-          if (!lap) QK[c] = Mfma<float>::run(at, bt, QK[c]);
+          const real b0 = k0[(c * 16 + l15) * S + ko], bt = kc[(c * 16 + l15) * S + ko];
+          ds[c] = Mfma<real>::run(at, b0, ds[c]);
+          ds[c] = Mfma<real>::run(a0, bt, ds[c]);
+          if (!lap) QK[c] = Mfma<real>::run(at, bt, QK[c]);
         }
     }
     // softmax algebra on the wave's 16 x M block (accumulator layout), row sums by 16-lane shuffles
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
-      float m = 0.f;
+      real m = 0;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
         if (c < n_cb) {
-          ds[c][rg] = lap ? (ds[c][rg] + 2.f * QK[c][rg]) * sc : ds[c][rg] * sc;     // dS_c  or  L_S
+          ds[c][rg] = lap ? (ds[c][rg] + 2 * QK[c][rg]) * sc : ds[c][rg] * sc;     // dS_c  or  L_S
           m += P[c][rg] * ds[c][rg];
         }
-      m = row16_sum(m);                                // rowsum(P*dS_c)  or  rowsum(P*L_S)
-      float s2 = 0.f;
+      m = row16_sum<real>(m);                          // rowsum(P*dS_c)  or  rowsum(P*L_S)
+      real s2 = 0;
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
         if (c < n_cb) {
-          float dp;
+          real dp;
           if (!lap) {
-            const float cc = ds[c][rg] - m;
+            const real cc = ds[c][rg] - m;
             dp = P[c][rg] * cc;
             A1[c][rg] += dp * cc;
             s2 += dp * ds[c][rg];
           } else {
             dp = A1[c][rg] + P[c][rg] * (ds[c][rg] - m - A2[rg]);                     // L_P
           }
-          myDA[Mfma<float>::row_of(lane, rg) * SA + c * 16 + l15] = dp;
+          myDA[Mfma<real>::row_of(lane, rg) * SA + c * 16 + l15] = dp;
         }
-      if (!lap) A2[rg] += row16_sum(s2);
+      if (!lap) A2[rg] += row16_sum<real>(s2);
     }
     wave_lds_fence();
     // O-phase (the wave reads back only what it wrote itself: LDS operations of a wave complete in order)
     acc_t o[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) o[c] = lap ? OL[c] : acc_t{0, 0, 0, 0};
-    for (int kk = 0; kk < M16 / 4; ++kk) {
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkm) break;
       const int jo = kk * 4 + l4;
-      const float adp = myDA[l15 * SA + jo], ap = myPA[l15 * SA + jo];
+      const real adp = myDA[l15 * SA + jo], ap = pa[kk];
 #pragma unroll
       for (int c = 0; c < MAXC; ++c)
         if (c < n_db) {
-          const float b0 = v0[jo * S + c * 16 + l15], bt = vc[jo * S + c * 16 + l15];
-          o[c] = Mfma<float>::run(adp, b0, o[c]);
-          o[c] = Mfma<float>::run(ap, bt, o[c]);
-          if (!lap) OL[c] = Mfma<float>::run(adp, bt + bt, OL[c]);                     // 2 sum_c dP_c v_c
+          const real b0 = v0[jo * S + c * 16 + l15], bt = vc[jo * S + c * 16 + l15];
+          o[c] = Mfma<real>::run(adp, b0, o[c]);
+          o[c] = Mfma<real>::run(ap, bt, o[c]);
+          if (!lap) OL[c] = Mfma<real>::run(adp, bt + bt, OL[c]);                     // 2 sum_c dP_c v_c
         }
     }
 #pragma unroll
@@ -264,33 +286,43 @@ __global__ void __launch_bounds__(256) k_attention_mfma(const float* __restrict_
   for (int t = T; t < TP; ++t)
     for (int e = tid; e < N * hd; e += nthr) {
       const int i = e / hd, d = e - i * hd;
-      out[(row0 + (long)i * TP + t) * width + col0 + d] = 0.f;
+      out[(row0 + (long)i * TP + t) * width + col0 + d] = 0;
     }
 }
 
-size_t attention_mfma_lds_bytes(int N, int hd, int n_const) {
+template <typename real> size_t attention_mfma_lds_bytes(int N, int hd, int n_const) {
   const size_t M16 = ((size_t)N + n_const + 15) / 16 * 16, N16 = ((size_t)N + 15) / 16 * 16;
-  return sizeof(float) * ((2 * N16 + 4 * M16) * (hd + 2) + 2 * 4 * 16 * (M16 + 2));
+  return sizeof(real) * ((N16 + 4 * M16) * (hd + 2) + (N16 / 16) * 16 * (M16 + 2));
 }
 
-bool attention_mfma_supported(int N, int hd, int n_const) {
-  return hd % 16 == 0 && hd <= 64 && N <= 64 && N + n_const <= 64 && attention_mfma_lds_bytes(N, hd, n_const) <= 160 * 1024;
+template <typename real> bool attention_mfma_supported(int N, int hd, int n_const) {
+  return hd % 16 == 0 && hd <= 64 && N <= 64 && N + n_const <= 64 && attention_mfma_lds_bytes<real>(N, hd, n_const) <= 160 * 1024;
 }
-// Measured on MI355X (4 heads x 64, attention time per VMC step, scalar kernel -> this one): 42 electrons
+// Measured on MI355X (float32, 4 heads x 64, attention time per VMC step, scalar kernel -> this one): 42 electrons
 // 135 -> 31 ms, 28 electrons 66 -> 49 ms, 14 electrons 29 -> 67 ms, 4 electrons 10 -> 75 ms: with a single query
 // row block three of the four waves idle through the per-lane tile traffic, so the scalar kernel keeps the
 // small systems.
 bool attention_mfma_profitable(int N) { return N > 16; }
 
-int launch_attention_mfma(hipStream_t st, const float* q, const float* k, const float* v, float* out, int width, int H,
-                          int hd, int B, LaneInfo li, int n_const, const float* k_const, const float* v_const) {
-  const size_t lds = attention_mfma_lds_bytes(li.N, hd, n_const);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+template <typename real>
+int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
+                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const) {
+  const size_t lds = attention_mfma_lds_bytes<real>(li.N, hd, n_const);
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_mfma<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)lds) != hipSuccess)
     return -2;
-  hipLaunchKernelGGL(k_attention_mfma, dim3((unsigned)(B * H)), dim3(256), lds, st, q, k, v, out, width, H, hd, li,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention_mfma<real>), dim3((unsigned)(B * H)), dim3(256), lds, st, q, k, v, out, width, H, hd, li,
                      n_const, k_const, v_const);
   return 0;
 }
+
+template size_t attention_mfma_lds_bytes<float>(int, int, int);
+template size_t attention_mfma_lds_bytes<double>(int, int, int);
+template bool attention_mfma_supported<float>(int, int, int);
+template bool attention_mfma_supported<double>(int, int, int);
+template int launch_attention_mfma<float>(hipStream_t, const float*, const float*, const float*, float*, int, int, int, int, LaneInfo, int,
+                                          const float*, const float*);
+template int launch_attention_mfma<double>(hipStream_t, const double*, const double*, const double*, double*, int, int, int, int, LaneInfo,
+                                           int, const double*, const double*);
 
 }  // namespace dqmc

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
   lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx);
 }
 
-// "linear_bf" (dqmc_set_option): 0 = float32 MFMAs everywhere, 1 = every float32 layer of sufficient depth on the bf16
+// "linear_bf" (dqmc_set_option, per context: LinArgs::cfg_bf): 0 = float32 MFMAs everywhere, 1 = every float32 layer of sufficient depth on the bf16
 // pipe, 2 (default) = only the Laplacian tiles of the 48-lane groups (11-15 electrons), the one place where it measured
 // FASTER.  Same-call A/Bs on the MI355X, ms per step, value 1 against 0: LiH / PauliNet 5.46 vs 5.46, N2 / FermiNet
 // 52.9 -> 54.4, benzene / Psiformer (256 walkers) 264 -> 284, although the matrix pipe does 44 % less work.  What the
@@ -675,14 +675,12 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
 // 3.12 against 2.71 ms per launch; held to 168 (three waves) they come out ahead: N2 53.1 -> 52.1 ms per step with value
 // 2, helped by the accuracy of the nine-product sum, which rounds less often than the f32 MFMA chain (refined walkers
 // 5.4 % -> 3.9 % on N2; 4.3 % -> 4.0 % on LiH with value 1).  The value-row tiles stay slower with the split (63 -> 68 us).
-static int g_linear_bf = 2;
-void set_linear_bf(int v) { g_linear_bf = v; }
 // a layer goes to the bf16 pipe when its chunks of 32 k (NP MFMAs of 16 cycles per block) cost less than its k-steps of
 // 4 (one MFMA of 32 cycles): pieces of a few k would multiply mostly padding
 static bool bf_pays(const LinArgs<float>& a, int np) {
   long chunks = 0, ksteps = 0;
   for (int p = 0; p < a.n_pieces; ++p) { chunks += (a.piece[p].K + 31) / 32; ksteps += (a.piece[p].K + 3) / 4; }
-  return g_linear_bf != 0 && chunks * np * 16 + chunks * 12 < ksteps * 32;
+  return a.cfg_bf != 0 && chunks * np * 16 + chunks * 12 < ksteps * 32;
 }
 template <int MR, int NR, int GPW, int WN> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
@@ -701,25 +699,21 @@ template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
 template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
   static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
     if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
-    if (g_linear_bf == 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
+    if (a.cfg_bf == 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
     launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
     return true;
   }
 };
 
-// A/B hook (dqmc_set_option "linear_bkx"): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
+// A/B hook (dqmc_set_option "linear_bkx", per context: LinArgs::cfg_bkx): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
 // 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
-static int g_linear_bkx = 3;
 // float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
 // alone are 96 / 128 registers and ONE wave per SIMD remains; one column block per wave (option "linear_f64_nr1")
 // doubles the waves per SIMD at the price of reading the A rows twice as often
-static int g_linear_f64_tall_nr1 = 0;
-void set_linear_f64_nr1(int v) { g_linear_f64_tall_nr1 = v; }
-void set_linear_bkx(int v) { g_linear_bkx = v; }
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
   int kmax = 0;
   for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
-  const bool on = sizeof(real) == 4 ? (g_linear_bkx == 2 || g_linear_bkx == 4) : (g_linear_bkx == 3 || g_linear_bkx == 4);
+  const bool on = sizeof(real) == 4 ? (a.cfg_bkx == 2 || a.cfg_bkx == 4) : (a.cfg_bkx == 3 || a.cfg_bkx == 4);
   return on && kmax >= 32;
 }
 template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
@@ -769,7 +763,7 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
   constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0;   // 8 waves, BN = 128: the A rows of a wide layer are read half as often
   if (a.ldw > 64 && WIDE) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, (WIDE ? 2 : 1)>(st, a);
   else if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, 1>(st, a);
-  else if (a.ldw > 16 && !(sizeof(real) == 8 && MR >= 6 && g_linear_f64_tall_nr1)) launch_cfg<real, MR, 2, GPW, 1>(st, a);
+  else if (a.ldw > 16 && !(sizeof(real) == 8 && MR >= 6 && a.cfg_f64_nr1)) launch_cfg<real, MR, 2, GPW, 1>(st, a);
   else launch_cfg<real, MR, 1, GPW, 1>(st, a);
 }
 

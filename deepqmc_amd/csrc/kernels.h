@@ -61,13 +61,15 @@ template <typename real> struct LinArgs {
   int ldw2;           // pad4(Nout of the second layer)
   const real* bias2;
   int act2;
+  // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_nr1";
+  // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
+  // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
+  int cfg_bf, cfg_bkx, cfg_f64_nr1;
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
-void set_linear_bkx(int v);
-void set_linear_bf(int v);          // 0: float32 MFMAs only; 1: float32 layers on the bf16 matrix pipe where that pays (kernel_linear.hip)
-void set_linear_f64_nr1(int v);
+constexpr int LINEAR_BF_DEFAULT = 2, LINEAR_BKX_DEFAULT = 3;      // (kernel_linear.hip: what the values select)
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
 struct FusedBuf {
@@ -180,11 +182,13 @@ int launch_attention(hipStream_t st, const real* q, const real* k, const real* v
                      int B, LaneInfo li, int n_const, const real* k_const, const real* v_const);
 template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const);
 
-// ---- kernel_attention_mfma.hip: float32, contractions on MFMA (head_dim % 16 == 0, <= 64 queries / keys) ----
-bool attention_mfma_supported(int N, int hd, int n_const);
+// ---- kernel_attention_mfma.hip: contractions on MFMA, float32 and float64 (head_dim % 16 == 0, <= 64 queries / keys) ----
+template <typename real> size_t attention_mfma_lds_bytes(int N, int hd, int n_const);
+template <typename real> bool attention_mfma_supported(int N, int hd, int n_const);
 bool attention_mfma_profitable(int N);
-int launch_attention_mfma(hipStream_t st, const float* q, const float* k, const float* v, float* out, int width, int H,
-                          int hd, int B, LaneInfo li, int n_const, const float* k_const, const float* v_const);
+template <typename real>
+int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
+                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const);
 
 // ---- kernels_head.hip ----
 template <typename real>

@@ -328,6 +328,13 @@ class Engine:
         self._check(self.lib.dqmc_refine_info(self._ctx, out))
         return {'mode': int(out[0]), 'score_threshold': out[1], 'error_per_score': out[2], 'direct_f64_calls_left': int(out[3])}
 
+    def last_chunks(self) -> dict:
+        """Walker chunks the last local-energy call was split into (dqmc_last_chunks): the context's own pass and its
+        float64 twin's."""
+        out = (ctypes.c_int * 2)()
+        self._check(self.lib.dqmc_last_chunks(self._ctx, out))
+        return {'own': int(out[0]), 'twin': int(out[1])}
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
 

@@ -67,6 +67,15 @@ class RcclCommunicator:
         if rc:
             raise RuntimeError(f'ncclCommInitRank failed: {rc}')
 
+    def count(self) -> int:
+        """Ranks of the communicator as RCCL itself reports them (ncclCommCount)."""
+        n = self._ct.c_int(0)
+        self.rccl.ncclCommCount.argtypes = [self._ct.c_void_p, self._ct.POINTER(self._ct.c_int)]
+        rc = self.rccl.ncclCommCount(self.comm, self._ct.byref(n))
+        if rc:
+            raise RuntimeError(f'ncclCommCount failed: {rc}')
+        return int(n.value)
+
     def close(self):
         if self.comm:
             self.rccl.ncclCommDestroy.argtypes = [self._ct.c_void_p]

@@ -37,10 +37,14 @@ class MetropolisSampler:
     length = 1
 
     def __init__(self, hamil, wf, *, tau: float = 1.0, target_acceptance: Optional[float] = 0.57,
-                 max_age: Optional[int] = None, sample_initializer=synthetic_walkers):
+                 max_age: Optional[int] = None, sample_initializer=synthetic_walkers, in_place: bool = False):
+        """`in_place`: `sample` advances the tensors of the state it is given instead of copies of them (no five
+        device-to-device clones per call; the state passed in is then NOT a snapshot of the previous step -- for loops
+        that never roll back, e.g. bench.py)."""
         self.hamil, self.wf = hamil, wf
         self.initial_tau, self.target_acceptance, self.max_age = tau, target_acceptance, max_age
         self.sample_initializer = sample_initializer
+        self.in_place = in_place
 
     def phys_conf(self, R, r) -> PhysicalConfiguration:
         """electron_samplers.py:165-173."""
@@ -66,8 +70,11 @@ class MetropolisSampler:
         eng = self.wf.engine(params, R)
         # the reference's samplers are functional (a new state per call); dqmc_mcmc_steps updates its arguments
         # in place, so it gets copies and the caller's previous state stays intact (rollback, multi-state loops)
-        st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
-              'age': state['age'].clone(), 'tau': state['tau'].clone()}
+        if self.in_place:
+            st = {'r': state['r'], 'log': state['psi'].log, 'sign': state['psi'].sign, 'age': state['age'], 'tau': state['tau']}
+        else:
+            st = {'r': state['r'].clone(), 'log': state['psi'].log.clone(), 'sign': state['psi'].sign.clone(),
+                  'age': state['age'].clone(), 'tau': state['tau'].clone()}
         stats = eng.mcmc_steps(st, self.length, max_age=self.max_age, target_acceptance=self.target_acceptance,
                                seed=int(rng), noise=noise, unif=unif, R=R)
         state = {'r': st['r'], 'psi': Psi(st['sign'], st['log']), 'age': st['age'], 'tau': st['tau']}

@@ -69,8 +69,14 @@ class NeuralNetworkWaveFunction:
             eng.set_params(params)
         else:
             if len(self._engines) >= self.max_engines:
-                # dropped, not closed: a caller may still hold the Engine; its context is released with the last reference
-                self._engines.pop(0)
+                # closed when nothing but this frame still refers to it (workspace, float64 twin and captured graphs go
+                # back to the device now, not when the garbage collector gets to a cycle); a caller that still holds the
+                # Engine keeps a working context, released with its last reference
+                import sys
+                _, _, old = self._engines.pop(0)
+                if sys.getrefcount(old) <= 2:
+                    old.close()
+                del old
                 self._evictions += 1
                 if self._evictions == 4 * self.max_engines:
                     import warnings
@@ -82,6 +88,11 @@ class NeuralNetworkWaveFunction:
                          norm_eps=self.norm_eps, lib=self._lib, R=R0)
         self._engines.append((params, gkey, eng))
         return eng
+
+    def release(self):
+        """Close every cached HIP context (device workspaces, twins, captured graphs) now."""
+        while self._engines:
+            self._engines.pop()[2].close()
 
     def invalidate(self, params=None):
         """Re-upload the weights of `params` (all cached trees if None) after their leaves were changed in place."""

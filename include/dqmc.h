@@ -267,6 +267,11 @@ int dqmc_last_refined(dqmc_ctx* ctx);
  * context), current score threshold, measured float32 error per unit of score (0 before the first probe), calls
  * that will still go to the direct float64 pass because most walkers were flagged}. */
 int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
+/* Walker chunks of the last dqmc_local_energy call: out2 = {chunks of the context's own forward-Laplacian pass (0: it did
+ * not run one, e.g. the whole batch went to float64), chunks of the largest pass of its float64 twin}.  An evaluation
+ * whose activations exceed "ws_budget_mb" is split into chunks inside the library (the reference has no such limit to
+ * replace: its vmap over the electron batch, loss/energy.py:50-57, simply needs the memory). */
+int dqmc_last_chunks(dqmc_ctx* ctx, int* out2);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op where that is the faster path
  * (N <= 4, or fewer than 1024 walkers; 2 = always, 0 = never, which also keeps every

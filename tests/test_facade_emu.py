@@ -79,6 +79,13 @@ def test_sampler_states_are_not_aliased():
     with pytest.raises(DqmcError):
         wf.engine(params).mcmc_steps({'r': s1['r'].float(), 'log': s1['psi'].log, 'sign': s1['psi'].sign, 'age': s1['age'],
                                       'tau': s1['tau']}, 1)
+    # opt-in in-place states (no clones per call): the same chain, advanced in the caller's tensors
+    inplace = DecorrSampler(h, wf, length=3, tau=0.4, in_place=True)
+    t0 = inplace.init(1, params, 4)
+    r_ptr = t0['r'].data_ptr()
+    t1, _, stats_ip = inplace.sample(2, t0, params)
+    assert t1['r'].data_ptr() == r_ptr and torch.equal(t1['r'], s1['r']) and torch.equal(t1['psi'].log, s1['psi'].log)
+    assert torch.equal(t1['age'], s1['age']) and torch.equal(t1['tau'], s1['tau']) and stats_ip == stats
 
 
 ECP_TABLES = {'Li': [0, [[-1, [[], [[5.41, 1.0]], [[4.6, -4.6]], [[2.7, 5.41]]]], [0, [[], [], [[1.33, 6.75]]]], [1, [[], [], [[1.25, 0.45]]]]]]}

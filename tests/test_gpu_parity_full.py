@@ -7,8 +7,8 @@ coefficients) 32 through the Psiformer / MFMA value path with its 2 160 psi rati
 
 Asserted, per configuration (north star: "within 1e-5 Ha relative", sign bit-exact), AT LIBRARY DEFAULTS:
   * every psi sign equals the oracle's;
-  * >= 99 % of the walkers with |E - E_ref| / max(1, |E_ref|) < 1e-5, and explicit p50 / p99 / max bounds
-    (table BOUNDS below -- plain percentiles), on the first call of a fresh context (the call that runs the
+  * EVERY walker of the BASELINE-size sets with |E - E_ref| / max(1, |E_ref|) < 1e-5 (>= 99 % for the auxiliary sets),
+    and explicit p50 / p99 / max bounds (table BOUNDS below -- plain percentiles), on the first call of a fresh context (the call that runs the
     calibration probe) AND on the following call (the calibrated steady state);
   * log|psi| absolute error percentiles.
 With the refinement off the same numbers are recorded (not asserted) so that the report shows what it buys, and
@@ -21,7 +21,7 @@ walker by score = (|lap| + |grad|^2) / max(1, |E_loc|) x conditioning record of 
 threshold for a 5e-6 target, walkers above it are re-evaluated by the float64 twin.  LiH / PauliNet refines ~3 % of
 its walkers, N2 / FermiNet ~10 %, the Psiformers and the random-init TransPsiformer most or all of them -- those
 fall into the direct float64 pass.
-Everything lands in gpurun_out/parity_report.json -> profiles/r03_parity_report.json.
+Everything lands in gpurun_out/parity_report.json -> profiles/r04_parity_report.json.
 """
 import json
 import os
@@ -44,18 +44,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 
 # name: (min fraction within 1e-5, p50 bound, p99 bound, max bound, log|psi| p99 bound)
+# The four BASELINE-size sets (+ the ECP set) assert the north-star tolerance itself: EVERY walker within 1e-5 (round-4;
+# observed maxima 9.0e-6 / 8.1e-6 / <= 6e-8, profiles/r03_parity_report.json).  The looser bounds below them belong to the
+# AUXILIARY sets only (small batches of the same systems, raw Gaussian walkers): 0.1-0.4 % of their walkers sit at 1.2-1.4e-5.
 BOUNDS = {
-    'lih_paulinet_4096': (0.99, 1e-6, 1e-5, 2e-5, 1e-5),
+    'lih_paulinet_4096': (1.0, 1e-6, 1e-5, 1e-5, 1e-5),
+    'n2_ferminet_4096': (1.0, 2e-6, 1e-5, 1e-5, 1e-4),
+    'benzene_psiformer_256': (1.0, 3e-6, 1e-5, 1e-5, 1e-3),
+    'c4h4_transpsiformer_512': (1.0, 1e-6, 1e-5, 1e-5, 1e-3),
+    'benzene_ecp_psiformer_32': (1.0, 2e-6, 1e-5, 1e-5, 1e-3),    # + V_nl: 2 160 psi ratios per walker (float64 for refined walkers)
+    # auxiliary sets
     'lih_psiformer_256': (0.99, 2e-6, 1e-5, 2e-5, 2e-5),
     'n2_ferminet_512': (0.99, 2e-6, 1e-5, 2e-5, 1e-4),
     'benzene_psiformer_8': (0.99, 3e-6, 1e-5, 1e-5, 5e-4),
     'c4h4_transpsiformer_64': (0.99, 1e-6, 1e-5, 1e-5, 1e-3),     # the probe sends this system to the direct float64 pass
     'lih_paulinet_raw_1024': (0.99, 1e-6, 1e-5, 5e-5, 5e-4),      # raw Gaussian walkers: log|psi| near nodes is not refined
-    # round 3: BASELINE batch sizes
-    'n2_ferminet_4096': (0.99, 2e-6, 1e-5, 5e-5, 1e-4),
-    'benzene_psiformer_256': (0.99, 3e-6, 1e-5, 2e-5, 1e-3),
-    'c4h4_transpsiformer_512': (0.99, 1e-6, 1e-5, 2e-5, 1e-3),
-    'benzene_ecp_psiformer_32': (0.99, 2e-6, 1e-5, 2e-5, 1e-3),   # + V_nl: 2 160 psi ratios per walker (float64 for refined walkers)
 }
 
 
@@ -196,3 +199,86 @@ def test_staged_metropolis_n2_bit_exact_f64():
         np.testing.assert_allclose(stats[k], ostats[k], rtol=1e-9, atol=1e-9, err_msg=k)
     report('staged_mcmc_n2_f64', {'walkers': B, 'sub_steps': n_sub, 'accept_bits_equal': True,
                                   'acceptance_last': stats['sampling/acceptance']})
+
+
+def test_chunked_workspace_benzene_256_bit_equal():
+    """BASELINE configs[3] runs 2048 benzene walkers per GPU, which only ever fit as workspace CHUNKS (Engine::run:
+    ~0.2 GB of Laplacian-mode activations per walker).  Here the 256-walker fixture with a budget that forces >= 4
+    chunks in the float32 engine AND in its float64 twin: bit-equal to the unchunked evaluation (energies, statistics,
+    gradient, psi), and within the fixture's bounds."""
+    d, meta, h, eng = load('benzene_psiformer_256')
+    r = torch.as_tensor(d['r'], device=DEV)
+    e0, st0, g0 = eng.local_energy(r, return_grad=True)
+    s0, l0 = eng.wf_eval(r)
+    n_ref0 = eng.last_refined()
+    for name in ('ws_budget_mb', 'twin.ws_budget_mb'):
+        eng.set_option(name, 10 * 1024)           # 10 GiB: ~50 float32 / ~25 float64 walkers per chunk
+    e1, st1, g1 = eng.local_energy(r, return_grad=True)
+    info = eng.last_chunks()
+    s1, l1 = eng.wf_eval(r)
+    assert eng.last_refined() == n_ref0
+    assert max(info['own'], info['twin']) >= 4, info                 # (the whole batch may go to the float64 twin)
+    assert torch.equal(e1, e0) and torch.equal(g1, g0) and torch.equal(s1, s0) and torch.equal(l1, l0)
+    for k in st0:
+        assert torch.equal(st1[k], st0[k]), k
+    rel, prof = profile(e1.double().cpu().numpy(), d['e_loc'])
+    report('chunked_benzene_256', {'walkers': int(r.shape[0]), 'workspace': info, **prof})
+    assert prof['frac_within_1e-5'] == 1.0 and prof['max'] < 1e-5, prof
+
+
+def test_three_states_c4h4_f32_local_energy_psi_ratio_overlap():
+    """BASELINE configs[4] on its own ansatz at LIBRARY DEFAULTS (float32 contexts, MFMA attention value path,
+    self-calibrated refinement): `compute_local_energy [1, 3, B]` (loss/energy.py:19-60), the psi-ratio matrix and the
+    overlap penalty (loss/overlap.py:40-149) for three parameter sets on the walkers of the c4h4_512 fixture, against the
+    oracle's float64 values (tests/golden/states_c4h4_transpsiformer.npz, made by make_states_fixture.py)."""
+    from deepqmc_amd import loss
+    from deepqmc_amd.wf import NeuralNetworkWaveFunction
+    path = os.path.join(ROOT, 'tests', 'golden', 'states_c4h4_transpsiformer.npz')
+    fx = np.load(path)
+    meta = json.loads(str(fx['meta']))
+    r_all = np.load(os.path.join(ROOT, 'tests', 'golden', meta['walkers_from']))['r']
+    mol = Molecule.from_name(meta['molecule'])
+    h = MolecularHamiltonian(mol=mol)
+    wf = NeuralNetworkWaveFunction(h, 'transpsiformer', dtype=torch.float32, device=DEV, norm_eps=geom.F32_EPS)
+    params = [wf.init(s, perturb_envelopes=meta['perturb_envelopes']) for s in meta['param_seeds']]
+    S, Be = 3, meta['b_eloc']
+    # --- local energies [1, 3, B]: state s on walkers [B s, B s + B) ---
+    r_e = torch.as_tensor(r_all[:S * Be].reshape(1, S, Be, h.n_elec, 3), device=DEV)
+    E, stats = loss.compute_local_energy(0, h, wf, params, r_e)
+    assert E.shape == (1, S, Be) and stats['hamil/E_kin'].shape == (1, S)
+    rel = np.abs(E[0].double().cpu().numpy() - fx['e_loc']) / np.maximum(1.0, np.abs(fx['e_loc']))
+    # --- psi ratios: three states x 170 walkers each ---
+    Bp = 170
+    r_p = torch.as_tensor(r_all[:S * Bp].reshape(1, S, Bp, h.n_elec, 3), device=DEV)
+    ratio = loss.compute_psi_ratio(wf, params, r_p)
+    assert ratio.shape == (1, S, S, Bp)
+    logs = fx['log'][:, :S * Bp].reshape(S, S, Bp)              # [i, j, b]: psi_i on the walkers of state j
+    signs = fx['sign'][:, :S * Bp].reshape(S, S, Bp).astype(np.float64)
+    shifted = logs - logs.mean(axis=(1, 2))[:, None, None]
+    dg = np.stack([shifted[j, j] for j in range(S)])
+    sdg = np.stack([signs[j, j] for j in range(S)])
+    ref = signs * sdg[None] * np.exp(shifted - dg[None])
+    got = ratio[0].cpu().numpy()
+    np.testing.assert_array_equal(np.sign(got), np.sign(ref))                     # sign work: bit-exact
+    rr = np.abs(got - ref) / np.abs(ref)
+    w = torch.ones(1, S, Bp, dtype=torch.float64, device=DEV)
+    pen, info = loss.compute_mean_overlap(ratio, w)
+    mean = ref.mean(-1)
+    sym = np.sign(mean) * np.sqrt(np.clip(mean * mean.T, 0, None))
+    pen_ref = sum(sym[i, j] ** 2 for i in range(S) for j in range(i + 1, S))
+    ov = info['overlap/pairwise/mean'][0].cpu().numpy()
+    # the value path behind the ratios in numbers: log|psi| of every (state, walker)
+    lg = np.stack([wf.engine(params[i]).wf_eval(r_p[0].reshape(S * Bp, h.n_elec, 3))[1].double().cpu().numpy() for i in range(S)])
+    lerr = np.abs(lg - fx['log'][:, :S * Bp])
+    report('three_states_c4h4_f32', {
+        'e_loc_rel_err': {'p50': float(np.median(rel)), 'max': float(rel.max()), 'frac_within_1e-5': float((rel < 1e-5).mean())},
+        'psi_ratio_rel_err': {'p50': float(np.median(rr)), 'p99': float(np.quantile(rr, 0.99)), 'max': float(rr.max())},
+        'logpsi_abs_err': {'p50': float(np.median(lerr)), 'p99': float(np.quantile(lerr, 0.99)), 'max': float(lerr.max())},
+        'overlap_abs_err_max': float(np.abs(ov - sym).max()), 'overlap_ref': sym.tolist(),
+        'penalty': float(pen), 'penalty_ref': float(pen_ref)})
+    assert (rel < 1e-5).all(), rel.max()                                          # the north-star tolerance on E_loc
+    # psi ratios are exp(differences of float32 log|psi| values of order 1e2): plain float32 value path, no refinement --
+    # the bound is what that path delivers (|d log psi| p99 < 1e-3, the value-path bound of the parity fixtures)
+    assert np.quantile(lerr, 0.99) < 1e-3 and np.quantile(rr, 0.99) < 2e-3 and rr.max() < 1e-2, (np.quantile(rr, 0.99), rr.max())
+    np.testing.assert_allclose(ov, sym, rtol=0, atol=2e-3 * max(1.0, np.abs(sym).max()))
+    np.testing.assert_allclose(float(pen), pen_ref, rtol=1e-2, atol=1e-6)

@@ -193,3 +193,24 @@ def test_inlib_rccl_allgather_single_rank():
         np.testing.assert_allclose(out['local_energy/std'], x.std(), rtol=1e-10)
     finally:
         comm.close()
+
+
+def test_inlib_rccl_allgather_two_ranks_through_bench():
+    """The multi-rank protocol on hardware when the node has it: `bench.py --gpus 2` (one process per GPU under
+    torch.distributed.run) reduces the energy statistics with ONE ncclAllGather inside the library on each context's stream
+    (`dqmc_energy_stats_allgather` over an `RcclCommunicator` whose unique id travels by one torch.distributed broadcast).
+    Skipped on a 1-GPU box (the gloo world-size-2 tests cover the host path there)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs >= 2 visible GPUs')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--walkers', '512', '--steps', '2', '--warmup', '1',
+                        '--repeats', '2', '--equilibrate', '50', '--no-cpu-baseline'], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 2 and out['n_ranks_seen'] == 2
+    assert out['config']['reduction'].startswith('in-library')
+    assert np.isfinite(out['energy']['local_energy/mean']) and out['energy']['local_energy/std'] > 0

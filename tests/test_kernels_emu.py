@@ -232,6 +232,7 @@ def test_emu_workspace_chunking():
     eng.set_option('fused', 0)
     eng.set_option('ws_budget_mb', 1)                 # ~2 walkers per chunk in Laplacian mode
     e1, st1, g1 = eng.local_energy(rt, return_grad=True)
+    assert eng.last_chunks()['own'] >= 2
     s1, l1 = eng.wf_eval(rt)
     np.testing.assert_array_equal(e1.numpy(), e0.numpy())
     np.testing.assert_array_equal(g1.numpy(), g0.numpy())
@@ -311,3 +312,36 @@ def test_emu_column_tiles_share_an_xcd_mapping():
     e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
     np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('molname,opts', [('N2', {}), ('LiH', {'lane_compact': 0})])
+def test_emu_chained_mlp_falls_back_to_two_layers(molname, opts):
+    """`analyse_chains` pairs the two layers of the row-wise MLPs from the layer widths alone; whether the chained
+    kernel really runs is decided per pass (kernel instances exist for 1 / 8 / 16 / 32 lanes and need parent and child in
+    the same lane layout).  PauliNet on N2 is a 48-lane Laplacian pass, and `lane_compact` 0 keeps the edge MLPs at full
+    lanes: the second layer must then run as an ordinary LINEAR op (round-3 advisor finding: it was skipped and the output
+    buffer stayed stale, E_loc -49.8 instead of -56.5)."""
+    import dataclasses
+    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=2, n_determinants=2) if molname == 'N2' else paulinet()
+    mol = Molecule.from_name(molname)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=4, perturb_envelopes=0.2)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+    eng.set_option('mlp_fuse', 0)
+    e0 = eng.local_energy(torch.as_tensor(r))[0]
+    np.testing.assert_allclose(e.numpy(), e0.numpy(), rtol=1e-11, atol=1e-11)
+    eng.set_option('fused', 0)                                   # layered value path (TP = 1: chained)
+    eng.set_option('mlp_fuse', 1)
+    val = it.run(r, mol.coords, laplacian=False)
+    sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+    np.testing.assert_array_equal(sign.numpy(), val['sign'])
+    np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)

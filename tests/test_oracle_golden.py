@@ -52,6 +52,26 @@ def test_hamil_init_golden(kats):
     assert h.mol_ecp_shells == [0, 0]
 
 
+def test_hamil_init_pp_golden(kats):
+    """reference tests/test_hamil.py:19-28 with `ecp_type='bfd'` (test_init_Molecular_PP_.npz): the integer logic of
+    hamil.py:119-142 -- default mask = charges > 2, valence counts = Z - n_core, electron / spin counts from them.  The
+    bfd table itself lives in pyscf (not available offline); what the golden fixes is independent of its coefficients:
+    lithium keeps one valence electron (n_core = 2), hydrogen is untouched."""
+    from deepqmc_amd.ecp import GaussianTypeECP
+    mol = Molecule.from_name('LiH')
+    li = [2, [[-1, [[], [[5.4, 1.0]], [[4.6, -4.6]], [[2.7, 5.4]]]], [0, [[], [], [[1.33, 6.75]]]]]]      # pyscf layout, n_core 2
+    h = MolecularHamiltonian(mol=mol, ecp_type='bfd', ecp_tables={'Li': li})
+    assert h.n_up == int(kats['hamil_init_Molecular_PP_n_up']) and h.n_down == int(kats['hamil_init_Molecular_PP_n_down'])
+    np.testing.assert_array_equal(h.ns_valence, kats['hamil_init_Molecular_PP_ns_valence'])
+    np.testing.assert_array_equal(h.ecp_mask, kats['hamil_init_Molecular_PP_pp_mask'])
+    assert isinstance(h.pot, GaussianTypeECP) and h.n_elec == 2
+    # an explicit mask overrides the default (hamil.py:122-125); no ECP atoms -> bare Coulomb, whatever ecp_type says
+    h2 = MolecularHamiltonian(mol=mol, ecp_type='bfd', ecp_mask=[False, False])
+    assert h2.pot is None and (h2.n_up, h2.n_down) == (2, 2)
+    with pytest.raises(AssertionError):
+        MolecularHamiltonian(mol=mol, ecp_type='bfd', ecp_mask=[True])
+
+
 def test_local_potential_golden(kats, lih_walker):
     # reference tests/test_potential.py (LiH, ecp None): -93.0144804569
     mol = Molecule.from_name('LiH')

@@ -128,3 +128,38 @@ def test_attention_query_blocks_are_independent():
         del os.environ['DQMC_ATTN_QSPLIT']
     np.testing.assert_array_equal(e0.numpy(), e1.numpy())
     np.testing.assert_array_equal(g0.numpy(), g1.numpy())
+
+
+@pytest.mark.parametrize('ansatz', ['psiformer', 'transpsiformer'])
+def test_attention_mfma_f64_two_row_blocks(ansatz):
+    """The float64 instance of the MFMA attention kernel (round 4: q0 and P held as A fragments in registers, dP scratch per
+    active wave) on 18 electrons -- two query row blocks, ragged second block, 56 of 64 lanes used, nuclear-token keys for
+    the TransPsiformer -- against the NumPy interpreter on every buffer, E_loc, gradient and psi."""
+    mol = Molecule(coords=np.array([[-1.3, 0.0, 0.0], [1.3, 0.0, 0.0]]), charges=np.array([9, 9]), charge=0, spin=0)
+    base = transpsiformer(mol.charges) if ansatz == 'transpsiformer' else psiformer()
+    spec = dataclasses.replace(base, embedding_dim=64, n_interactions=1, n_determinants=2)
+    h = MolecularHamiltonian(mol=mol)
+    assert h.n_elec == 18
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 1
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    eng.timing(True); eng.timing_reset()
+    from buffers_util import check_every_buffer
+    (e, stats, grad), _ = check_every_buffer(eng, it, B, lambda: eng.local_energy(torch.as_tensor(r), return_grad=True))
+    rep = eng.timing_report(); eng.timing(False)
+    assert 'attention' in rep
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+    # ... and bit-for-bit the same energies as the scalar kernel is NOT expected (different summation order): 1e-10
+    eng.set_option('attention_mfma', 0)
+    e0 = eng.local_energy(torch.as_tensor(r))[0]
+    np.testing.assert_allclose(e.numpy(), e0.numpy(), rtol=1e-10, atol=1e-10)
+    eng.set_option('attention_mfma', 1)
+    eng.set_option('fused', 0)
+    val = it.run(r, mol.coords, laplacian=False)
+    sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+    np.testing.assert_array_equal(sign.numpy(), val['sign'])
+    np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-11, atol=1e-11)
