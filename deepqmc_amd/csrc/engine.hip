@@ -167,7 +167,7 @@ struct Engine : dqmc_ctx {
   std::vector<int> mlp_child;
   std::vector<char> mlp_skip;
   int mlp_fuse = 1;
-  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0;   // LinArgs::cfg_*
+  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0, linear_f64_split = 1;   // LinArgs::cfg_*
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
@@ -665,6 +665,7 @@ struct Engine : dqmc_ctx {
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "linear_f64_nr1") { linear_f64_nr1 = value; return DQMC_OK; }
+    if (s == "linear_f64_split") { linear_f64_split = value; return DQMC_OK; }
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
@@ -1562,7 +1563,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_LINEAR: {
           dqmc::LinArgs<real> a{};
-          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1;
+          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1; a.cfg_f64_split = linear_f64_split;
           a.n_pieces = i[0];
           int ktot = 0, w_row = 0, n_bc = 0;
           for (int p = 0; p < i[0]; ++p) {

@@ -108,8 +108,10 @@ template <typename real> struct LdsSink {
 // `sink`.  MR x NR accumulator tiles; wave `wm` of the workgroup's M stack; col_w0 = first column of the wave's tile.
 template <typename real, int MR, int NR, int GPW, typename Sink>
 __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[MR][NR], const LinArgs<real>& a, const real* bias, int act,
-                                             int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink, int bx) {
-  constexpr bool HALF = GPW < 0;
+                                             int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink, int bx,
+                                             real* xch = nullptr) {
+  constexpr bool HALF = GPW == -1;
+  constexpr bool SPLIT = GPW == -2;
   constexpr int GB = GPW > 0 ? MR / GPW : 1;
   constexpr int BM = 64 * MR;
   const int lane = threadIdx.x & 63, cl = lane & 15;
@@ -160,6 +162,77 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, col_ok && (h ? g_ok[1] : g_ok[0]));
         }
       }
+    }
+  } else if (SPLIT) {
+    // A group of TP = 32 MR lanes spans the TWO waves of a pair (wm & 1 = which half of the lanes): the accumulators of a
+    // 96- / 128-lane group in float64 are 96 / 128 registers per column-block pair -- one wave per SIMD when one wave holds
+    // them all.  The chain rule needs the value lane (first half, lane 0) and sum_c J_c^2 over ALL derivative lanes: both
+    // cross the pair through `xch` (the A tile of the finished K loop).
+    const int half = wm & 1, gl = wm >> 1;
+    const int g = bx * 2 + gl;
+    const bool g_ok = g < n_groups;        // wave-uniform
+    const int b = (g_ok ? g : 0) / a.nrows;
+    const int t0 = half * (16 * MR);
+    sink.group(0, g_ok ? g : 0);
+    if (pre != nullptr && g_ok) {
+#pragma unroll
+      for (int n = 0; n < NR; ++n) {
+        const int col = col_w0 + n * 16 + cl;
+        if (col < ldw) {
+#pragma unroll
+          for (int tb = 0; tb < MR; ++tb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int t = t0 + tb * 16 + Mfma<real>::row_of(lane, rg);
+              acc[tb][n][rg] += pre[((long)b * a.TP + t) * a.ld_pre + col];
+            }
+        }
+      }
+    }
+    real* xv = xch + gl * (3 * NR * 16);
+    real* xs = xv + NR * 16;
+    __syncthreads();                       // every fragment read of the K loop is done: the A tile becomes the exchange area
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      real s_part = 0;
+#pragma unroll
+      for (int tb = 0; tb < MR; ++tb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int t = t0 + tb * 16 + Mfma<real>::row_of(lane, rg);
+          const real x = acc[tb][n][rg];
+          if (t >= 1 && t < a.T - 1) s_part += x * x;
+        }
+      const real Sh = quad_sum<real>(s_part);
+      if (lane < 16) {                     // (lanes 0..15 hold accumulator row 0 in register 0: the value lane of the first half)
+        xs[half * (NR * 16) + n * 16 + cl] = Sh;
+        if (half == 0) xv[n * 16 + cl] = acc[0][n][0];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      const int col = col_w0 + n * 16 + cl;
+      const bool col_ok = col < ldw;
+      real v = xv[n * 16 + cl];
+      if (bias != nullptr && col_ok) v += bias[col];
+      const real S = xs[n * 16 + cl] + xs[NR * 16 + n * 16 + cl];
+      real y, d1, d2;
+      act_derivs<real>(act, v, y, d1, d2);
+#pragma unroll
+      for (int tb = 0; tb < MR; ++tb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg);
+          const int t = t0 + tb * 16 + row;
+          const real x = acc[tb][n][rg];
+          real o;
+          if (t == 0) o = y;
+          else if (t < a.T - 1) o = d1 * x;
+          else if (t == a.T - 1) o = d1 * x + d2 * S;
+          else o = 0;
+          sink.put(0, t, wm * (16 * MR) + tb * 16 + row, col, o, col_ok && g_ok);
+        }
     }
   } else if (GPW > 0) {
 #pragma unroll
@@ -258,12 +331,15 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // stream their rows once) are bound by the latency of the chunk loads, not by bandwidth or MFMA rate -- each thread has
 // one 16-byte A load and one B load in flight per chunk; BKX = 2 doubles the bytes in flight per workgroup and halves
 // the number of load -> barrier -> multiply round trips.
+// (second launch bound = waves per SIMD the register allocation must leave room for: the split-group tiles exist to run
+// two waves per SIMD -- unconstrained, the 4 x 4 float64 tile takes 200 + 128 registers and one wave remains)
 template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1>
-__global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
+__global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
   constexpr int AS = BK + 2, BS = BStride<BN>::v;
-  constexpr bool HALF = GPW < 0;                        // 8-lane groups: two per row block
+  constexpr bool HALF = GPW == -1;                      // 8-lane groups: two per row block
+  constexpr bool SPLIT = GPW == -2;                     // 32 MR-lane groups held by a PAIR of waves (16 MR lanes each)
   constexpr int GB = GPW > 0 ? MR / GPW : 1;            // row blocks per group
   constexpr int APT = MR / WN;                          // A float4 per thread and chunk
   constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
@@ -271,6 +347,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
   constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
+  static_assert(!SPLIT || (!CHAIN && WN == 1 && 6 * NR * 16 <= BM * AS), "split groups: plain layers, one column tile per workgroup");
   typedef typename Mfma<real>::acc_t acc_t;
   __shared__ real As[BM * AS];
   __shared__ real Bs[BK * BS];
@@ -297,6 +374,10 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
       g = ((bx * 4 + w) * MR + rb) * 2 + ((row & 15) >> 3);
       t = row & 7;
+    } else if (SPLIT) {
+      const int w = row / (16 * MR), rb = (row >> 4) % MR;
+      g = bx * 2 + (w >> 1);
+      t = ((w & 1) * MR + rb) * 16 + (row & 15);
     } else if (GPW > 0) {
       const int w = row / (16 * MR), rb = (row >> 4) % MR;
       g = (bx * 4 + w) * GPW + rb / GB;
@@ -390,7 +471,7 @@ __global__ void __launch_bounds__(256 * WN) k_linear(const LinArgs<real> a) {
 
   if (!CHAIN) {
     HbmSink<real> sink(a);
-    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx);
+    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx, As);
     return;
   }
   // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there ----
@@ -459,7 +540,7 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 32;
   constexpr int AS = BK + 2, BSTR = BN + 4;
-  constexpr bool HALF = GPW < 0;
+  constexpr bool HALF = GPW == -1;
   constexpr int GB = GPW > 0 ? MR / GPW : 1;
   constexpr int APT = MR / WN;                                  // A rows per thread and chunk (two 16-byte loads each)
   constexpr int NBI = ((BK / 2) * (BN / 4) + NT - 1) / NT;       // B items (2 k rows x 4 columns) per thread and chunk
@@ -719,7 +800,8 @@ template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
 template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg(hipStream_t st, const LinArgs<real>& a) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   const long n_groups = (long)a.B * a.nrows;
-  const unsigned gx = GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
+  const unsigned gx = GPW == -2 ? (unsigned)((n_groups + 1) / 2)
+                      : GPW < 0 ? (unsigned)((n_groups + 8 * MR - 1) / (8 * MR))
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
   if (BfLaunch<real, MR, NR, GPW, WN>::run(st, a, gx, gy)) return;
@@ -767,6 +849,23 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
   else launch_cfg<real, MR, 1, GPW, 1>(st, a);
 }
 
+// float64, 96- / 128-lane groups (28 / 42 electrons: what the refinement twin of the attention ansatzes runs): with one wave
+// per group the accumulators of MR = 6 / 8 row blocks x 2 column blocks alone are 96 / 128 registers, the kernel needs
+// 282 / 362 and ONE wave per SIMD remains (a quarter of the time of a benzene step at ~55 % of the f64 MFMA peak).
+// Split groups (GPW = -2): a PAIR of waves holds a group, 3 / 4 row blocks each, FOUR column blocks (the A tile of a chunk
+// feeds 64 columns instead of 32: half the L2 -> LDS traffic per flop); value lane and sum_c J_c^2 cross the pair through
+// LDS in the epilogue.  Option "linear_f64_split" (default 1) / LinArgs::cfg_f64_split.
+template <typename real, int MRH> static bool launch_split(hipStream_t st, const LinArgs<real>& a) {
+  if constexpr (sizeof(real) == 8) {
+    if (!a.cfg_f64_split) return false;
+    if (a.ldw > 32) launch_cfg<real, MRH, 4, -2, 1>(st, a);
+    else if (a.ldw > 16) launch_cfg<real, MRH, 2, -2, 1>(st, a);
+    else launch_cfg<real, MRH, 1, -2, 1>(st, a);
+    return true;
+  }
+  return false;
+}
+
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
     case 1: {
@@ -798,8 +897,8 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
     case 32: launch_nr<real, 2, 1>(st, a); break;      // (H2O / PauliNet, 4096 walkers: E_loc-only +3 % against <4, 2>)
     case 48: launch_nr<real, 3, 1>(st, a); break;
     case 64: launch_nr<real, 4, 1>(st, a); break;
-    case 96: launch_nr<real, 6, 1>(st, a); break;
-    case 128: launch_nr<real, 8, 1>(st, a); break;
+    case 96: if (!launch_split<real, 3>(st, a)) launch_nr<real, 6, 1>(st, a); break;
+    case 128: if (!launch_split<real, 4>(st, a)) launch_nr<real, 8, 1>(st, a); break;
     default: break;  // rejected by the engine before launch (lanes_supported)
   }
 }

@@ -114,3 +114,18 @@ def batch_local_energy(params, spec, r: torch.Tensor, R: torch.Tensor, charges, 
         qfs.append(qf.detach())
     out = {k: torch.stack([s[k] for s in stats]) for k in stats[0]}
     return torch.stack(es), out, torch.stack(qfs)
+
+
+def evaluate_spin(params, spec, r: torch.Tensor, R: torch.Tensor, n_up: int, n_down: int, eps: float) -> torch.Tensor:
+    """Reference physics.py:159-226 for ONE walker r[N,3], read literally: the constant term, then for every down
+    electron beta and every up electron alpha the ratio of the wave function with the two positions exchanged."""
+    umd = n_up - n_down
+    s2 = torch.tensor(umd / 2 * (umd / 2 + 1) + n_down, dtype=torch.float64)        # physics.py:168
+    s0, l0 = owf.wave_function(params, spec, r, R, n_up, eps)                       # physics.py:171
+    for down_idx in range(n_up, n_up + n_down):                                     # physics.py:174-176
+        for up_idx in range(n_up):                                                  # physics.py:224-226
+            perm = list(range(r.shape[0]))                                          # physics.py:206-211
+            perm[down_idx], perm[up_idx] = up_idx, down_idx
+            sp, lp = owf.wave_function(params, spec, r[perm], R, n_up, eps)
+            s2 = s2 - s0 * sp * torch.exp(lp - l0)                                  # physics.py:218-222
+    return s2

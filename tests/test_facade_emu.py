@@ -211,3 +211,34 @@ def test_enqueue_ahead_refinement_matches_the_synchronous_path():
         for k in ss:
             np.testing.assert_array_equal(ss[k].numpy(), sa[k].numpy())
     assert 0 < (es.numpy() != e0.numpy()).sum() <= sync.last_refined()      # and refined walkers did change
+
+
+@pytest.mark.parametrize('molname,ansatz', [('LiH', 'paulinet'), ('C', 'ferminet')])
+def test_evaluate_spin_matches_the_reference_loop(molname, ansatz):
+    """`evaluate_spin` (reference physics.py:159-226): all n_up n_down swapped configurations of a walker batch as ONE
+    value-only evaluation through the (emulated) HIP engine against the oracle's literal double loop per walker; the carbon
+    atom is spin-polarised (4 up / 2 down: a non-zero constant term).  For a determinant-based ansatz <S^2> of a sample
+    is not an eigenvalue, so the check is the estimator, not a number."""
+    from deepqmc_amd.physics import evaluate_spin, make_stochastic_spin_raising_operator
+    from oracle import physics as ophys
+    from oracle import wf as owf
+    h = MolecularHamiltonian(mol=Molecule.from_name(molname))
+    wf = NeuralNetworkWaveFunction(h, ansatz, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    params = wf.init(2, perturb_envelopes=0.1)
+    B = 3
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=6))
+    s2 = evaluate_spin(h, wf)(params, r)
+    p = owf.to_torch(params)
+    T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+    ref = torch.stack([ophys.evaluate_spin(p, wf.spec, r[b], T(h.mol.coords), h.n_up, h.n_down, geom.F32_EPS) for b in range(B)])
+    np.testing.assert_allclose(s2.numpy(), ref.numpy(), rtol=1e-9, atol=1e-10)
+    # the stochastic estimator: <S^2> = const + sum over down electrons of (raising-operator value - 1)
+    op = make_stochastic_spin_raising_operator(h, wf)
+    umd = h.n_up - h.n_down
+    tot = torch.full((B,), umd / 2 * (umd / 2 + 1) + h.n_down, dtype=torch.float64)
+    for d in range(h.n_up, h.n_up + h.n_down):
+        tot = tot + op(params, r, d) - 1.0
+    np.testing.assert_allclose(tot.numpy(), s2.numpy(), rtol=1e-10, atol=1e-10)
+    per_walker = op(params, PhysicalConfiguration(torch.as_tensor(h.mol.coords), r, None), torch.tensor([h.n_up, h.n_up + h.n_down - 1, h.n_up]))
+    np.testing.assert_allclose(per_walker[0].item(), op(params, r[:1], h.n_up)[0].item(), rtol=1e-12)
+    np.testing.assert_allclose(per_walker[1].item(), op(params, r[1:2], h.n_up + h.n_down - 1)[0].item(), rtol=1e-12)

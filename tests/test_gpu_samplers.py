@@ -214,3 +214,24 @@ def test_inlib_rccl_allgather_two_ranks_through_bench():
     assert out['n_gpus'] == 2 and out['n_ranks_seen'] == 2
     assert out['config']['reduction'].startswith('in-library')
     assert np.isfinite(out['energy']['local_energy/mean']) and out['energy']['local_energy/std'] > 0
+
+
+def test_evaluate_spin_on_device():
+    """`evaluate_spin` (reference physics.py:159-226) through the HIP value path on the device: float64 against the oracle's
+    literal loop; float32 (the fused LDS-resident kernel, 4096 x 4 swapped configurations in one launch) against float64."""
+    from deepqmc_amd.physics import evaluate_spin
+    from oracle import physics as ophys
+    h, wf = make('LiH', 'paulinet')
+    params = wf.init(2, perturb_envelopes=0.1)
+    B = 6
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=6), device=DEV)
+    s2 = evaluate_spin(h, wf)(params, r)
+    p = owf.to_torch(params)
+    ref = torch.stack([ophys.evaluate_spin(p, wf.spec, r[b].cpu(), T(h.mol.coords), h.n_up, h.n_down, geom.F32_EPS) for b in range(B)])
+    np.testing.assert_allclose(s2.cpu().numpy(), ref.numpy(), rtol=1e-9, atol=1e-10)
+    h32, wf32 = make('LiH', 'paulinet', dtype=torch.float32)
+    big = torch.as_tensor(synthetic_walkers(h, 4096, seed=7), device=DEV)
+    a = evaluate_spin(h32, wf32)(params, big.float())
+    b = evaluate_spin(h, wf)(params, big.float().double())
+    err = ((a - b).abs() / b.abs().clamp(min=1.0)).cpu().numpy()
+    assert np.quantile(err, 0.99) < 1e-3 and np.median(err) < 1e-5, (np.median(err), np.quantile(err, 0.99))

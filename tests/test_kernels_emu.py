@@ -345,3 +345,30 @@ def test_emu_chained_mlp_falls_back_to_two_layers(molname, opts):
     sign, logpsi = eng.wf_eval(torch.as_tensor(r))
     np.testing.assert_array_equal(sign.numpy(), val['sign'])
     np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize('z,emb', [(14, 64), (19, 32), (14, 16)])
+def test_emu_f64_split_group_linear(z, emb):
+    """float64 layers over 96- / 128-lane groups (28 / 38 electrons): a PAIR of waves holds one (walker, row) group
+    (kernel_linear.hip: GPW = -2), the value lane and sum_c J_c^2 cross the pair through LDS in the epilogue -- four, two
+    and one column block per wave -- against the interpreter, and against the one-wave-per-group tiles (option
+    "linear_f64_split" 0)."""
+    import dataclasses
+    mol = Molecule(coords=np.array([[-1.4, 0.0, 0.0], [1.4, 0.0, 0.0]]), charges=np.array([z, z]), charge=0, spin=0)
+    spec = dataclasses.replace(ferminet(), embedding_dim=emb, n_interactions=1, n_determinants=1, two_particle_dim=8)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=4, perturb_envelopes=0.2)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 3                                     # 3 walkers x N rows: an odd number of groups, the last workgroup half empty
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    assert eng.lib.dqmc_debug_lanes(eng._ctx) in (0, 1)
+    e, stats, grad = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    assert eng.lib.dqmc_debug_lanes(eng._ctx) == (96 if z == 14 else 128)
+    np.testing.assert_allclose(e.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(grad.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
+    eng.set_option('linear_f64_split', 0)
+    e0, _, g0 = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    np.testing.assert_allclose(e.numpy(), e0.numpy(), rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(grad.numpy(), g0.numpy(), rtol=1e-10, atol=1e-10)
