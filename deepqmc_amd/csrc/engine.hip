@@ -68,11 +68,13 @@ struct dqmc_ctx {
   virtual int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
+  virtual dqmc_ctx* twin_ctx() { return nullptr; }     // the float64 refinement twin of a float32 context, once it exists
   int last_TP = 0;
   bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
   bool ecp_skip_nl = false; // ... and no non-local ECP quadrature
   int last_refined = 0;     // walkers re-evaluated in float64 by the last local-energy / psi_grad call
   double refine_info[4] = {0, 0, 0, 0};   // {mode, score threshold, measured error per unit of score, direct float64 calls left}
+  int64_t ecp_last_counts[3] = {0, 0, 0};   // (nucleus, electron) pairs of the last mixed-precision quadrature: float32, float64, dropped
   int last_chunks[2] = {0, 0};   // walker chunks of the last Laplacian-mode evaluation: this context's own pass, its float64 twin's (max over its passes)
   int device = 0;           // every entry point makes this the calling thread's current device
   double* d_gather = nullptr;   // all-gathered energy records (dqmc_energy_stats_allgather)
@@ -219,6 +221,14 @@ struct Engine : dqmc_ctx {
   int ecp_nl_L_h = 0, ecp_nl_nt_h = 0;
   char* d_ecp = nullptr;        // quadrature walkers + their psi + psi of the walkers themselves
   size_t ecp_bytes = 0;
+  // mixed-precision quadrature of a float32 context (ecp_mixed): "ecp_mixed" 1 (default) with "refine" 1; a triple whose
+  // weight w = max_l (2l+1)|V_l| exceeds ecp_w_heavy ("ecp_heavy_e6", in 1e-6 Ha) gets float64 psi ratios, one below
+  // ecp_w_skip ("ecp_skip_e12", in 1e-12 Ha) is dropped
+  int ecp_mixed_on = 1;
+  bool ecp_defer = false;       // set while lap_refined_core runs for a call whose quadrature follows in ecp_mixed
+  double ecp_w_heavy = 1e-2, ecp_w_skip = 1e-10;
+  char* d_ecpm = nullptr;
+  size_t ecpm_bytes = 0;
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
   // float64 refinement (float32 build): walkers flagged by k_final as ill conditioned (near a node of psi the kinetic
   // energy is a difference of huge numbers and float32 round-off is amplified by the CI cancellation) are
@@ -298,6 +308,7 @@ struct Engine : dqmc_ctx {
   std::vector<double> ph_loc_h, ph_l2_h;      // host copies for the float64 twin
   std::vector<int32_t> ph_mask_h;
   dqmc_ctx* twin = nullptr;
+  dqmc_ctx* twin_ctx() override { return twin; }
   int32_t* d_flag = nullptr;     // [0] = count, [1..] = walker indices
   double* d_score = nullptr;     // [B] error predictor of the last flagged pass
   size_t flag_cap = 0;
@@ -333,6 +344,7 @@ struct Engine : dqmc_ctx {
     if (d_ph_l2) (void)hipFree(d_ph_l2);
     if (d_ph_nuc) (void)hipFree(d_ph_nuc);
     if (d_ecp) (void)hipFree(d_ecp);
+    if (d_ecpm) (void)hipFree(d_ecpm);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (d_w) (void)hipFree(d_w);
     if (d_it) (void)hipFree(d_it);
@@ -706,6 +718,9 @@ struct Engine : dqmc_ctx {
           }
       return DQMC_OK;
     }
+    if (s == "ecp_mixed") { ecp_mixed_on = value; return DQMC_OK; }
+    if (s == "ecp_heavy_e6") { if (value < 0) return fail(DQMC_E_ARG, "ecp_heavy_e6 must be >= 0"); ecp_w_heavy = 1e-6 * value; return DQMC_OK; }
+    if (s == "ecp_skip_e12") { if (value < 0) return fail(DQMC_E_ARG, "ecp_skip_e12 must be >= 0"); ecp_w_skip = 1e-12 * value; return DQMC_OK; }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
     if (s == "fused_dbg") {
@@ -1770,7 +1785,7 @@ struct Engine : dqmc_ctx {
   // the pass in this context's own precision: forward-Laplacian evaluation, plus the non-local ECP quadrature when the
   // Hamiltonian has one and a local energy is asked for
   int pass_own(const real* r, const real* R, int B, real* logpsi, int32_t* sign, real* e_loc, real* stats, real* grad) {
-    if (ecp_n_nl == 0 || !e_loc || ecp_skip_nl) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
+    if (ecp_n_nl == 0 || !e_loc || ecp_skip_nl || ecp_defer) return run(r, R, B, true, logpsi, sign, e_loc, stats, grad);
     return local_energy_ecp(r, R, B, e_loc, stats, grad, logpsi, sign);
   }
 
@@ -1796,6 +1811,7 @@ struct Engine : dqmc_ctx {
     for (size_t k = 0; k < twin_opts.size() && !rc; ++k) rc = t->option(twin_opts[k].first.c_str(), twin_opts[k].second);
     if (rc) { delete t; return rc; }
     t->ws_budget = twin_full_budget ? ws_budget : ws_budget / 2;
+    t->timing = timing;
     twin = t;
     return DQMC_OK;
   }
@@ -1826,7 +1842,7 @@ struct Engine : dqmc_ctx {
     // a Hamiltonian with a non-local ECP: the twin runs the quadrature of its walkers in float64 with the rotation angles
     // of the walkers they stand for (its psi ratios carry the float64 value path's accuracy: float32 ratios alone put
     // ~1e-4 relative on E_loc of a 30-electron Psiformer)
-    twin->ecp_skip_nl = (e_loc == nullptr);
+    twin->ecp_skip_nl = (e_loc == nullptr) || ecp_defer;      // (deferred: ecp_mixed adds V_nl to every walker afterwards)
     static_cast<Engine<double>*>(twin)->ecp_seed = ecp_seed;
     static_cast<Engine<double>*>(twin)->ecp_phi = ecp_phi;
     static_cast<Engine<double>*>(twin)->ecp_phi_f32 = true;
@@ -1879,6 +1895,77 @@ struct Engine : dqmc_ctx {
     return rc;
   }
   int lap_refined_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
+    if constexpr (sizeof(real) == 4) {
+      if (refine == 1 && ecp_mixed_on && ecp_n_nl > 0 && e_loc && !ecp_skip_nl) {
+        // kinetic part first (float32 pass, flagged walkers re-run in float64 WITHOUT the quadrature), then V_nl of every
+        // walker with the precision chosen per (nucleus, electron) pair
+        ecp_defer = true;
+        int rc = lap_refined_core(r, R, B, e_loc, stats, grad, logpsi, sign);
+        ecp_defer = false;
+        if (rc) return rc;
+        return ecp_mixed((const float*)r, (const float*)R, B, (float*)e_loc, (float*)stats);
+      }
+    }
+    return lap_refined_core(r, R, B, e_loc, stats, grad, logpsi, sign);
+  }
+  // Non-local ECP term of a float32 context with per-pair precision (kernels_ecp.hip: "mixed-precision quadrature"):
+  // added to e_loc, stored in stats[3].
+  int ecp_mixed(const float* r, const float* R, int B, float* e_loc, float* stats) {
+    int rc = ensure_twin();
+    if (rc) return rc;
+    const size_t per_walker = (size_t)ecp_n_nl * N * 12, triples_pw = (size_t)ecp_n_nl * N;
+    int nbw = (int)(ecp_max_cfg / per_walker);
+    nbw = nbw < 1 ? 1 : (nbw > B ? B : nbw);
+    const size_t n_cfg = (size_t)nbw * (per_walker + 1), n_tr = (size_t)nbw * triples_pw;
+    auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+    const size_t o_cls = 0, o_ll = o_cls + al(4 * n_tr), o_lh = o_ll + al(4 * n_tr), o_cnt = o_lh + al(4 * n_tr),
+                 o_r32 = o_cnt + 256, o_l32 = o_r32 + al(4 * n_cfg * N * 3), o_s32 = o_l32 + al(4 * n_cfg),
+                 o_r64 = o_s32 + al(4 * n_cfg), o_l64 = o_r64 + al(8 * n_cfg * N * 3), o_s64 = o_l64 + al(8 * n_cfg),
+                 o_R64 = o_s64 + al(4 * n_cfg), tot = o_R64 + al(8 * 3 * (size_t)sys.n_nuc);
+    if (tot > ecpm_bytes) {
+      if (d_ecpm) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_ecpm)); d_ecpm = nullptr; ecpm_bytes = 0; }
+      hipError_t e = hipMalloc((void**)&d_ecpm, tot);
+      if (e != hipSuccess) return fail(DQMC_E_NOMEM, "ECP scratch of " + std::to_string(tot) + " bytes: " + hipGetErrorString(e));
+      ecpm_bytes = tot;
+    }
+    int32_t* cls = (int32_t*)(d_ecpm + o_cls); int32_t* list_l = (int32_t*)(d_ecpm + o_ll); int32_t* list_h = (int32_t*)(d_ecpm + o_lh);
+    int32_t* cnt = (int32_t*)(d_ecpm + o_cnt);
+    float* rq32 = (float*)(d_ecpm + o_r32); float* lq32 = (float*)(d_ecpm + o_l32); int32_t* sq32 = (int32_t*)(d_ecpm + o_s32);
+    double* rq64 = (double*)(d_ecpm + o_r64); double* lq64 = (double*)(d_ecpm + o_l64); int32_t* sq64 = (int32_t*)(d_ecpm + o_s64);
+    double* R64 = (double*)(d_ecpm + o_R64);
+    dqmc::launch_refine_gather(st, r, R, nullptr, nullptr, 0, 3 * N, 3 * sys.n_nuc, nullptr, R64);      // (widens R only)
+    dqmc::EcpMixArgs a{};
+    a.r = r; a.R = R; a.nl_nuc = d_ecp_nuc; a.nl = d_ecp_nl; a.phi = (const float*)ecp_phi; a.seed = ecp_seed;
+    a.B = B; a.N = N; a.n_nl = ecp_n_nl; a.L = ecp_L; a.n_t = ecp_nt_nl;
+    a.w_heavy = ecp_w_heavy; a.w_skip = ecp_w_skip;
+    ecp_last_counts[0] = ecp_last_counts[1] = ecp_last_counts[2] = 0;
+    for (int b0 = 0; b0 < B; b0 += nbw) {
+      a.b0 = b0; a.nb = (B - b0) < nbw ? (B - b0) : nbw;
+      HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int32_t), st));
+      t_begin("ecp", 0);
+      dqmc::launch_ecp_classify(st, a, cls, list_l, list_h, cnt);
+      t_end();
+      int32_t n2[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(n2, cnt, sizeof(n2), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      ecp_last_counts[0] += n2[0]; ecp_last_counts[1] += n2[1];
+      ecp_last_counts[2] += (long)a.nb * (long)triples_pw - n2[0] - n2[1];
+      t_begin("ecp", 0);
+      dqmc::launch_ecp_points_list<float>(st, a, list_l, n2[0], rq32);
+      dqmc::launch_ecp_points_list<double>(st, a, list_h, n2[1], rq64);
+      t_end();
+      rc = run((const real*)rq32, (const real*)R, a.nb + 12 * n2[0], false, (real*)lq32, sq32, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      rc = twin->wf_eval(rq64, R64, a.nb + 12 * n2[1], lq64, sq64);
+      if (rc) return rc;
+      t_begin("ecp", 0);
+      dqmc::launch_ecp_reduce_mixed(st, a, cls, lq32, sq32, lq64, sq64, e_loc, stats);
+      t_end();
+    }
+    HIP_TRY(hipGetLastError());
+    return DQMC_OK;
+  }
+  int lap_refined_core(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     last_refined = 0;
     if constexpr (sizeof(real) == 8) {
       return pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
@@ -2634,6 +2721,11 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
+int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3) {
+  if (!ctx || !out3) return DQMC_E_ARG;
+  for (int k = 0; k < 3; ++k) out3[k] = ctx->ecp_last_counts[k];
+  return DQMC_OK;
+}
 int dqmc_last_chunks(dqmc_ctx* ctx, int* out2) {
   if (!ctx || !out2) return DQMC_E_ARG;
   out2[0] = ctx->last_chunks[0]; out2[1] = ctx->last_chunks[1];
@@ -2650,20 +2742,30 @@ int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
   return ctx->option(name, value);
 }
 
+// Per-launch HIP-event timing.  The records of a float32 context's float64 refinement twin are reported under the same
+// names with the prefix "f64." ("f64.linear", "f64.attention", ...).
 int dqmc_timing_enable(dqmc_ctx* ctx, int enable) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");
   ctx->t_collect();
   ctx->timing = enable != 0;
+  if (dqmc_ctx* t = ctx->twin_ctx()) { t->t_collect(); t->timing = enable != 0; }
   return DQMC_OK;
 }
 int dqmc_timing_reset(dqmc_ctx* ctx) {
   if (!ctx) return fail(DQMC_E_ARG, "null argument");
   ctx->t_collect();
   ctx->trec.clear();
+  if (dqmc_ctx* t = ctx->twin_ctx()) { t->t_collect(); t->trec.clear(); }
   return DQMC_OK;
 }
 int dqmc_timing_get(dqmc_ctx* ctx, const char* name, double* ms, int64_t* launches, double* flops) {
   if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");
+  if (!std::strncmp(name, "f64.", 4)) {
+    dqmc_ctx* t = ctx->twin_ctx();
+    if (t) return dqmc_timing_get(t, name + 4, ms, launches, flops);
+    if (ms) *ms = 0; if (launches) *launches = 0; if (flops) *flops = 0;
+    return DQMC_OK;
+  }
   ctx->t_collect();
   auto it = ctx->trec.find(name);
   TimingRec r = it == ctx->trec.end() ? TimingRec{} : it->second;
@@ -2677,6 +2779,10 @@ int dqmc_timing_names(dqmc_ctx* ctx, char* out, size_t n) {
   ctx->t_collect();
   std::string s;
   for (auto& kv : ctx->trec) { if (!s.empty()) s += ","; s += kv.first; }
+  if (dqmc_ctx* t = ctx->twin_ctx()) {
+    t->t_collect();
+    for (auto& kv : t->trec) { if (!s.empty()) s += ","; s += "f64." + kv.first; }
+  }
   std::snprintf(out, n, "%s", s.c_str());
   return DQMC_OK;
 }

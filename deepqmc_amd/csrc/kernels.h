@@ -258,6 +258,22 @@ struct EcpArgs {
   int B, N, n_nl, L, n_t;
   int b0, nb;              // walker chunk of this launch
 };
+// mixed-precision quadrature of a float32 context (kernels_ecp.hip)
+struct EcpMixArgs {
+  const float* r;          // float[B][N][3], all walkers of the caller
+  const float* R;          // float[n_nuc][3]
+  const int32_t* nl_nuc;
+  const double* nl;
+  const float* phi;        // float[B][n_nl][N] rotation angles, or nullptr: Philox(seed)
+  uint64_t seed;
+  int B, N, n_nl, L, n_t;
+  int b0, nb;              // walker chunk of this launch
+  double w_heavy, w_skip;  // class bounds on w = max_l (2l+1) |V_l(r_ia)|
+};
+void launch_ecp_classify(hipStream_t st, const EcpMixArgs& a, int32_t* cls, int32_t* list_l, int32_t* list_h, int32_t* counts);
+template <typename real_out> void launch_ecp_points_list(hipStream_t st, const EcpMixArgs& a, const int32_t* list, int n_list, real_out* rq);
+void launch_ecp_reduce_mixed(hipStream_t st, const EcpMixArgs& a, const int32_t* cls, const float* lq32, const int32_t* sq32,
+                             const double* lq64, const int32_t* sq64, float* e_loc, float* stats);
 template <typename real> void launch_ecp_points(hipStream_t st, const EcpArgs& a, real* rq);
 template <typename real>
 void launch_ecp_reduce(hipStream_t st, const EcpArgs& a, const real* logq, const int32_t* signq, const real* log0,

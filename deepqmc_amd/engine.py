@@ -335,6 +335,12 @@ class Engine:
         self._check(self.lib.dqmc_last_chunks(self._ctx, out))
         return {'own': int(out[0]), 'twin': int(out[1])}
 
+    def ecp_counts(self) -> dict:
+        """(nucleus, electron) pairs of the last mixed-precision ECP quadrature by class (dqmc_ecp_counts)."""
+        out = (ctypes.c_int64 * 3)()
+        self._check(self.lib.dqmc_ecp_counts(self._ctx, out))
+        return {'f32': int(out[0]), 'f64': int(out[1]), 'dropped': int(out[2])}
+
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
 

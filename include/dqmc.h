@@ -272,6 +272,13 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * whose activations exceed "ws_budget_mb" is split into chunks inside the library (the reference has no such limit to
  * replace: its vmap over the electron batch, loss/energy.py:50-57, simply needs the memory). */
 int dqmc_last_chunks(dqmc_ctx* ctx, int* out2);
+/* Non-local ECP term of a float32 context (replaces nonloc_potential, ecp/gaussian_type_ecp.py:161-255, for a whole
+ * batch): with "refine" 1 the 12-point quadrature of every (walker, ECP nucleus, electron) triple runs in the precision its
+ * weight w = max_l (2l+1)|V_l(|r_i - R_a|)| calls for -- float64 psi ratios above "ecp_heavy_e6" (default 10000 = 1e-2 Ha),
+ * float32 below, none below "ecp_skip_e12" (default 100 = 1e-10 Ha: the contribution is below that times the mean ratio);
+ * "ecp_mixed" 0 restores whole-walker float64 quadrature for flagged walkers only.  out3 = triples of the last call
+ * {float32, float64, dropped}. */
+int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
 /* Tuning / debugging switches.  "fused" (default 1): evaluate value-only psi (dqmc_wf_eval,
  * MCMC) with the single LDS-resident kernel instead of one launch per op where that is the faster path
  * (N <= 4, or fewer than 1024 walkers; 2 = always, 0 = never, which also keeps every

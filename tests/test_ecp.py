@@ -114,3 +114,49 @@ def test_hip_ecp_matches_oracle_two_centres():
     t['H'] = [0, [TABLES['H'][1][0], [0, [[], [], [[0.7, 0.3]]]]]]
     h, stats = _hip_vs_oracle([True, True], t, B=1)
     assert h.n_elec == 4 and len(h.pot.nuc_with_nl_pot) == 2
+
+
+def test_mixed_precision_quadrature_classes():
+    """float32 context, library defaults ("refine" 1, "ecp_mixed" 1): the non-local term of every walker is assembled from
+    psi ratios whose precision follows the radial weight w = max_l (2l+1)|V_l(r_ia)| of the (nucleus, electron) pair
+    (kernels_ecp.hip).  Through the emulator: all pairs float64 / all float32 / the default split, against the float64
+    engine on the same walkers and angles; the classes partition the pairs; repeated calls are bit-identical."""
+    mol = Molecule.from_name('LiH')
+    t = dict(TABLES)
+    t['Li'] = [0, TABLES['Li'][1]]                          # 4 electrons, non-local channels on Li
+    h = MolecularHamiltonian(mol=mol, ecp_type='synthetic', ecp_mask=[True, False], ecp_tables=t)
+    mk = lambda dt: NeuralNetworkWaveFunction(h, 'paulinet', dtype=dt, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    wf32, wf64 = mk(torch.float32), mk(torch.float64)
+    params = wf32.init(0, perturb_envelopes=0.1)
+    B, N = 3, h.n_elec
+    r = synthetic_walkers(h, B, seed=5).astype(np.float32)
+    r[0, 0] = mol.coords[0] + np.array([6.5, 0.3, -0.2])     # one electron far from the Li core: a negligible pair
+    n_nl = len(h.pot.nuc_with_nl_pot)
+    phi = np.random.default_rng(1).uniform(0, math.pi / 5, (B, n_nl, N)).astype(np.float32)
+    # reference: the float64 engine at the float32-rounded geometry a float32 context sees
+    from deepqmc_amd.types import PhysicalConfiguration
+    R32 = torch.as_tensor(mol.coords.astype(np.float32).astype(np.float64))
+    e64, st64 = wf64.engine(params, R32).local_energy(PhysicalConfiguration(R32, torch.as_tensor(r.astype(np.float64)), None),
+                                                      ecp_phi=torch.as_tensor(phi.astype(np.float64)))
+    v64 = st64['hamil/V_nl'].numpy()
+    eng = wf32.engine(params)
+    n_pairs = B * n_nl * N
+    out = {}
+    for name, opts in (('all_f64', {'ecp_heavy_e6': 0, 'ecp_skip_e12': 0}), ('all_f32', {'ecp_heavy_e6': 2_000_000_000, 'ecp_skip_e12': 0}),
+                       ('default', {'ecp_heavy_e6': 10_000, 'ecp_skip_e12': 100})):
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        e, st = eng.local_energy(torch.as_tensor(r), ecp_phi=torch.as_tensor(phi))
+        c = eng.ecp_counts()
+        assert c['f32'] + c['f64'] + c['dropped'] == n_pairs, c
+        out[name] = (st['hamil/V_nl'].numpy().astype(np.float64), c, e)
+    e2, st2 = eng.local_energy(torch.as_tensor(r), ecp_phi=torch.as_tensor(phi))
+    assert torch.equal(out['default'][2], e2) and np.array_equal(out['default'][0], st2['hamil/V_nl'].numpy().astype(np.float64))
+    assert out['all_f64'][1]['f64'] == n_pairs and out['all_f32'][1]['f32'] == n_pairs
+    d = out['default'][1]
+    assert d['f64'] > 0 and d['dropped'] >= 1, d            # the far electron's pair is dropped, the core-near ones are float64
+    np.testing.assert_allclose(out['all_f64'][0], v64, rtol=2e-6, atol=2e-7)          # float32 output rounding of float64 ratios
+    np.testing.assert_allclose(out['all_f32'][0], v64, rtol=2e-3, atol=2e-4)          # the float32 value path's ratios
+    np.testing.assert_allclose(out['default'][0], v64, rtol=2e-3, atol=2e-4)
+    # what the classes are for: the default is at least as close to float64 as all-float32 on the batch
+    assert np.abs(out['default'][0] - v64).max() <= np.abs(out['all_f32'][0] - v64).max() + 1e-7

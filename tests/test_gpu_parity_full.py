@@ -263,10 +263,15 @@ def test_three_states_c4h4_local_energy_psi_ratio_overlap(dtype):
     params = [wf.init(s, perturb_envelopes=meta['perturb_envelopes']) for s in meta['param_seeds']]
     S, Be = 3, meta['b_eloc']
     # --- local energies [1, 3, B]: state s on walkers [B s, B s + B) ---
-    # the fixture was evaluated at the float32-rounded geometry (what a float32 context sees): float64 contexts get it explicitly
-    from deepqmc_amd.types import PhysicalConfiguration
-    Rr = torch.as_tensor(mol.coords.astype(np.float32).astype(np.float64), device=DEV) if dtype == 'f64' else None
-    pc = (lambda r: PhysicalConfiguration(Rr[None], r, None)) if dtype == 'f64' else (lambda r: r)
+    # The fixture is what a float32 context sees: the nuclear stream folded on the host at the Hamiltonian's geometry, the
+    # electron-nucleus features at the float32-ROUNDED geometry.  With cond(A) ~ 1e6 that rounding moves log|psi| by ~1e-3,
+    # so the float64 contexts are given exactly the same view (their run-time R replaced by the rounded one).
+    if dtype == 'f64':
+        for p_ in params:
+            eng_ = wf.engine(p_)
+            eng_.R = torch.as_tensor(mol.coords.astype(np.float32).astype(np.float64), device=DEV)
+    Rr = None
+    pc = lambda r: r
     r_e = torch.as_tensor(r_all[:S * Be].reshape(1, S, Be, h.n_elec, 3), dtype=tdt, device=DEV)
     E, stats = loss.compute_local_energy(0, h, wf, params, pc(r_e))
     assert E.shape == (1, S, Be) and stats['hamil/E_kin'].shape == (1, S)
