@@ -204,6 +204,9 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (dqmc_set_option), repeatable')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
     ap.add_argument('--min-seconds', type=float, default=10.0, help='steady-state time the timed blocks must cover')
+    ap.add_argument('--defer-refine', action='store_true', help='library option refine_defer: the float64 pass of step k on a side stream '
+                    'beside the float32 pass of step k + 1, energy statistics of step k reduced one step later, last step drained inside '
+                    'the timed region.  Measured SLOWER on the MI355X (5.37 -> 5.71 ms per step: the two passes contend, DESIGN section 4): opt-in')
     ap.add_argument('--torch-reduce', action='store_true', help='reduce the energy statistics through torch.distributed on the host '
                     '(default: one ncclAllGather inside the library on the context\'s stream)')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
@@ -229,6 +232,12 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
                '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+    # stdout carries ONE JSON line.  Libraries underneath write there too (this RCCL build prints a version banner through C
+    # stdio when a communicator is created, flushed at exit -- after the JSON line): file descriptor 1 points at stderr for
+    # the rest of the run, and the result line goes out through a private duplicate of the original descriptor.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -366,6 +375,12 @@ def main():
         return state, stats
 
     refined = []           # walkers re-evaluated in float64 per step (host-side counter of the library, no sync)
+    # deferred refinement: software pipelining of the float64 pass (same work per step, bit-identical energies)
+    defer = (args.defer_refine and not args.emulated and S == 1 and not args.ecp and not args.overlap and args.dtype == 'f32'
+             and args.refine in (-1, 1))
+    if defer:
+        eng.set_option('refine_defer', 1)
+    held = {'e': None}
 
     def vmc_step(step, state):
         if S > 1:
@@ -377,8 +392,19 @@ def main():
             r = state['r']
         e, _ = loc_ene(step, params, r)
         refined.append(eng.last_refined())
+        if defer:          # e of THIS step is final after the next local-energy call: reduce the previous step's now
+            prev, held['e'] = held['e'], e
+            return state, (reduce_stats(eng, prev) if prev is not None else None)
         stats = reduce_stats(eng, e)
         return state, stats
+
+    def drain_deferred():
+        if held['e'] is None:
+            return None
+        eng.refine_finish()
+        out_ = reduce_stats(eng, held['e'])
+        held['e'] = None
+        return out_
 
     # ---- software-pipelined variant: E_loc(k) runs on a second stream while the sub-steps of step k+1 run ----
     pipe = {'e': None, 'stats': None}
@@ -428,6 +454,8 @@ def main():
         state, stats = step_fn(s, state)
     if args.overlap:
         stats = drain()
+    if defer:
+        stats = drain_deferred() or stats
 
     def timed_block(first_step):
         nonlocal state, stats
@@ -437,6 +465,8 @@ def main():
             state, stats = step_fn(first_step + s, state)
         if args.overlap:
             stats = drain()          # the last step's E_loc and reduction are inside the timed region
+        if defer:
+            stats = drain_deferred() or stats      # ... and so are the last step's float64 pass and its reduction
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -470,6 +500,16 @@ def main():
         off = [timed_block(10_000 + (k + 1) * args.steps) for k in range(max(3, min(len(blocks), 10)))]
         ms_refine_off = 1e3 * float(np.median(off)) / args.steps
         eng.set_option('refine', 1)
+    # ---- the same loop with the float64 pass inside each call (no software pipelining) ----
+    ms_sync_refine = None
+    if defer:
+        eng.set_option('refine_defer', 0)
+        defer = False
+        timed_block(20_000)
+        sy = [timed_block(20_000 + (k + 1) * args.steps) for k in range(max(3, min(len(blocks), 10)))]
+        ms_sync_refine = 1e3 * float(np.median(sy)) / args.steps
+        eng.set_option('refine_defer', 1)
+        defer = True
     eloc_only, roofline = None, None
     if not args.emulated:       # (the emulated test harness only exercises launch / shard / reduce)
         # ---- pure E_loc throughput (n_sub = 0), not the headline ----
@@ -481,6 +521,8 @@ def main():
         n_rep = max(5, args.steps)
         for k in range(n_rep):
             loc_ene(k, params, r)
+        if defer:
+            eng.refine_finish()
         sync()
         eloc_only = B * world / ((time.perf_counter() - t0) / n_rep)
 
@@ -488,7 +530,10 @@ def main():
         eng.timing(True)
         eng.timing_reset()
         for s in range(3):
-            state, stats = vmc_step(10_000_000 + s, state)
+            state, stats_t = vmc_step(10_000_000 + s, state)
+            stats = stats_t or stats
+        if defer:
+            stats = drain_deferred() or stats
         sync()
         rep = eng.timing_report()
         eng.timing(False)
@@ -553,13 +598,14 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'timed_blocks': len(blocks), 'timed_seconds': float(np.sum(blocks)),
             'ms_per_step_min': 1e3 * float(np.min(blocks)) / args.steps, 'ms_per_step_max': 1e3 * float(np.max(blocks)) / args.steps,
-            'n_ranks_seen': n_ranks_seen, 'ms_per_step_refine_off': ms_refine_off,
+            'n_ranks_seen': n_ranks_seen, 'ms_per_step_refine_off': ms_refine_off, 'ms_per_step_sync_refine': ms_sync_refine,
             'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
             'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, '
                                    + (f'{S} electronic states x ' if S > 1 else '') + f'{B} walkers/GPU, '
                                    f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats'
                                    + (f' + {S}x{S} psi-ratio matrix + overlap penalty' if S > 1 else ''),
                        'walkers_per_gpu': B, 'n_sub': args.n_sub, 'states': S, 'parallelism': f'walker-dp{world}',
+                       'refine_deferred': bool(defer),
                        'reduction': ('in-library: dqmc_energy_stats_allgather (one ncclAllGather of 7 doubles per rank on the '
                                      'context stream)' if comm is not None else 'host: torch.distributed.all_gather of the 7-double record'),
                        'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers, self-calibrated threshold)', 0: 'off',
@@ -582,7 +628,8 @@ def main():
         log('GPU sections done; CPU baseline')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.molecule, args.ansatz, args.n_sub, args.dtype)
-        print(json.dumps(out))
+        result_out.write(json.dumps(out) + '\n')
+        result_out.flush()
     if comm is not None:
         comm.close()
     if world > 1:

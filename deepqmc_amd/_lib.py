@@ -44,6 +44,7 @@ SIGNATURES = [
     ('dqmc_refine_info', c_int, [c_void_p, POINTER(c_double)]),
     ('dqmc_last_chunks', c_int, [c_void_p, POINTER(c_int)]),
     ('dqmc_ecp_counts', c_int, [c_void_p, POINTER(c_int64)]),
+    ('dqmc_refine_finish', c_int, [c_void_p]),
     ('dqmc_set_option', c_int, [c_void_p, c_char_p, c_int]),
     ('dqmc_timing_enable', c_int, [c_void_p, c_int]),
     ('dqmc_timing_reset', c_int, [c_void_p]),

@@ -68,7 +68,8 @@ struct dqmc_ctx {
   virtual int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
-  virtual dqmc_ctx* twin_ctx() { return nullptr; }     // the float64 refinement twin of a float32 context, once it exists
+  virtual dqmc_ctx* twin_ctx() { return nullptr; }
+  virtual int refine_finish() { return DQMC_OK; }       // join a deferred float64 pass (option "refine_defer")     // the float64 refinement twin of a float32 context, once it exists
   int last_TP = 0;
   bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
   bool ecp_skip_nl = false; // ... and no non-local ECP quadrature
@@ -168,6 +169,10 @@ struct Engine : dqmc_ctx {
   // of the LINEAR op k, or -1; mlp_skip[k]: op k is such a second layer (executed with its parent)
   std::vector<int> mlp_child;
   std::vector<char> mlp_skip;
+  // mlp_dual[k] = LINEAR op m > k: ops k and m are both first layers of chained MLPs over the SAME input rows with the same
+  // shapes (the node MLPs h of the two edge types of a message-passing layer): one dual launch at k's position
+  std::vector<int> mlp_dual;
+  int mlp_dual_on = 1;
   int mlp_fuse = 1;
   int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0, linear_f64_split = 1;   // LinArgs::cfg_*
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
@@ -280,7 +285,9 @@ struct Engine : dqmc_ctx {
   // 266 -> 338 ms per step when it was tried)
   bool graph_fits(int B) const {
     const int TP = (3 * N + 2 + 15) / 16 * 16;
-    return graphs_active() && (double)ws_bytes_per_walker(TP) * (double)B <= 2147483648.0;
+    // (batches below 64 walkers -- the twin's are multiples of 64 -- stay eager: probes, test and debugging calls; a capture
+    // costs milliseconds and such calls rarely repeat)
+    return graphs_active() && B >= 64 && (double)ws_bytes_per_walker(TP) * (double)B <= 2147483648.0;
   }
   void drop_graphs() {
 #if defined(__HIPCC__)
@@ -314,6 +321,29 @@ struct Engine : dqmc_ctx {
   size_t flag_cap = 0;
   char* d_ref = nullptr;
   size_t ref_bytes = 0;
+  // Deferred refinement (option "refine_defer"): the float64 pass over the flagged walkers of call k is enqueued on a
+  // stream of its own at the START of call k + 1 (i.e. behind whatever the caller put on the context's stream in between:
+  // the Metropolis sub-steps of the next VMC step, which leave no LDS for other kernels) and runs beside the float32 pass
+  // of call k + 1; the context's stream joins it before call k + 1 returns.  The flag list and the gather / result scratch
+  // of a pending pass belong to it, the following call works on the alternates.
+  int refine_defer = 0;
+  size_t score_cap = 0;
+  int32_t* d_flag_alt = nullptr;
+  size_t flag_cap_alt = 0;
+  char* d_ref_alt = nullptr;
+  size_t ref_bytes_alt = 0;
+  struct PendingRefine {
+    bool on = false, launched = false, use_count = false;
+    long call = 0;
+    int n = 0, n_pad = 0, B = 0;
+    const real* r = nullptr; const real* R = nullptr;
+    real* e_loc = nullptr; real* stats = nullptr; real* grad = nullptr; real* logpsi = nullptr; int32_t* sign = nullptr;
+    int32_t* flag = nullptr; size_t flag_cap = 0;
+    char* ref = nullptr; size_t ref_bytes = 0;
+  } pend;
+  long lap_calls = 0;
+  hipStream_t st_tw = nullptr;
+  hipEvent_t ev_tw_go = nullptr, ev_tw_done = nullptr;
   const double* ref_e64 = nullptr;   // float64 local energies of the last refine_listed pass (device)
   std::vector<double> probe_sample_e;          // ... of the calibration sample of a probe call (host)
   std::function<void()> probe_rethreshold;     // set by the probe call: derives refine_thresh from probe_sample_e
@@ -334,6 +364,12 @@ struct Engine : dqmc_ctx {
     if (d_flag) (void)hipFree(d_flag);
     if (d_score) (void)hipFree(d_score);
     if (d_ref) (void)hipFree(d_ref);
+    if (pend.on) { if (pend.flag) (void)hipFree(pend.flag); if (pend.ref) (void)hipFree(pend.ref); }
+    if (d_flag_alt) (void)hipFree(d_flag_alt);
+    if (d_ref_alt) (void)hipFree(d_ref_alt);
+    if (st_tw) (void)hipStreamDestroy(st_tw);
+    if (ev_tw_go) (void)hipEventDestroy(ev_tw_go);
+    if (ev_tw_done) (void)hipEventDestroy(ev_tw_done);
     if (d_descs) (void)hipFree(d_descs);
     if (d_wave_begin) (void)hipFree(d_wave_begin);
     if (d_fbufs2) (void)hipFree(d_fbufs2);
@@ -469,6 +505,7 @@ struct Engine : dqmc_ctx {
     const int no = (int)ops.size(), nb = (int)bufs.size();
     mlp_child.assign(no, -1);
     mlp_skip.assign(no, 0);
+    mlp_dual.assign(no, -1);
     if (!mlp_fuse) return;
     std::vector<int> rd, wr;
     std::vector<std::vector<int>> writers(nb), readers(nb);
@@ -497,6 +534,42 @@ struct Engine : dqmc_ctx {
       if (!ok) continue;
       mlp_child[p] = c;
       mlp_skip[c] = 1;
+    }
+    // pairs of chained MLPs on the same input
+    mlp_dual.assign(no, -1);
+    if (!mlp_dual_on) return;
+    std::vector<char> taken(no, 0);
+    for (int k = 0; k < no; ++k) {
+      if (mlp_child[k] < 0 || taken[k]) continue;
+      const int32_t* ki = ops[k].i;
+      const int32_t* kc = ops[mlp_child[k]].i;
+      if (ki[0] != 1) continue;                                                              // one input piece
+      for (int m = k + 1; m < no; ++m) {
+        if (mlp_child[m] < 0 || taken[m]) continue;
+        const int32_t* mi = ops[m].i;
+        const int32_t* mc = ops[mlp_child[m]].i;
+        bool same = mi[0] == 1 && (mi[23] >= 0) == (ki[23] >= 0) && (mc[23] >= 0) == (kc[23] >= 0);
+        for (int q = 1; q <= 4 && same; ++q) same = mi[q] == ki[q];                        // input buffer, first row, width, broadcast flag
+        same = same && mi[18] == ki[18] && mi[20] == ki[20] && mi[21] == ki[21] && mi[24] == ki[24];                  // rows, hidden width, activation
+        same = same && mc[3] == kc[3] && mc[18] == kc[18] && mc[19] == kc[19] && mc[20] == kc[20] && mc[21] == kc[21] && mc[24] == kc[24] && mc[27] == kc[27];
+        same = same && bufs[mc[17]].width == bufs[kc[17]].width && bufs[mc[17]].rows == bufs[kc[17]].rows && mc[17] != kc[17];
+        same = same && (mc[25] >= 0) == (kc[25] >= 0);
+        if (same && mc[25] >= 0) same = mc[26] == kc[26] && bufs[mc[25]].width == bufs[kc[25]].width && bufs[mc[25]].rows == bufs[kc[25]].rows;
+        if (!same) continue;
+        // legal to run m's MLP at k's position: nothing in (k, child(m)] other than the two MLPs themselves touches m's
+        // hidden / output buffers or writes the shared input, and m's residual input is complete before k
+        bool ok = true;
+        if (mc[25] >= 0) for (int w : writers[mc[25]]) ok = ok && w < k;
+        for (int x = k + 1; x <= mlp_child[m] && ok; ++x) {
+          if (x == m || x == mlp_child[m] || x == mlp_child[k]) continue;
+          op_io(ops[x], rd, wr);
+          for (int b : rd) ok = ok && b != mc[17] && b != mi[17];
+          for (int b : wr) ok = ok && b != mc[17] && b != mi[17] && b != ki[1];
+        }
+        if (!ok) continue;
+        mlp_dual[k] = m; taken[k] = taken[m] = 1;
+        break;
+      }
     }
   }
 
@@ -645,6 +718,7 @@ struct Engine : dqmc_ctx {
 
   int set_weights(const double* w, size_t n) override {
     if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
+    { const int rcj = refine_finish(); if (rcj) return rcj; }      // (a deferred float64 pass belongs to the old weights)
     ++graph_epoch;
     wtmp.resize(n);
     for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
@@ -667,6 +741,7 @@ struct Engine : dqmc_ctx {
       twin_opts.emplace_back(s.substr(5), value);
       return twin ? twin->option(s.c_str() + 5, value) : DQMC_OK;
     }
+    { const int rcj = refine_finish(); if (rcj) return rcj; }      // (a deferred float64 pass runs with the settings it was deferred under)
     ++graph_epoch;                             // (any switch may change what a captured pass would launch)
     if (s == "pass_graph") { pass_graph = value; if (!value) drop_graphs(); if (twin) twin->option("pass_graph", value); twin_opts.emplace_back(s, value); return DQMC_OK; }
     if (s == "fused") { fused_enabled = value; return DQMC_OK; }
@@ -680,6 +755,7 @@ struct Engine : dqmc_ctx {
     if (s == "linear_f64_split") { linear_f64_split = value; return DQMC_OK; }
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
+    if (s == "mlp_dual") { mlp_dual_on = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
@@ -700,6 +776,7 @@ struct Engine : dqmc_ctx {
     if (s == "refine") { refine = value; return DQMC_OK; }
     if (s == "twin_full_budget") { twin_full_budget = value; if (twin) twin->option("ws_budget_mb", (int)((value ? ws_budget : ws_budget / 2) >> 20)); return DQMC_OK; }
     if (s == "refine_ahead") { refine_ahead = value; return DQMC_OK; }
+    if (s == "refine_defer") { if (!value) { const int rcj = refine_finish(); if (rcj) return rcj; } refine_defer = value; return DQMC_OK; }
     if (s == "refine_probe") { if (value < 0) return fail(DQMC_E_ARG, "refine_probe must be >= 0"); refine_probe = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
@@ -1616,6 +1693,27 @@ struct Engine : dqmc_ctx {
             a.res = c[25] >= 0 ? bptr(c[25]) : nullptr;
             if (c[25] >= 0) { a.ld_res = bufs[c[25]].width; a.rpw_res = bufs[c[25]].rows; a.r0_res = c[26]; }
             a.res_scale = c[27] ? (real)0.70710678118654752440 : (real)1;
+            const int mate = mlp_dual.size() == ops.size() ? mlp_dual[opi] : -1;
+            if (mate >= 0 && dqmc::linear_chain_dual_supported(a.TP, a.ldw, a.ldw2) && compact[ops[mate].i[17]] == compact[i[17]] &&
+                compact[ops[mlp_child[mate]].i[17]] == compact[i[17]]) {
+              // the other MLP on the same rows rides along: the input tile is fetched and staged once for both
+              const dqmc_op& mo = ops[mate];
+              const dqmc_op& mch = ops[mlp_child[mate]];
+              { const int rcb = before(mo, sid); if (rcb) return rcb; }
+              { const int rcb = before(mch, sid); if (rcb) return rcb; }
+              a.W_b = d_w + mo.i[22]; a.bias_b = mo.i[23] >= 0 ? d_w + mo.i[23] : nullptr;
+              a.W2_b = d_w + mch.i[22]; a.bias2_b = mch.i[23] >= 0 ? d_w + mch.i[23] : nullptr;
+              a.dst_b = bptr(mch.i[17]); a.res_b = mch.i[25] >= 0 ? bptr(mch.i[25]) : nullptr;
+              t_begin("linear", 4.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
+              dqmc::launch_linear_chain_dual<real>(so, a);
+              t_end();
+              ran_with_parent[mlp_child[opi]] = 1; ran_with_parent[mate] = 1; ran_with_parent[mlp_child[mate]] = 1;
+              { const int rca = after(op, sid); if (rca) return rca; }
+              { const int rca = after(ch, sid); if (rca) return rca; }
+              { const int rca = after(mo, sid); if (rca) return rca; }
+              { const int rca = after(mch, sid); if (rca) return rca; }
+              continue;
+            }
             t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
             dqmc::launch_linear_chain<real>(so, a);
             t_end();
@@ -1817,8 +1915,12 @@ struct Engine : dqmc_ctx {
   }
   // float64 results of the n walkers listed in d_flag[1..n] replace the float32 ones.  d_count != nullptr: the list is
   // still being produced on the device, n is the capacity of this pass (kernels_mcmc.hip: k_refine_gather).
+  // phase 0: gather, float64 pass and write-back; 1: gather only (the rest is deferred: `pend`); 2: float64 pass and
+  // write-back of the pending gather (d_ref / d_flag are the pending pass's own at that moment)
   int refine_listed(const real* r, const real* R, int B, int n, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign,
-                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr, int n_scatter = -1, bool use_score = false) {
+                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr, int n_scatter = -1, bool use_score = false,
+                    int phase = 0) {
+    if (phase == 0) { const int rcj = refine_finish(); if (rcj) return rcj; }      // (one float64 pass at a time on the twin)
     if (!d_list) d_list = d_flag + 1;
     if (n_scatter < 0) n_scatter = n;
     const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
@@ -1835,9 +1937,12 @@ struct Engine : dqmc_ctx {
     double* r64 = (double*)(d_ref + o_r); double* R64 = (double*)(d_ref + o_R); double* e64 = (double*)(d_ref + o_e);
     double* s64 = (double*)(d_ref + o_s); double* g64 = (double*)(d_ref + o_g); double* l64 = (double*)(d_ref + o_l);
     int32_t* sg64 = (int32_t*)(d_ref + o_sg);
-    t_begin("refine", 0);
-    dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
-    t_end();
+    if (phase != 2) {
+      t_begin("refine", 0);
+      dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
+      t_end();
+    }
+    if (phase == 1) return DQMC_OK;
     twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
     // a Hamiltonian with a non-local ECP: the twin runs the quadrature of its walkers in float64 with the rotation angles
     // of the walkers they stand for (its psi ratios carry the float64 value path's accuracy: float32 ratios alone put
@@ -1871,6 +1976,54 @@ struct Engine : dqmc_ctx {
     if (!d_count && !use_score) last_refined += n_scatter;
     return DQMC_OK;
   }
+  // Enqueue the pending float64 pass on its own stream, gated by everything the context's stream holds at this moment.
+  int refine_launch() {
+    if constexpr (sizeof(real) == 4) {
+      if (!pend.on || pend.launched) return DQMC_OK;
+      if (!st_tw) {
+        HIP_TRY(hipStreamCreateWithFlags(&st_tw, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_tw_go, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_tw_done, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(ev_tw_go, st));
+      HIP_TRY(hipStreamWaitEvent(st_tw, ev_tw_go, 0));
+      // the pass works on the pending call's own flag list and scratch, on the side stream
+      std::swap(d_flag, pend.flag); std::swap(flag_cap, pend.flag_cap);
+      std::swap(d_ref, pend.ref); std::swap(ref_bytes, pend.ref_bytes);
+      hipStream_t keep = st, keep_t = twin->st;
+      const bool keep_timing = timing, keep_timing_t = twin->timing;
+      st = st_tw; twin->st = st_tw; timing = false; twin->timing = false;        // (HIP-event timing assumes the context's stream)
+      const int save_refined = last_refined;
+      const int rc = refine_listed(pend.r, pend.R, pend.B, pend.n_pad, pend.e_loc, pend.stats, pend.grad, pend.logpsi, pend.sign,
+                                   pend.use_count ? d_flag : nullptr, nullptr, -1, false, 2);
+      last_refined = save_refined;
+      hipError_t ee = hipEventRecord(ev_tw_done, st_tw);
+      st = keep; twin->st = keep_t; timing = keep_timing; twin->timing = keep_timing_t;
+      std::swap(d_flag, pend.flag); std::swap(flag_cap, pend.flag_cap);
+      std::swap(d_ref, pend.ref); std::swap(ref_bytes, pend.ref_bytes);
+      if (rc) return rc;
+      HIP_TRY(ee);
+      pend.launched = true;
+    }
+    return DQMC_OK;
+  }
+  // The context's stream waits for the pending float64 pass (enqueueing it first if need be): whatever the caller puts on
+  // the stream next sees the refined values.
+  int refine_finish() override {
+    if constexpr (sizeof(real) == 4) {
+      if (!pend.on) return DQMC_OK;
+      const int rc = refine_launch();
+      if (rc) return rc;
+      HIP_TRY(hipStreamWaitEvent(st, ev_tw_done, 0));
+      pend.on = false;
+      // its flag list and scratch become the alternates of the next deferral
+      if (d_flag_alt) HIP_TRY(hipFree(d_flag_alt));
+      if (d_ref_alt) HIP_TRY(hipFree(d_ref_alt));
+      d_flag_alt = pend.flag; flag_cap_alt = pend.flag_cap; d_ref_alt = pend.ref; ref_bytes_alt = pend.ref_bytes;
+      pend.flag = nullptr; pend.ref = nullptr; pend.flag_cap = pend.ref_bytes = 0;
+    }
+    return DQMC_OK;
+  }
   // capacity of the enqueue-ahead float64 pass: 1.5 x the largest of the last counts, in steps of 32 (small batches: 8) walkers
   void update_ahead_cap(int n, int B) {
     ahead_hist[ahead_pos++ & 3] = n;
@@ -1895,6 +2048,17 @@ struct Engine : dqmc_ctx {
     return rc;
   }
   int lap_refined_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
+    ++lap_calls;
+    if (pend.on) {       // the float64 pass deferred by the previous call: start it now, beside this call's float32 pass ...
+      const int rcl = refine_launch();
+      if (rcl) return rcl;
+    }
+    const int rc0 = lap_refined_ecp(r, R, B, e_loc, stats, grad, logpsi, sign);
+    if (rc0) return rc0;
+    if (pend.on && pend.call < lap_calls) return refine_finish();      // ... and join it before this call returns
+    return DQMC_OK;
+  }
+  int lap_refined_ecp(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     if constexpr (sizeof(real) == 4) {
       if (refine == 1 && ecp_mixed_on && ecp_n_nl > 0 && e_loc && !ecp_skip_nl) {
         // kinetic part first (float32 pass, flagged walkers re-run in float64 WITHOUT the quadrature), then V_nl of every
@@ -1974,10 +2138,14 @@ struct Engine : dqmc_ctx {
       if ((size_t)B + 1 > flag_cap) {
         HIP_TRY(hipStreamSynchronize(st));
         if (d_flag) { HIP_TRY(hipFree(d_flag)); d_flag = nullptr; }
-        if (d_score) { HIP_TRY(hipFree(d_score)); d_score = nullptr; }
         HIP_TRY(hipMalloc((void**)&d_flag, sizeof(int32_t) * ((size_t)B + 1)));
-        HIP_TRY(hipMalloc((void**)&d_score, sizeof(double) * (size_t)B));
         flag_cap = (size_t)B + 1;
+      }
+      if ((size_t)B > score_cap) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (d_score) { HIP_TRY(hipFree(d_score)); d_score = nullptr; }
+        HIP_TRY(hipMalloc((void**)&d_score, sizeof(double) * (size_t)B));
+        score_cap = (size_t)B;
       }
       int rc = DQMC_OK;
       // mode 1 on a system where most walkers get flagged (deep attention networks, ill-conditioned Slater matrices of a
@@ -2057,18 +2225,31 @@ struct Engine : dqmc_ctx {
           if (rc) return rc;
           n = B;
         }
-        if (n < B && static_cast<Engine<double>*>(twin)->graph_fits((n + 63) / 64 * 64)) {
-          // the twin's pass replays a captured graph per batch size: round the count up to a multiple of 64 (the surplus
-          // rows re-evaluate the first flagged walker and are not written back: k_refine_gather / scatter read the count
-          // on the device), so that a handful of sizes serve every step
-          int n_pad = (n + 63) / 64 * 64;
-          if (n_pad > B) n_pad = B;
-          rc = refine_listed(r, R, B, n_pad, e_loc, stats, grad, logpsi, sign, d_flag);
+        // the twin's pass replays a captured graph per batch size: round the count up to a multiple of 64 (the surplus rows
+        // re-evaluate the first flagged walker and are not written back: k_refine_gather / scatter read the count on the
+        // device), so that a handful of sizes serve every step
+        const bool padded = n < B && static_cast<Engine<double>*>(twin)->graph_fits((n + 63) / 64 * 64);
+        int n_eval = padded ? (n + 63) / 64 * 64 : n;
+        if (n_eval > B) n_eval = B;
+        const int32_t* d_cnt = padded ? d_flag : nullptr;
+        if (refine_defer && e_loc && ecp_n_nl == 0 && !timing && n < B) {
+          // deferred: gather the flagged walkers now (the caller may move them before the pass runs), hand flag list and
+          // scratch to the pending pass, continue on the alternates
+          rc = refine_finish();
+          if (rc) return rc;
+          rc = refine_listed(r, R, B, n_eval, e_loc, stats, grad, logpsi, sign, d_cnt, nullptr, -1, false, 1);
+          if (rc) return rc;
+          pend.on = true; pend.launched = false; pend.call = lap_calls; pend.n = n; pend.n_pad = n_eval; pend.B = B; pend.use_count = padded;
+          pend.r = r; pend.R = R; pend.e_loc = e_loc; pend.stats = stats; pend.grad = grad; pend.logpsi = logpsi; pend.sign = sign;
+          pend.flag = d_flag; pend.flag_cap = flag_cap; pend.ref = d_ref; pend.ref_bytes = ref_bytes;
+          d_flag = d_flag_alt; flag_cap = flag_cap_alt; d_flag_alt = nullptr; flag_cap_alt = 0;
+          d_ref = d_ref_alt; ref_bytes = ref_bytes_alt; d_ref_alt = nullptr; ref_bytes_alt = 0;
           last_refined = n;
           HIP_TRY(hipGetLastError());
-          return rc;
+          return DQMC_OK;
         }
-        rc = refine_listed(r, R, B, n, e_loc, stats, grad, logpsi, sign);
+        rc = refine_listed(r, R, B, n_eval, e_loc, stats, grad, logpsi, sign, d_cnt);
+        last_refined = n;
         HIP_TRY(hipGetLastError());
         return rc;
       }
@@ -2721,6 +2902,11 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
+int dqmc_refine_finish(dqmc_ctx* ctx) {
+  if (!ctx) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->refine_finish();
+}
 int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3) {
   if (!ctx || !out3) return DQMC_E_ARG;
   for (int k = 0; k < 3; ++k) out3[k] = ctx->ecp_last_counts[k];

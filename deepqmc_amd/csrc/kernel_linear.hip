@@ -333,7 +333,12 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // the number of load -> barrier -> multiply round trips.
 // (second launch bound = waves per SIMD the register allocation must leave room for: the split-group tiles exist to run
 // two waves per SIMD -- unconstrained, the 4 x 4 float64 tile takes 200 + 128 registers and one wave remains)
-template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1>
+// DUAL (CHAIN only): TWO such MLPs on the same input rows -- the node MLPs h of the two edge types of a message-passing layer
+// (reference gnn/electron_gnn.py:139-160: one subnet per edge type, each applied to the same node embeddings) -- in one
+// launch: the A tile is fetched and staged once and multiplied by both first-layer weight matrices, then the two hidden tiles
+// pass through the LDS tile one after the other.  The second MLP's pointers are LinArgs::*_b; shapes, activations and the
+// destination geometry are those of the first.
+template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1, bool DUAL = false>
 __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
@@ -347,10 +352,12 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
   constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
+  static_assert(!DUAL || CHAIN, "dual MLPs are chained MLPs");
+  constexpr int ND = DUAL ? 2 : 1;
   static_assert(!SPLIT || (!CHAIN && WN == 1 && 6 * NR * 16 <= BM * AS), "split groups: plain layers, one column tile per workgroup");
   typedef typename Mfma<real>::acc_t acc_t;
   __shared__ real As[BM * AS];
-  __shared__ real Bs[BK * BS];
+  __shared__ real Bs[ND * BK * BS];
   __shared__ real Hs[CHAIN ? BM * HS : 1];
   __shared__ real Bs2[CHAIN ? BK2 * BS2 : 1];
 
@@ -391,10 +398,16 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
   }
 
   acc_t acc[MR][NR];
+  acc_t accb[DUAL ? MR : 1][DUAL ? NR : 1];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
+  if (DUAL)
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) accb[DUAL ? i : 0][DUAL ? j : 0] = acc_t{0, 0, 0, 0};
 
   for (int p = 0; p < a.n_pieces; ++p) {
     const LinPiece<real> pc = a.piece[p];
@@ -411,7 +424,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT][BKX], rb_[NBV];
+    Vec4<real> ra[APT][BKX], rb_[NBV], rbb_[DUAL ? NBV : 1];
     auto load_chunk = [&](int kc) {
 #pragma unroll
       for (int j = 0; j < APT; ++j)
@@ -426,10 +439,13 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
         const int f = tid + NT * j;
         const int k = f / (BN / 4), n4 = f % (BN / 4);
         const int kk = kc * BK + k, col = col_blk0 + 4 * n4;
-        if (f < BK * BN / 4 && kk < pc.K && col < a.ldw)
+        if (f < BK * BN / 4 && kk < pc.K && col < a.ldw) {
           rb_[j] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk) * a.ldw + col);
-        else
+          if (DUAL) rbb_[DUAL ? j : 0] = *reinterpret_cast<const Vec4<real>*>(a.W_b + (long)(w_row0 + kk) * a.ldw + col);
+        } else {
           rb_[j] = Vec4<real>{{0, 0, 0, 0}};
+          if (DUAL) rbb_[DUAL ? j : 0] = Vec4<real>{{0, 0, 0, 0}};
+        }
       }
     };
     load_chunk(0);
@@ -449,6 +465,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
         if (f < BK * BN / 4) {
           const int k = f / (BN / 4), n4 = f % (BN / 4);
           *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = rb_[j];
+          if (DUAL) *reinterpret_cast<Vec4<real>*>(&Bs[BK * BS + k * BS + 4 * n4]) = rbb_[DUAL ? j : 0];
         }
       }
       __syncthreads();
@@ -465,6 +482,14 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
+        if (DUAL) {
+#pragma unroll
+          for (int j = 0; j < NR; ++j) fb[j] = Bs[BK * BS + kcol * BS + wn * (16 * NR) + j * 16 + (lane & 15)];
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) accb[DUAL ? i : 0][DUAL ? j : 0] = Mfma<real>::run(fa[i], fb[j], accb[DUAL ? i : 0][DUAL ? j : 0]);
+        }
       }
     }
   }
@@ -474,46 +499,55 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const Li
     lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx, As);
     return;
   }
-  // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there ----
-  {
-    LdsSink<real> hsink{Hs, HS};
-    lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink, bx);
-  }
-  acc_t acc2[MR][NR2];
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < NR2; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
-  const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
-  const int n_chunks2 = (K2 + BK2 - 1) / BK2;
-  for (int kc = 0; kc < n_chunks2; ++kc) {
-    __syncthreads();                                      // hidden tile complete (kc = 0) / previous chunk of W2 consumed
-    for (int f = tid; f < BK2 * BN2 / 4; f += NT) {
-      const int k = f / (BN2 / 4), n4 = f % (BN2 / 4);
-      const int kk = kc * BK2 + k, col = 4 * n4;
-      Vec4<real> v;
-      if (kk < K2 && col < a.ldw2) v = *reinterpret_cast<const Vec4<real>*>(a.W2 + (long)kk * a.ldw2 + col);
-      else v = Vec4<real>{{0, 0, 0, 0}};
-      *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = v;
+  // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there (DUAL: once per MLP) ----
+  auto second_layer = [&](acc_t (&h)[MR][NR], const real* bias1, const real* W2, const real* bias2, const LinArgs<real>& out, bool first) {
+    if (!first) __syncthreads();                            // the first MLP's second product has read the hidden tile
+    {
+      LdsSink<real> hsink{Hs, HS};
+      lin_epilogue<real, MR, NR, GPW>(h, a, bias1, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink, bx);
     }
-    __syncthreads();
+    acc_t acc2[MR][NR2];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int kcol = kk * 4 + (lane >> 4);
-      if (kc * BK2 + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
-      real fa[MR], fb[NR2];
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
-      for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK2 + kcol];
+      for (int j = 0; j < NR2; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
+    const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
+    const int n_chunks2 = (K2 + BK2 - 1) / BK2;
+    for (int kc = 0; kc < n_chunks2; ++kc) {
+      __syncthreads();                                      // hidden tile complete (kc = 0) / previous chunk of W2 consumed
+      for (int f = tid; f < BK2 * BN2 / 4; f += NT) {
+        const int k = f / (BN2 / 4), n4 = f % (BN2 / 4);
+        const int kk = kc * BK2 + k, col = 4 * n4;
+        Vec4<real> v;
+        if (kk < K2 && col < a.ldw2) v = *reinterpret_cast<const Vec4<real>*>(W2 + (long)kk * a.ldw2 + col);
+        else v = Vec4<real>{{0, 0, 0, 0}};
+        *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = v;
+      }
+      __syncthreads();
 #pragma unroll
-      for (int j = 0; j < NR2; ++j) fb[j] = Bs2[kcol * BS2 + j * 16 + (lane & 15)];
+      for (int kk = 0; kk < 4; ++kk) {
+        const int kcol = kk * 4 + (lane >> 4);
+        if (kc * BK2 + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
+        real fa[MR], fb[NR2];
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
+        for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK2 + kcol];
 #pragma unroll
-        for (int j = 0; j < NR2; ++j) acc2[i][j] = Mfma<real>::run(fa[i], fb[j], acc2[i][j]);
+        for (int j = 0; j < NR2; ++j) fb[j] = Bs2[kcol * BS2 + j * 16 + (lane & 15)];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR2; ++j) acc2[i][j] = Mfma<real>::run(fa[i], fb[j], acc2[i][j]);
+      }
     }
+    HbmSink<real> sink(out);
+    lin_epilogue<real, MR, NR2, GPW>(acc2, out, bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink, bx);
+  };
+  second_layer(acc, a.bias, a.W2, a.bias2, a, true);
+  if constexpr (DUAL) {
+    LinArgs<real> ab = a;                                   // the second MLP's destination and residual, same geometry
+    ab.dst = a.dst_b; ab.res = a.res_b;
+    second_layer(accb, a.bias_b, a.W2_b, a.bias2_b, ab, false);
   }
-  HbmSink<real> sink(a);
-  lin_epilogue<real, MR, NR2, GPW>(acc2, a, a.bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink, bx);
 }
 
 // ---- float32 layers on the bf16 matrix pipe (common.h: "float32 products on the bf16 matrix pipe") ----
@@ -820,6 +854,11 @@ template <typename real, int MR, int NR, int GPW> static void launch_chain_cfg(h
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2>), dim3(gx, 1), dim3(256), 0, st, a);
 }
+template <typename real, int MR, int NR, int GPW> static void launch_chain_dual(hipStream_t st, const LinArgs<real>& a) {
+  const long n_groups = (long)a.B * a.nrows;
+  const unsigned gx = (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2, 1, true>), dim3(gx, 1), dim3(256), 0, st, a);
+}
 template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_t st, const LinArgs<real>& a) {
   if (a.ldw > 32) launch_chain_cfg<real, MR, 4, GPW>(st, a);
   else if (a.ldw > 16) launch_chain_cfg<real, MR, 2, GPW>(st, a);
@@ -829,6 +868,14 @@ template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_
 // value-only rows.
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out) {
   return (TP == 1 || TP == 8 || TP == 16 || TP == 32) && ldw_hidden <= 64 && ldw_out <= 32;
+}
+// Two chained MLPs on the same rows in one launch (k_linear DUAL): 16- / 32-lane groups, hidden width 33..64, output <= 32.
+bool linear_chain_dual_supported(int TP, int ldw_hidden, int ldw_out) {
+  return (TP == 16 || TP == 32) && ldw_hidden > 32 && ldw_hidden <= 64 && ldw_out <= 32;
+}
+template <typename real> void launch_linear_chain_dual(hipStream_t st, const LinArgs<real>& a) {
+  if (a.TP == 16) launch_chain_dual<real, 1, 4, 1>(st, a);
+  else launch_chain_dual<real, 2, 4, 1>(st, a);
 }
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
@@ -907,5 +954,7 @@ template void launch_linear<float>(hipStream_t, const LinArgs<float>&);
 template void launch_linear<double>(hipStream_t, const LinArgs<double>&);
 template void launch_linear_chain<float>(hipStream_t, const LinArgs<float>&);
 template void launch_linear_chain<double>(hipStream_t, const LinArgs<double>&);
+template void launch_linear_chain_dual<float>(hipStream_t, const LinArgs<float>&);
+template void launch_linear_chain_dual<double>(hipStream_t, const LinArgs<double>&);
 
 }  // namespace dqmc

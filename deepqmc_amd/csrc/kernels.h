@@ -61,6 +61,14 @@ template <typename real> struct LinArgs {
   int ldw2;           // pad4(Nout of the second layer)
   const real* bias2;
   int act2;
+  // second MLP of a dual chained launch (launch_linear_chain_dual): same input rows, shapes, activations and destination
+  // geometry as the first; its own weights, destination and residual
+  const real* W_b;
+  const real* bias_b;
+  const real* W2_b;
+  const real* bias2_b;
+  real* dst_b;
+  const real* res_b;
   // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_nr1";
   // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
   // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
@@ -69,6 +77,8 @@ template <typename real> struct LinArgs {
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
+template <typename real> void launch_linear_chain_dual(hipStream_t st, const LinArgs<real>& a);
+bool linear_chain_dual_supported(int TP, int ldw_hidden, int ldw_out);
 constexpr int LINEAR_BF_DEFAULT = 2, LINEAR_BKX_DEFAULT = 3;      // (kernel_linear.hip: what the values select)
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----

@@ -163,8 +163,14 @@ class Engine:
         e = torch.empty(B, dtype=self.dtype, device=self.device)
         st = torch.empty(6, B, dtype=self.dtype, device=self.device)
         grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device) if return_grad else None
+        # option 'refine_defer': the float64 pass of the PREVIOUS call still writes into that call's output tensors on a side
+        # stream until this call has returned -- they are kept alive here whatever the caller did with them (a block handed
+        # back to the caching allocator could otherwise be reused for the tensors above while it is still being written)
+        prev_outputs = getattr(self, '_deferred_outputs', None)
         self._check(self.lib.dqmc_local_energy(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, e.data_ptr(),
                                                st.data_ptr(), grad.data_ptr() if return_grad else None, None, None))
+        self._deferred_outputs = (e, st, grad) if getattr(self, '_refine_defer', False) else None
+        del prev_outputs
         stats = {k: st[i] for i, k in enumerate(STAT_KEYS)}
         return (e, stats, grad) if return_grad else (e, stats)
 
@@ -335,6 +341,11 @@ class Engine:
         self._check(self.lib.dqmc_last_chunks(self._ctx, out))
         return {'own': int(out[0]), 'twin': int(out[1])}
 
+    def refine_finish(self):
+        """Join a float64 pass deferred by the last local-energy call (option 'refine_defer'; dqmc_refine_finish)."""
+        self._check(self.lib.dqmc_refine_finish(self._ctx))
+        self._deferred_outputs = None
+
     def ecp_counts(self) -> dict:
         """(nucleus, electron) pairs of the last mixed-precision ECP quadrature by class (dqmc_ecp_counts)."""
         out = (ctypes.c_int64 * 3)()
@@ -343,6 +354,9 @@ class Engine:
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
+        if name == 'refine_defer':
+            self._refine_defer = bool(value)
+        self._deferred_outputs = None          # (every option change joins a pending pass first)
 
     def timing(self, enable=True):
         self._check(self.lib.dqmc_timing_enable(self._ctx, int(enable)))

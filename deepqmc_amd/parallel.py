@@ -37,6 +37,29 @@ def energy_stats(engine, e_loc, w=None):
     return engine.merge_energy_records(all_gather_records(rec, dev))
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr while the block runs; C stdio is flushed on both edges so that text buffered by
+    a C library inside the block leaves through the redirected descriptor."""
+
+    def __enter__(self):
+        import ctypes
+        import os
+        import sys
+        self._libc = ctypes.CDLL(None)
+        sys.stdout.flush()
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class RcclCommunicator:
     """An RCCL communicator of the library's own (`ncclCommInitRank` through ctypes) for
     `dqmc_energy_stats_allgather`: the unique id is created on rank 0 and distributed with one torch.distributed
@@ -63,7 +86,8 @@ class RcclCommunicator:
         ctypes.memmove(ctypes.byref(u), uid, 128)
         self.comm = ctypes.c_void_p()
         self.rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, _Uid, ctypes.c_int]
-        rc = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), world, u, rank)
+        with _stdout_to_stderr():          # (this RCCL build prints a version banner on stdout at communicator creation:
+            rc = self.rccl.ncclCommInitRank(ctypes.byref(self.comm), world, u, rank)      # a caller's stdout may be a protocol)
         if rc:
             raise RuntimeError(f'ncclCommInitRank failed: {rc}')
 

@@ -272,6 +272,15 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * whose activations exceed "ws_budget_mb" is split into chunks inside the library (the reference has no such limit to
  * replace: its vmap over the electron batch, loss/energy.py:50-57, simply needs the memory). */
 int dqmc_last_chunks(dqmc_ctx* ctx, int* out2);
+/* Deferred refinement (option "refine_defer" 1, float32 contexts, no ECP): dqmc_local_energy returns with the float32
+ * values of the flagged walkers still in place; their float64 pass is enqueued on a stream of the library's own at the
+ * start of the NEXT dqmc_local_energy / dqmc_psi_grad call of the context -- behind everything the caller put on the
+ * context's stream in between -- runs beside that call's float32 pass, and the context's stream joins it before that call
+ * returns.  The output arrays of a call (e_loc, stats, grad, logpsi, sign) must therefore stay alive, and are final in
+ * stream order, after the next local-energy call or after dqmc_refine_finish, which enqueues and joins a pending pass
+ * at once.  Results are bit-identical to the synchronous path; probe calls and calls that refine most of the batch stay
+ * synchronous.  (The reference's loop has no counterpart: XLA schedules its one program per step.) */
+int dqmc_refine_finish(dqmc_ctx* ctx);
 /* Non-local ECP term of a float32 context (replaces nonloc_potential, ecp/gaussian_type_ecp.py:161-255, for a whole
  * batch): with "refine" 1 the 12-point quadrature of every (walker, ECP nucleus, electron) triple runs in the precision its
  * weight w = max_l (2l+1)|V_l(|r_i - R_a|)| calls for -- float64 psi ratios above "ecp_heavy_e6" (default 10000 = 1e-2 Ha),

@@ -125,7 +125,10 @@ def test_mixed_precision_quadrature_classes():
     t = dict(TABLES)
     t['Li'] = [0, TABLES['Li'][1]]                          # 4 electrons, non-local channels on Li
     h = MolecularHamiltonian(mol=mol, ecp_type='synthetic', ecp_mask=[True, False], ecp_tables=t)
-    mk = lambda dt: NeuralNetworkWaveFunction(h, 'paulinet', dtype=dt, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    import dataclasses
+    from deepqmc_amd.spec import paulinet
+    small = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)      # (keeps the emulation short)
+    mk = lambda dt: NeuralNetworkWaveFunction(h, small, dtype=dt, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     wf32, wf64 = mk(torch.float32), mk(torch.float64)
     params = wf32.init(0, perturb_envelopes=0.1)
     B, N = 3, h.n_elec
