@@ -171,10 +171,14 @@ struct Engine : dqmc_ctx {
   std::vector<char> mlp_skip;
   // mlp_dual[k] = LINEAR op m > k: ops k and m are both first layers of chained MLPs over the SAME input rows with the same
   // shapes (the node MLPs h of the two edge types of a message-passing layer): one dual launch at k's position
+  // Measured on the MI355X (LiH / PauliNet, 4096 walkers): SLOWER than the two chained launches running side by side on two
+  // streams -- E_loc pass 1.59 -> 1.64 ms, VMC step 5.32 -> 5.44 ms: the pass is not bound by the 0.27 GB of input reads
+  // this saves, and one workgroup now carries both epilogue -> LDS -> second-product chains back to back.  Option
+  // "mlp_dual" (default 0).
   std::vector<int> mlp_dual;
-  int mlp_dual_on = 1;
+  int mlp_dual_on = 0;
   int mlp_fuse = 1;
-  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0, linear_f64_split = 1;   // LinArgs::cfg_*
+  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0, linear_f64_split = 1, linear_bkx_big = 0, linear_bkx_val = 0;   // LinArgs::cfg_*
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
@@ -753,6 +757,8 @@ struct Engine : dqmc_ctx {
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "linear_f64_nr1") { linear_f64_nr1 = value; return DQMC_OK; }
     if (s == "linear_f64_split") { linear_f64_split = value; return DQMC_OK; }
+    if (s == "linear_bkx_big") { linear_bkx_big = value; return DQMC_OK; }
+    if (s == "linear_bkx_val") { linear_bkx_val = value; return DQMC_OK; }
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
     if (s == "mlp_dual") { mlp_dual_on = value; analyse_chains(); return DQMC_OK; }
@@ -1655,7 +1661,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_LINEAR: {
           dqmc::LinArgs<real> a{};
-          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1; a.cfg_f64_split = linear_f64_split;
+          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1; a.cfg_f64_split = linear_f64_split; a.cfg_bkx_big = linear_bkx_big; a.cfg_bkx_val = linear_bkx_val;
           a.n_pieces = i[0];
           int ktot = 0, w_row = 0, n_bc = 0;
           for (int p = 0; p < i[0]; ++p) {

@@ -42,7 +42,10 @@ template <typename real> __device__ __forceinline__ real row16_max(real v) {
 
 // (second launch bound: float32 tile sets are <= 80 KB, two workgroups share a CU and each wave gets 256 registers;
 // a float64 workgroup has the CU to itself)
-template <typename real>
+// NCB = key tiles (compile time: the accumulator-layout state P, A1, QK, dS is NCB x 4 values per lane, and the float64
+// instance lives at the 512-register limit -- what does not fit travels through AGPR copies, 12 VALU instructions per MFMA by
+// the SQ counters of round 4 with NCB fixed at 4)
+template <typename real, int NCB>
 __global__ void __launch_bounds__(256, sizeof(real) == 4 ? 2 : 1)
 k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const real* __restrict__ v, real* __restrict__ out, int width,
                  int H, int hd, LaneInfo li, int n_const, const real* __restrict__ k_const, const real* __restrict__ v_const) {
@@ -55,7 +58,7 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int S = hd + 2;                               // row stride of the [rows][hd] tiles
-  const int n_cb = (M + 15) / 16, n_db = hd / 16;     // key tiles, head_dim tiles
+  const int n_cb = NCB < (M + 15) / 16 ? NCB : (M + 15) / 16, n_db = hd / 16;     // key tiles (<= NCB; the launcher picks NCB = their number), head_dim tiles
   const int n_rb = (N + 15) / 16;                     // query row blocks = active waves
   const int M16 = n_cb * 16, N16 = n_rb * 16;
   const int SA = M16 + 2;                             // row stride of the per-wave [16][keys] A-operand tile
@@ -72,7 +75,7 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
   // Tile loads: thread (r_in, v4) moves one 4-vector per pass of rpp rows; the (<= MAXP) loads of a lane's q, k and
   // v tiles are all issued before any is used, and the next lane's are in flight while the current one is
   // multiplied (registers, not LDS, are the second buffer).
-  constexpr int MAXP = 4;
+  constexpr int MAXP = NCB;                            // passes of rpp >= 16 rows cover the 16 NCB key rows (and the query rows)
   const int vpr = hd / 4;                              // 4-vectors per row
   const int rpp = 256 / vpr;                           // rows per pass
   const int r_in = tid / vpr, v4 = tid - r_in * vpr;
@@ -129,11 +132,13 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
   if (T > 1) issue(1);
   __syncthreads();
 
-  acc_t P[MAXC], A1[MAXC], QK[MAXC], OL[MAXC];
+  acc_t P[NCB], A1[NCB], QK[NCB], OL[MAXC];
   real A2[4] = {0, 0, 0, 0};
   real qa[MAXK], pa[MAXK];                            // q0 and P as A fragments: row l15, k = 4 kk + l4
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) { P[c] = acc_t{0, 0, 0, 0}; A1[c] = acc_t{0, 0, 0, 0}; QK[c] = acc_t{0, 0, 0, 0}; OL[c] = acc_t{0, 0, 0, 0}; }
+  for (int c = 0; c < NCB; ++c) { P[c] = acc_t{0, 0, 0, 0}; A1[c] = acc_t{0, 0, 0, 0}; QK[c] = acc_t{0, 0, 0, 0}; }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) OL[c] = acc_t{0, 0, 0, 0};
 #pragma unroll
   for (int kk = 0; kk < MAXK; ++kk) { qa[kk] = 0; pa[kk] = 0; }
   real* myDA = DA + (active ? wave : 0) * 16 * SA;
@@ -143,26 +148,26 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk)
       if (kk < nkd) qa[kk] = qc[(i_base + l15) * S + kk * 4 + l4];
-    acc_t s0[MAXC];
+    acc_t s0[NCB];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) s0[c] = acc_t{0, 0, 0, 0};
+    for (int c = 0; c < NCB; ++c) s0[c] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk) {
       if (kk >= nkd) break;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
+      for (int c = 0; c < NCB; ++c)
         if (c < n_cb) s0[c] = Mfma<real>::run(qa[kk], k0[(c * 16 + l15) * S + kk * 4 + l4], s0[c]);
     }
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       real mx = -INFINITY;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
+      for (int c = 0; c < NCB; ++c)
         if (c < n_cb && c * 16 + l15 < M) mx = rmax(mx, (real)(s0[c][rg] * sc));
       mx = row16_max<real>(mx);
       real sum = 0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) {
+      for (int c = 0; c < NCB; ++c) {
         real e = 0;
         if (c < n_cb && c * 16 + l15 < M) e = r_exp<real>(s0[c][rg] * sc - mx);
         P[c][rg] = e;
@@ -171,11 +176,11 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
       sum = row16_sum<real>(sum);
       const real inv = 1 / sum;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) P[c][rg] *= inv;
+      for (int c = 0; c < NCB; ++c) P[c][rg] *= inv;
     }
     // P as an A operand (row = query, k = key): through the wave's scratch tile, then held in registers
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c)
+    for (int c = 0; c < NCB; ++c)
       if (c < n_cb)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) myDA[Mfma<real>::row_of(lane, rg) * SA + c * 16 + l15] = P[c][rg];
@@ -211,16 +216,16 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
     if (t + 1 < T) issue(t + 1);                      // in flight while this lane is multiplied
     if (!active) continue;
     // S-phase
-    acc_t ds[MAXC];
+    acc_t ds[NCB];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) ds[c] = acc_t{0, 0, 0, 0};
+    for (int c = 0; c < NCB; ++c) ds[c] = acc_t{0, 0, 0, 0};
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk) {
       if (kk >= nkd) break;
       const int ko = kk * 4 + l4;
       const real a0 = qa[kk], at = qc[(i_base + l15) * S + ko];
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
+      for (int c = 0; c < NCB; ++c)
         if (c < n_cb) {
           const real b0 = k0[(c * 16 + l15) * S + ko], bt = kc[(c * 16 + l15) * S + ko];
           ds[c] = Mfma<real>::run(at, b0, ds[c]);
@@ -233,7 +238,7 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
     for (int rg = 0; rg < 4; ++rg) {
       real m = 0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
+      for (int c = 0; c < NCB; ++c)
         if (c < n_cb) {
           ds[c][rg] = lap ? (ds[c][rg] + 2 * QK[c][rg]) * sc : ds[c][rg] * sc;     // dS_c  or  L_S
           m += P[c][rg] * ds[c][rg];
@@ -241,7 +246,7 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
       m = row16_sum<real>(m);                          // rowsum(P*dS_c)  or  rowsum(P*L_S)
       real s2 = 0;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c)
+      for (int c = 0; c < NCB; ++c)
         if (c < n_cb) {
           real dp;
           if (!lap) {
@@ -304,16 +309,24 @@ template <typename real> bool attention_mfma_supported(int N, int hd, int n_cons
 // small systems.
 bool attention_mfma_profitable(int N) { return N > 16; }
 
+template <typename real, int NCB>
+static int launch_attention_mfma_ncb(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd, int B,
+                                     LaneInfo li, int n_const, const real* k_const, const real* v_const, size_t lds) {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_mfma<real, NCB>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention_mfma<real, NCB>), dim3((unsigned)(B * H)), dim3(256), lds, st, q, k, v, out, width, H, hd,
+                     li, n_const, k_const, v_const);
+  return 0;
+}
 template <typename real>
 int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
                           int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const) {
   const size_t lds = attention_mfma_lds_bytes<real>(li.N, hd, n_const);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_mfma<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)lds) != hipSuccess)
-    return -2;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention_mfma<real>), dim3((unsigned)(B * H)), dim3(256), lds, st, q, k, v, out, width, H, hd, li,
-                     n_const, k_const, v_const);
-  return 0;
+  const int n_cb = (li.N + n_const + 15) / 16;
+  if (n_cb <= 2) return launch_attention_mfma_ncb<real, 2>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
+  if (n_cb == 3) return launch_attention_mfma_ncb<real, 3>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
+  return launch_attention_mfma_ncb<real, 4>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
 }
 
 template size_t attention_mfma_lds_bytes<float>(int, int, int);

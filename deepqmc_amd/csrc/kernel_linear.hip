@@ -825,6 +825,11 @@ template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, W
 // float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
 // alone are 96 / 128 registers and ONE wave per SIMD remains; one column block per wave (option "linear_f64_nr1")
 // doubles the waves per SIMD at the price of reading the A rows twice as often
+template <typename real> static int kmax_of(const LinArgs<real>& a) {
+  int kmax = 0;
+  for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
+  return kmax;
+}
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
   int kmax = 0;
   for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
@@ -839,8 +844,17 @@ template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
   if (BfLaunch<real, MR, NR, GPW, WN>::run(st, a, gx, gy)) return;
+  constexpr bool BIG16 = sizeof(real) == 4 && MR == 2 && NR == 4 && GPW == 2 && WN == 2;      // the 128 x 128 tiles of the 16-lane g layers
   if (MR == 1 && WN == 1 && GPW != 0 && wide_chunks(a))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW != 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
+  else if (MR == 1 && WN == 1 && GPW == 0 && a.cfg_bkx_val && kmax_of(a) >= 64)
+    // value-only rows of the mid-size ansatzes (Metropolis sub-steps of a few hundred walkers, the quadrature walkers of an
+    // ECP): 64-row tiles, K = 256 -- sixteen load -> barrier -> 16 MFMAs round trips of one chunk each; 32-wide chunks halve them
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW == 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
+  else if (BIG16 && a.cfg_bkx_big)
+    // K chunks of 32: a chunk of 16 is 1024 matrix-pipe cycles per wave between two barriers, less than one HBM round trip
+    // with a single chunk of prefetch
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, BIG16 ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
 }

@@ -72,7 +72,7 @@ template <typename real> struct LinArgs {
   // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_nr1";
   // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
   // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
-  int cfg_bf, cfg_bkx, cfg_f64_nr1, cfg_f64_split;
+  int cfg_bf, cfg_bkx, cfg_f64_nr1, cfg_f64_split, cfg_bkx_big, cfg_bkx_val;
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);

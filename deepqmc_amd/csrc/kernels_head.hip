@@ -482,70 +482,70 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
     if (tid == 0) cond[bk] = (colp[0] + colp[1] + colp[2] + colp[3]) / N;
     __syncthreads();
   }
-  double tr2_sum = 0.0;
+  // ---- derivative lanes (round 4: software-pipelined, LDS traffic cut) ----
+  // SQ counters of the previous structure on benzene (42 electrons; profiles/r04_pmc_sq_counters_benzene.json): the LDS
+  // unit of a CU was busy for the whole launch -- every lane staged dA_c through LDS (9 writes per thread, 36 fragment
+  // reads per MFMA wave), then all 256 threads re-read M for the two traces and reduced them with 24 ds_bpermute and two
+  // workgroup barriers -- for 36 MFMAs of work: 15 % of a benzene step.  Now: waves 0 .. nt-1 fetch their B fragments of
+  // dA_c straight from global memory in operand order (two lanes ahead, registers), multiply, and leave M_c in one of two
+  // LDS buffers; wave 3 reduces the traces of the PREVIOUS lane from the other buffer meanwhile.  One barrier per lane.
   typedef Mfma<double>::acc_t acc_t;
-  // dA_c of the next lane travels global -> registers while the current lane is multiplied (all loads of a
-  // thread are issued back to back; N*N <= 2304 = 9 per thread), registers -> LDS after the barrier
-  constexpr int MAXE = 9;
-  real regs[MAXE];
-  int lds_off[MAXE];
-#pragma unroll
-  for (int u = 0; u < MAXE; ++u) {
-    const int e = tid + u * 256;
-    const int i = e / N, j = e - i * N;
-    lds_off[u] = e < NN ? i * NS + j : -1;
-  }
-  auto issue = [&](int t) {
-    const real* At = base + (long)t * orb_width;
-#pragma unroll
-    for (int u = 0; u < MAXE; ++u) regs[u] = lds_off[u] >= 0 ? At[tid + u * 256] : (real)0;
-  };
-  auto put = [&]() {
-#pragma unroll
-    for (int u = 0; u < MAXE; ++u) if (lds_off[u] >= 0) A[lds_off[u]] = (double)regs[u];
-  };
-  if (T > 1) { issue(1); put(); }
   double fa[12];                                            // this wave's row block of A^-1 as MFMA A fragments
 #pragma unroll
   for (int kk = 0; kk < 12; ++kk) fa[kk] = (wave < nt && kk * 4 < N16) ? Inv[(wave * 16 + l15) * NS + kk * 4 + l4] : 0.0;
-  __syncthreads();
-  for (int t = 1; t < T; ++t) {
-    if (t + 1 < T) issue(t + 1);
-    if (wave < nt) {                                        // wave w owns row block w of M = A^-1 dA_c
-      for (int cb = 0; cb < nt; ++cb) {
-        const double* ib = A + l4 * NS + cb * 16 + l15;
-        acc_t acc;
-        if (nt == 1) acc = slogdet_tile_mm<4>(fa, ib, NS);
-        else if (nt == 2) acc = slogdet_tile_mm<8>(fa, ib, NS);
-        else acc = slogdet_tile_mm<12>(fa, ib, NS);
+  __syncthreads();                                          // (Inv and A are free from here on)
+  double* Mbuf[2] = {Mx, A};
+  const int nk = N16 / 4;
+  real fbA[3][12], fbB[3][12];                              // B fragments of two lanes in flight: dA_c[4 kk + l4][16 cb + l15]
+  auto load_frags = [&](real (&fb)[3][12], int t) {
+    const real* At = base + (long)t * orb_width;
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) Mx[(wave * 16 + Mfma<double>::row_of(lane, rg)) * NS + cb * 16 + l15] = acc[rg];
+    for (int cb = 0; cb < 3; ++cb)
+#pragma unroll
+      for (int kk = 0; kk < 12; ++kk) {
+        const int k = kk * 4 + l4, col = cb * 16 + l15;
+        fb[cb][kk] = (t < T && cb < nt && k < N && col < N) ? At[k * N + col] : (real)0;
       }
-    }
-    __syncthreads();                                        // M complete, dA_c no longer read
-    if (t + 1 < T) put();
-    double tr = 0.0, t2 = 0.0;
-    const bool need2 = t < T - 1;
-    for (int e = tid; e < NN; e += nthr) {
-      const int i = e / N, l = e - i * N;
-      const double m = Mx[i * NS + l];
-      if (i == l) tr += m;
-      if (need2) t2 += m * Mx[l * NS + i];
-    }
-    tr = wave_sum<double>(tr);
-    t2 = wave_sum<double>(t2);
-    double* rd = red + 8 * (t & 1);                         // double buffered: consumed after the next barrier
-    if (lane == 0) { rd[wave] = tr; rd[4 + wave] = t2; }
-    __syncthreads();                                        // next dA_c and the partial sums visible, M free
-    if (tid == 0) {
-      const double trs = rd[0] + rd[1] + rd[2] + rd[3];
+  };
+  double tr2_sum = 0.0;
+  // iteration `it`: the MFMA waves produce M of lane it (it < T) into Mbuf[it & 1]; the trace wave reduces lane it - 1
+  auto step = [&](real (&fb)[3][12], int it) {
+    if (wave < nt) {
+      if (it < T) {
+        double* Mo = Mbuf[it & 1];
+#pragma unroll
+        for (int cb = 0; cb < 3; ++cb)
+          if (cb < nt) {
+            acc_t acc = acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int kk = 0; kk < 12; ++kk)
+              if (kk < nk) acc = Mfma<double>::run(fa[kk], (double)fb[cb][kk], acc);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) Mo[(wave * 16 + Mfma<double>::row_of(lane, rg)) * NS + cb * 16 + l15] = acc[rg];
+          }
+        load_frags(fb, it + 2);                             // this register set is free again: two lanes ahead
+      }
+    } else if (wave == 3 && it >= 2) {
+      const int t = it - 1;                                 // 1 <= t < T
+      const double* Mi = Mbuf[t & 1];
+      const bool need2 = t < T - 1;
+      double tr = (lane < N) ? Mi[lane * NS + lane] : 0.0, t2 = 0.0;
+      if (need2 && lane < N)
+        for (int i = 0; i < N; ++i) t2 += Mi[i * NS + lane] * Mi[lane * NS + i];
+      tr = wave_sum<double>(tr);
       if (need2) {
-        tr2_sum += rd[4] + rd[5] + rd[6] + rd[7];
-        logdet[bk * li.TP + t] = trs;
-      } else {
-        logdet[bk * li.TP + t] = trs - tr2_sum;
+        tr2_sum += wave_sum<double>(t2);
+        if (lane == 0) logdet[bk * li.TP + t] = tr;
+      } else if (lane == 0) {
+        logdet[bk * li.TP + t] = tr - tr2_sum;
       }
     }
+    __syncthreads();
+  };
+  if (wave < nt) { load_frags(fbA, 1); load_frags(fbB, 2); }
+  for (int it = 1; it <= T; it += 2) {
+    step(fbA, it);
+    step(fbB, it + 1);
   }
   for (int t = T + tid; t < li.TP; t += nthr) logdet[bk * li.TP + t] = 0.0;
 }

@@ -55,8 +55,9 @@ class Engine:
         # eps under the safe norm is the compute dtype's machine eps (reference utils.py:79-85)
         self.norm_eps = norm_eps if norm_eps is not None else (F32_EPS if dtype == torch.float32 else F64_EPS)
         self.R0 = np.asarray(hamil.mol.coords if R is None else R, np.float64).reshape(hamil.n_nuc, 3)
-        self._compile = compiler if compiler is not None else (
-            lambda p_: compile_program(spec, p_, hamil.n_up, hamil.n_down, hamil.n_nuc, R=self.R0, eps=self.norm_eps))
+        R0_, eps_ = self.R0, self.norm_eps      # (no `self` in the closure: a cycle would leave the context -- tens of GB of
+        self._compile = compiler if compiler is not None else (       # workspace -- to the cyclic collector instead of the reference count)
+            lambda p_: compile_program(spec, p_, hamil.n_up, hamil.n_down, hamil.n_nuc, R=R0_, eps=eps_))
         self.program: Program = self._compile(params)
         self.N = hamil.n_up + hamil.n_down
         sysd = DqmcSystem(hamil.n_up, hamil.n_down, hamil.n_nuc, spec.n_determinants,

@@ -300,3 +300,23 @@ def test_deferred_refinement_is_bit_identical_and_final_after_the_next_call():
     np.testing.assert_array_equal(e3[0].numpy(), ref[0][0].numpy())
     e4 = dfr.local_energy(rs[1])
     np.testing.assert_array_equal(e4[0].numpy(), ref[1][0].numpy())
+
+
+def test_engine_is_released_by_reference_count():
+    """A context owns device memory by the tens of GB (workspace, float64 twin, captured graphs): it must go when the last
+    reference goes, not when the cyclic collector gets round to it (round 4: a `self`-capturing closure kept every Engine
+    in a cycle; on the GPU box a run of large tests then ran out of memory)."""
+    import gc
+    import weakref
+    h, wf = make()
+    params = wf.init(0, perturb_envelopes=0.1)
+    gc.collect()
+    gc.disable()
+    try:
+        eng = Engine(wf.spec, h, params, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+        eng.local_energy(torch.as_tensor(synthetic_walkers(h, 2, seed=1)))
+        ref = weakref.ref(eng)
+        del eng
+        assert ref() is None
+    finally:
+        gc.enable()

@@ -386,6 +386,7 @@ def test_emu_dual_chained_mlps(molname, dtype):
         eng.set_option('refine', 0)
         r = r.astype(np.float32)
     rt = torch.as_tensor(r)
+    eng.set_option('mlp_dual', 1)              # (opt-in: measured slower than two side-by-side launches on the MI355X)
     eng.timing(True); eng.timing_reset()
     e1, st1, g1 = eng.local_energy(rt, return_grad=True)
     n_dual = eng.timing_report()['linear']['launches']
