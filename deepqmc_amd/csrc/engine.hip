@@ -163,6 +163,8 @@ struct Engine : dqmc_ctx {
                                          // (electronic states, float64 twins) share the 288 GB of one GPU
   bool lane_compact = true;
   int attention_mfma = 1;      // 1: where profitable (N > 16), 2: wherever supported, 0: never
+  int attention_ncb = -1;      // 1: kernel instance for the exact number of key tiles, 0: the four-tile instance, -1: exact in float32 only (measured)
+  int attention_split = -1;    // float64 contexts: eight-wave variant (a pair of waves per query row block) for Laplacian passes (1 / -1), 0: never
   int slogdet_mfma = 1;        // 1: where profitable (N > 16), 2: from N > 8 on, 0: never
   std::vector<char> compact;
   // two-layer row-wise MLPs run as ONE launch (kernel_linear.hip: CHAIN): mlp_child[k] = op index of the second layer
@@ -752,6 +754,8 @@ struct Engine : dqmc_ctx {
     if (s == "fused_wt") { fused_wt_req = value; return build_fused_plan(); }
     if (s == "fused_occ") { fused_occ_req = value; return DQMC_OK; }
     if (s == "attention_mfma") { attention_mfma = value; return DQMC_OK; }
+    if (s == "attention_ncb") { attention_ncb = value; return DQMC_OK; }
+    if (s == "attention_split") { attention_split = value; return DQMC_OK; }
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
@@ -1801,10 +1805,24 @@ struct Engine : dqmc_ctx {
           // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
           t_begin("attention", 2.0 * B * i[4] * (double)N * (N + i[6]) * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
           int rc2;
-          if (attention_mfma && dqmc::attention_mfma_supported<real>(N, i[5], i[6]) &&
-              (attention_mfma >= 2 || dqmc::attention_mfma_profitable(N)))
+          const bool att_mfma = attention_mfma && dqmc::attention_mfma_supported<real>(N, i[5], i[6]) &&
+                                (attention_mfma >= 2 || dqmc::attention_mfma_profitable(N));
+          // (float64 only: the float32 instance of the split kernel agrees with float64 in the emulator but sent a whole benzene
+          // batch to the float64 pass on the MI355X when it was tried -- not understood, not instantiated for the product)
+          const int att_split = sizeof(real) == 8 ? (attention_split < 0 ? 1 : attention_split) : 0;
+          bool done = false;
+          if constexpr (sizeof(real) == 8) {
+            if (att_mfma && att_split && li.TP > 1 && dqmc::attention_mfma_split_lds_bytes<real>(N, i[5], i[6]) <= (size_t)160 * 1024 &&
+                i[5] >= 16) {
+              rc2 = dqmc::launch_attention_mfma_split<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width, i[4], i[5],
+                                                            B, li, i[6], d_w + i[7], d_w + i[8]);
+              done = true;
+            }
+          }
+          if (done) {}
+          else if (att_mfma)
             rc2 = dqmc::launch_attention_mfma<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width, i[4], i[5], B, li,
-                                                    i[6], d_w + i[7], d_w + i[8]);
+                                                    i[6], d_w + i[7], d_w + i[8], attention_ncb < 0 ? (sizeof(real) == 4 ? 1 : 0) : attention_ncb);
           else
             rc2 = dqmc::launch_attention<real>(st, bptr(i[0]), bptr(i[1]), bptr(i[2]), bptr(i[3]), bufs[i[0]].width,
                                                i[4], i[5], B, li, i[6], d_w + i[7], d_w + i[8]);

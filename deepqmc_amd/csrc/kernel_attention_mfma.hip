@@ -295,6 +295,337 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
     }
 }
 
+// ---- split variant (round 4): a PAIR of waves per query row block ---------------------------------------------------------
+// k_attention_mfma gives a row block of 16 queries to one wave: 28 electrons (C4H4) keep two of the four waves busy, 42 three,
+// and the float64 instance holds so much accumulator-layout state per wave that it lives on AGPR copies (12 VALU instructions
+// per MFMA by the SQ counters).  Here the workgroup has EIGHT waves, wave = 2 rb + half: in the S-phase a wave owns the key
+// tiles c = half, half + 2 of its row block (state P, A1, QK, dS for two tiles instead of four), in the O-phase the head_dim
+// tiles d = half, half + 2 (OL, out for two tiles) with the contraction over ALL keys.  What crosses the pair goes through LDS:
+// the row maximum and row sum of the softmax once, the row sums m_t = sum_keys P dS_t once per lane (and the running A2 sums
+// with the Laplacian lane), dP_t into the row block's shared scratch tile.  Four workgroup barriers per lane instead of two.
+template <typename real>
+__global__ void __launch_bounds__(512, 2)
+k_attention_mfma_split(const real* __restrict__ q, const real* __restrict__ k, const real* __restrict__ v, real* __restrict__ out, int width,
+                       int H, int hd, LaneInfo li, int n_const, const real* __restrict__ k_const, const real* __restrict__ v_const) {
+  typedef typename Mfma<real>::acc_t acc_t;
+  HIP_DYNAMIC_SHARED(char, smem_raw)
+  real* sm = reinterpret_cast<real*>(smem_raw);
+  const int N = li.N, T = li.T, TP = li.TP;
+  const int M = n_const + N;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
+  const int rb = wave >> 1, half = wave & 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int S = hd + 2;
+  const int n_cb = (M + 15) / 16, n_db = hd / 16, n_rb = (N + 15) / 16;
+  const int M16 = n_cb * 16, N16 = n_rb * 16;
+  const int SA = M16 + 2;
+  const int nkd = hd / 4, nkm = M16 / 4;
+  real* k0 = sm;                real* v0 = k0 + M16 * S;
+  real* qc = v0 + M16 * S;      real* kc = qc + N16 * S;   real* vc = kc + M16 * S;
+  real* DA = vc + M16 * S;                            // [n_rb][16][SA]  P once, then dP_t, as A operand (shared by the pair)
+  real* XC = DA + n_rb * 16 * SA;                     // [4 slots][n_rb][2 halves][16 rows][2]  partial row sums crossing the pair
+  const real sc = (real)(1.0 / sqrt((double)hd));
+  const long row0 = (long)b * N * TP;
+  const int col0 = h * hd;
+  const bool active = rb < n_rb;
+  const int i_base = rb * 16;
+
+  constexpr int MAXP = 2;                              // 512 threads: >= 32 rows per pass
+  const int vpr = hd / 4;
+  const int rpp = 512 / vpr;
+  const int r_in = tid / vpr, v4 = tid - r_in * vpr;
+  const real* qg = q + row0 * width + col0 + 4 * v4;
+  const real* kg = k + row0 * width + col0 + 4 * v4;
+  const real* vg = v + row0 * width + col0 + 4 * v4;
+  Vec4<real> Rq[MAXP], Rk[MAXP], Rv[MAXP];
+  auto issue = [&](int t) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int row = p * rpp + r_in;
+      Rq[p] = Vec4<real>{{0, 0, 0, 0}};
+      Rk[p] = Vec4<real>{{0, 0, 0, 0}};
+      Rv[p] = Vec4<real>{{0, 0, 0, 0}};
+      if (row < N) Rq[p] = *reinterpret_cast<const Vec4<real>*>(qg + ((long)row * TP + t) * width);
+      if (row < n_const) {
+        if (t == 0) {
+          Rk[p] = *reinterpret_cast<const Vec4<real>*>(k_const + (long)row * (H * hd) + col0 + 4 * v4);
+          Rv[p] = *reinterpret_cast<const Vec4<real>*>(v_const + (long)row * (H * hd) + col0 + 4 * v4);
+        }
+      } else if (row < M) {
+        const long off = ((long)(row - n_const) * TP + t) * width;
+        Rk[p] = *reinterpret_cast<const Vec4<real>*>(kg + off);
+        Rv[p] = *reinterpret_cast<const Vec4<real>*>(vg + off);
+      }
+    }
+  };
+  auto put = [&](real* dq, real* dk, real* dv) {
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+      const int row = p * rpp + r_in;
+      if (row < N16) {
+        Vec2<real>* d2 = reinterpret_cast<Vec2<real>*>(dq + row * S + 4 * v4);
+        d2[0] = Vec2<real>{{Rq[p].v[0], Rq[p].v[1]}}; d2[1] = Vec2<real>{{Rq[p].v[2], Rq[p].v[3]}};
+      }
+      if (row < M16) {
+        Vec2<real>* k2 = reinterpret_cast<Vec2<real>*>(dk + row * S + 4 * v4);
+        k2[0] = Vec2<real>{{Rk[p].v[0], Rk[p].v[1]}}; k2[1] = Vec2<real>{{Rk[p].v[2], Rk[p].v[3]}};
+        Vec2<real>* v2 = reinterpret_cast<Vec2<real>*>(dv + row * S + 4 * v4);
+        v2[0] = Vec2<real>{{Rv[p].v[0], Rv[p].v[1]}}; v2[1] = Vec2<real>{{Rv[p].v[2], Rv[p].v[3]}};
+      }
+    }
+  };
+  int irow[4];
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) irow[rg] = i_base + Mfma<real>::row_of(lane, rg);
+  // partial row quantities crossing the pair: slot s, value index x (0 / 1)
+  auto xc_put = [&](int slot, int x, const real (&val)[4]) {
+    if (active && l15 == 0) {
+      real* dst = XC + (((slot * n_rb + rb) * 2 + half) * 16) * 2;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[Mfma<real>::row_of(lane, rg) * 2 + x] = val[rg];
+    }
+  };
+  auto xc_other = [&](int slot, int x, int rg) -> real {
+    return XC[(((slot * n_rb + rb) * 2 + (half ^ 1)) * 16 + Mfma<real>::row_of(lane, rg)) * 2 + x];
+  };
+
+  issue(0);
+  put(qc, k0, v0);
+  if (T > 1) issue(1);
+  __syncthreads();
+
+  acc_t P[2], A1[2], QK[2], OL[2];
+  real A2[4] = {0, 0, 0, 0};                          // this half's share of the running sums
+  real qa[MAXK], pa[MAXK];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { P[j] = acc_t{0, 0, 0, 0}; A1[j] = acc_t{0, 0, 0, 0}; QK[j] = acc_t{0, 0, 0, 0}; OL[j] = acc_t{0, 0, 0, 0}; }
+#pragma unroll
+  for (int kk = 0; kk < MAXK; ++kk) { qa[kk] = 0; pa[kk] = 0; }
+  real* myDA = DA + (active ? rb : 0) * 16 * SA;
+
+  // ---- value lane ----
+  acc_t s0[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) s0[j] = acc_t{0, 0, 0, 0};
+  real part[4];
+  if (active) {
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk)
+      if (kk < nkd) qa[kk] = qc[(i_base + l15) * S + kk * 4 + l4];
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkd) break;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = half + 2 * j;
+        if (c < n_cb) s0[j] = Mfma<real>::run(qa[kk], k0[(c * 16 + l15) * S + kk * 4 + l4], s0[j]);
+      }
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      real mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = half + 2 * j;
+        if (c < n_cb && c * 16 + l15 < M) mx = rmax(mx, (real)(s0[j][rg] * sc));
+      }
+      part[rg] = row16_max<real>(mx);
+    }
+  }
+  xc_put(0, 0, part);
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const real mx = rmax(part[rg], xc_other(0, 0, rg));
+      real sum = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = half + 2 * j;
+        real e = 0;
+        if (c < n_cb && c * 16 + l15 < M) e = r_exp<real>(s0[j][rg] * sc - mx);
+        P[j][rg] = e;
+        sum += e;
+      }
+      part[rg] = row16_sum<real>(sum);
+    }
+  }
+  xc_put(1, 0, part);
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const real inv = 1 / (part[rg] + xc_other(1, 0, rg));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) P[j][rg] *= inv;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = half + 2 * j;
+      if (c < n_cb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) myDA[Mfma<real>::row_of(lane, rg) * SA + c * 16 + l15] = P[j][rg];
+    }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk)
+      if (kk < nkm) pa[kk] = myDA[l15 * SA + kk * 4 + l4];
+    acc_t o[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o[j] = acc_t{0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      if (kk >= nkm) break;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int d = half + 2 * j;
+        if (d < n_db) o[j] = Mfma<real>::run(pa[kk], v0[(kk * 4 + l4) * S + d * 16 + l15], o[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int d = half + 2 * j;
+      if (d < n_db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+          if (irow[rg] < N) out[(row0 + (long)irow[rg] * TP) * width + col0 + d * 16 + l15] = o[j][rg];
+    }
+  }
+  if (T == 1) return;
+
+  // ---- derivative lanes, then the Laplacian lane ----
+  for (int t = 1; t < T; ++t) {
+    const bool lap = t == T - 1;
+    __syncthreads();                                  // previous lane's tiles and dP scratch are no longer read
+    put(qc, kc, vc);
+    __syncthreads();
+    if (t + 1 < T) issue(t + 1);
+    acc_t ds[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ds[j] = acc_t{0, 0, 0, 0};
+    real mp[4] = {0, 0, 0, 0};
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < MAXK; ++kk) {
+        if (kk >= nkd) break;
+        const int ko = kk * 4 + l4;
+        const real a0 = qa[kk], at = qc[(i_base + l15) * S + ko];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = half + 2 * j;
+          if (c < n_cb) {
+            const real b0 = k0[(c * 16 + l15) * S + ko], bt = kc[(c * 16 + l15) * S + ko];
+            ds[j] = Mfma<real>::run(at, b0, ds[j]);
+            ds[j] = Mfma<real>::run(a0, bt, ds[j]);
+            if (!lap) QK[j] = Mfma<real>::run(at, bt, QK[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        real m = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = half + 2 * j;
+          if (c < n_cb) {
+            ds[j][rg] = lap ? (ds[j][rg] + 2 * QK[j][rg]) * sc : ds[j][rg] * sc;     // dS_c  or  L_S
+            m += P[j][rg] * ds[j][rg];
+          }
+        }
+        mp[rg] = row16_sum<real>(m);
+      }
+    }
+    const int slot = 2 + (t & 1);
+    xc_put(slot, 0, mp);
+    if (lap) xc_put(slot, 1, A2);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const real m = mp[rg] + xc_other(slot, 0, rg);
+        const real a2 = lap ? A2[rg] + xc_other(slot, 1, rg) : (real)0;
+        real s2 = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = half + 2 * j;
+          if (c < n_cb) {
+            real dp;
+            if (!lap) {
+              const real cc = ds[j][rg] - m;
+              dp = P[j][rg] * cc;
+              A1[j][rg] += dp * cc;
+              s2 += dp * ds[j][rg];
+            } else {
+              dp = A1[j][rg] + P[j][rg] * (ds[j][rg] - m - a2);                       // L_P
+            }
+            myDA[Mfma<real>::row_of(lane, rg) * SA + c * 16 + l15] = dp;
+          }
+        }
+        if (!lap) A2[rg] += row16_sum<real>(s2);
+      }
+    }
+    __syncthreads();                                  // dP_t of both halves is in the row block's scratch tile
+    if (active) {
+      acc_t o[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) o[j] = lap ? OL[j] : acc_t{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < MAXK; ++kk) {
+        if (kk >= nkm) break;
+        const int jo = kk * 4 + l4;
+        const real adp = myDA[l15 * SA + jo], ap = pa[kk];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int d = half + 2 * j;
+          if (d < n_db) {
+            const real b0 = v0[jo * S + d * 16 + l15], bt = vc[jo * S + d * 16 + l15];
+            o[j] = Mfma<real>::run(adp, b0, o[j]);
+            o[j] = Mfma<real>::run(ap, bt, o[j]);
+            if (!lap) OL[j] = Mfma<real>::run(adp, bt + bt, OL[j]);                   // 2 sum_c dP_c v_c
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int d = half + 2 * j;
+        if (d < n_db)
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg)
+            if (irow[rg] < N) out[(row0 + (long)irow[rg] * TP + t) * width + col0 + d * 16 + l15] = o[j][rg];
+      }
+    }
+  }
+  __syncthreads();
+  for (int t = T; t < TP; ++t)
+    for (int e = tid; e < N * hd; e += nthr) {
+      const int i = e / hd, d = e - i * hd;
+      out[(row0 + (long)i * TP + t) * width + col0 + d] = 0;
+    }
+}
+
+template <typename real> size_t attention_mfma_split_lds_bytes(int N, int hd, int n_const) {
+  const size_t M16 = ((size_t)N + n_const + 15) / 16 * 16, N16 = ((size_t)N + 15) / 16 * 16;
+  return sizeof(real) * ((N16 + 4 * M16) * (hd + 2) + (N16 / 16) * 16 * (M16 + 2) + 4 * (N16 / 16) * 2 * 16 * 2);
+}
+template <typename real>
+int launch_attention_mfma_split(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd, int B,
+                                LaneInfo li, int n_const, const real* k_const, const real* v_const) {
+  const size_t lds = attention_mfma_split_lds_bytes<real>(li.N, hd, n_const);
+  if (lds > 160 * 1024 || hd % 16 != 0 || hd > 64 || hd < 16 || li.N > 64 || li.N + n_const > 64) return -1;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attention_mfma_split<real>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return -2;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_attention_mfma_split<real>), dim3((unsigned)(B * H)), dim3(512), lds, st, q, k, v, out, width, H, hd,
+                     li, n_const, k_const, v_const);
+  return 0;
+}
+template int launch_attention_mfma_split<double>(hipStream_t, const double*, const double*, const double*, double*, int, int, int, int, LaneInfo,
+                                                 int, const double*, const double*);
+template size_t attention_mfma_split_lds_bytes<double>(int, int, int);
+
 template <typename real> size_t attention_mfma_lds_bytes(int N, int hd, int n_const) {
   const size_t M16 = ((size_t)N + n_const + 15) / 16 * 16, N16 = ((size_t)N + 15) / 16 * 16;
   return sizeof(real) * ((N16 + 4 * M16) * (hd + 2) + (N16 / 16) * 16 * (M16 + 2));
@@ -321,9 +652,9 @@ static int launch_attention_mfma_ncb(hipStream_t st, const real* q, const real* 
 }
 template <typename real>
 int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
-                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const) {
+                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const, int exact_tiles) {
   const size_t lds = attention_mfma_lds_bytes<real>(li.N, hd, n_const);
-  const int n_cb = (li.N + n_const + 15) / 16;
+  const int n_cb = exact_tiles ? (li.N + n_const + 15) / 16 : 4;
   if (n_cb <= 2) return launch_attention_mfma_ncb<real, 2>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
   if (n_cb == 3) return launch_attention_mfma_ncb<real, 3>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
   return launch_attention_mfma_ncb<real, 4>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
@@ -334,8 +665,8 @@ template size_t attention_mfma_lds_bytes<double>(int, int, int);
 template bool attention_mfma_supported<float>(int, int, int);
 template bool attention_mfma_supported<double>(int, int, int);
 template int launch_attention_mfma<float>(hipStream_t, const float*, const float*, const float*, float*, int, int, int, int, LaneInfo, int,
-                                          const float*, const float*);
+                                          const float*, const float*, int);
 template int launch_attention_mfma<double>(hipStream_t, const double*, const double*, const double*, double*, int, int, int, int, LaneInfo,
-                                           int, const double*, const double*);
+                                           int, const double*, const double*, int);
 
 }  // namespace dqmc

@@ -196,9 +196,15 @@ template <typename real> size_t attention_lds_bytes(int N, int hd, int n_const);
 template <typename real> size_t attention_mfma_lds_bytes(int N, int hd, int n_const);
 template <typename real> bool attention_mfma_supported(int N, int hd, int n_const);
 bool attention_mfma_profitable(int N);
+// split variant: eight waves, a pair per query row block (kernel_attention_mfma.hip); returns -1 when the shape is not supported
+template <typename real> size_t attention_mfma_split_lds_bytes(int N, int hd, int n_const);
+template <typename real>
+int launch_attention_mfma_split(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H, int hd, int B,
+                                LaneInfo li, int n_const, const real* k_const, const real* v_const);
 template <typename real>
 int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
-                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const);
+                          int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const,
+                          int exact_tiles = 1);      // 0: the instance for four key tiles whatever their number (option "attention_ncb")
 
 // ---- kernels_head.hip ----
 template <typename real>

@@ -402,7 +402,7 @@ __device__ __forceinline__ Mfma<double>::acc_t slogdet_tile_mm(const double (&fa
 // the (N/16)^2 output tiles; traces tr(M) and tr(M^2) from the LDS copy of M.  The inverse itself is the same
 // pivoted Gauss-Jordan as k_slogdet (256 threads instead of 64).  One workgroup per (walker, determinant).
 template <typename real>
-__global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ orb, int orb_width,
+__global__ void __launch_bounds__(256, 2) k_slogdet_mfma(const real* __restrict__ orb, int orb_width,
                                                       double* __restrict__ logdet, int32_t* __restrict__ sign_k,
                                                       LaneInfo li, double* __restrict__ cond) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
@@ -427,15 +427,28 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
   __syncthreads();
   double logabs = 0.0;
   int sgn = 1;
+  // elements of the elimination update owned by this thread (the same for every pivot: no integer division in the loop)
+  constexpr int MAXU = 9;                                   // N * N <= 2304 = 9 x 256
+  int e_row[MAXU], e_off[MAXU];
+#pragma unroll
+  for (int u = 0; u < MAXU; ++u) {
+    const int e = tid + u * 256;
+    const int i = e / N, j = e - i * N;
+    e_row[u] = e < NN ? i : -1;
+    e_off[u] = i * NS + j;
+  }
   for (int p = 0; p < N; ++p) {
-    if (tid == 0) {
-      int best = p;
-      double bv = fabs(A[p * NS + p]);
-      for (int i = p + 1; i < N; ++i) {
-        const double x = fabs(A[i * NS + p]);
-        if (x > bv) { bv = x; best = i; }   // first maximum, as LAPACK idamax
+    if (wave == 0) {
+      // pivot search by one wave (N <= 48 rows): largest |A[i][p]|, i >= p; ties to the smaller row, as LAPACK idamax
+      double bv = (lane >= p && lane < N) ? fabs(A[lane * NS + p]) : -1.0;
+      int best = lane;
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) {
+        const double ov = __shfl_xor(bv, m, 64);
+        const int ob = __shfl_xor(best, m, 64);
+        if (ov > bv || (ov == bv && ob < best)) { bv = ov; best = ob; }
       }
-      piv_s = best;
+      if (lane == 0) piv_s = best;
     }
     __syncthreads();
     const int q = piv_s;
@@ -448,7 +461,7 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
     }
     __syncthreads();
     const double piv = A[p * NS + p];
-    logabs += log(fabs(piv));
+    if (tid == 0) logabs += log(fabs(piv));                 // (only thread 0 writes log|det|)
     if (piv < 0) sgn = -sgn;
     if (piv == 0) sgn = 0;
     __syncthreads();
@@ -456,12 +469,14 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
     for (int j = tid; j < N; j += nthr) { A[p * NS + j] *= ip; Inv[p * NS + j] *= ip; }
     for (int i = tid; i < N; i += nthr) colp[i] = A[i * NS + p];
     __syncthreads();
-    for (int e = tid; e < NN; e += nthr) {
-      const int i = e / N, j = e - i * N;
-      if (i != p) {
+#pragma unroll
+    for (int u = 0; u < MAXU; ++u) {
+      const int i = e_row[u];
+      if (i >= 0 && i != p) {
         const double f = colp[i];
-        A[i * NS + j] -= f * A[p * NS + j];
-        Inv[i * NS + j] -= f * Inv[p * NS + j];
+        const int j = e_off[u] - i * NS;
+        A[e_off[u]] -= f * A[p * NS + j];
+        Inv[e_off[u]] -= f * Inv[p * NS + j];
       }
     }
     __syncthreads();
@@ -530,8 +545,21 @@ __global__ void __launch_bounds__(256) k_slogdet_mfma(const real* __restrict__ o
       const double* Mi = Mbuf[t & 1];
       const bool need2 = t < T - 1;
       double tr = (lane < N) ? Mi[lane * NS + lane] : 0.0, t2 = 0.0;
-      if (need2 && lane < N)
-        for (int i = 0; i < N; ++i) t2 += Mi[i * NS + lane] * Mi[lane * NS + i];
+      if (need2 && lane < N) {
+        // (four independent partial sums: the LDS reads of four terms are in flight together instead of one dependent
+        // read -> multiply -> add chain per term)
+        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+        const double* col = Mi + lane;
+        const double* row = Mi + lane * NS;
+        int i = 0;
+        for (; i + 4 <= N; i += 4) {
+          const double c0 = col[(i + 0) * NS], c1 = col[(i + 1) * NS], c2 = col[(i + 2) * NS], c3 = col[(i + 3) * NS];
+          const double r0 = row[i + 0], r1 = row[i + 1], r2 = row[i + 2], r3 = row[i + 3];
+          p0 += c0 * r0; p1 += c1 * r1; p2 += c2 * r2; p3 += c3 * r3;
+        }
+        for (; i < N; ++i) p0 += col[i * NS] * row[i];
+        t2 = (p0 + p1) + (p2 + p3);
+      }
       tr = wave_sum<double>(tr);
       if (need2) {
         tr2_sum += wave_sum<double>(t2);

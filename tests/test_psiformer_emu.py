@@ -167,3 +167,30 @@ def test_attention_mfma_f64_two_row_blocks(ansatz):
     sign2, logpsi2 = eng.wf_eval(torch.as_tensor(r))
     np.testing.assert_array_equal(sign2.numpy(), sign.numpy())
     np.testing.assert_array_equal(logpsi2.numpy(), logpsi.numpy())
+
+
+def test_attention_mfma_split_three_row_blocks():
+    """The eight-wave attention kernel (a pair of waves per query row block: kernel_attention_mfma.hip, split variant) on 38
+    electrons: three row blocks, three key tiles (the pair owns two / one of them), 116 of 128 lanes -- against the four-wave
+    kernel (option "attention_split" 0) and the interpreter (float64: the only instance the product builds)."""
+    mol = Molecule(coords=np.array([[-1.4, 0.0, 0.0], [1.4, 0.0, 0.0]]), charges=np.array([19, 19]), charge=0, spin=0)
+    spec = dataclasses.replace(psiformer(), embedding_dim=64, n_interactions=1, n_determinants=1)
+    h = MolecularHamiltonian(mol=mol)
+    assert h.n_elec == 38
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    B = 1
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    ref = it.run(r, mol.coords, laplacian=True)
+    names = [n for n in eng.program.buf_names if n.endswith('/att')]
+    e1, _, g1 = eng.local_energy(torch.as_tensor(r), return_grad=True)          # float64 default: split
+    att1 = {n: eng.debug_read(n, B) for n in names}
+    eng.set_option('attention_split', 0)
+    e0, _, g0 = eng.local_energy(torch.as_tensor(r), return_grad=True)
+    for n in names:
+        np.testing.assert_allclose(att1[n], eng.debug_read(n, B), rtol=1e-11, atol=1e-12, err_msg=n)
+        np.testing.assert_allclose(att1[n], it.bufs[eng.program.buf_names[n]], rtol=1e-9, atol=1e-10, err_msg=n)
+    np.testing.assert_allclose(e1.numpy(), e0.numpy(), rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(e1.numpy(), ref['e_loc'], rtol=1e-8, atol=1e-8)
+    np.testing.assert_allclose(g1.numpy(), ref['grad'], rtol=1e-8, atol=1e-8)
