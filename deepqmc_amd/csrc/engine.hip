@@ -387,6 +387,7 @@ struct Engine : dqmc_ctx {
     if (d_ph_nuc) (void)hipFree(d_ph_nuc);
     if (d_ecp) (void)hipFree(d_ecp);
     if (d_ecpm) (void)hipFree(d_ecpm);
+    if (d_wbf) (void)hipFree(d_wbf);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (d_w) (void)hipFree(d_w);
     if (d_it) (void)hipFree(d_it);
@@ -734,7 +735,52 @@ struct Engine : dqmc_ctx {
     }
     HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    { const int rcb = upload_bf_planes(); if (rcb) return rcb; }
     if (fused_n_ops > 0) return pack_fused_weights();
+    return DQMC_OK;
+  }
+  // Pre-split weight planes for k_linear_bf (float32 contexts): every LINEAR op's block W[K][ldw] as three planes of bf16
+  // pairs along k (round-to-nearest-even pieces, exactly what the device split produces), at word offset (W offset) / 2.
+  uint32_t* d_wbf = nullptr;
+  long wbf_plane = 0;
+  static uint32_t bf16_rne(float x) {
+    uint32_t u; std::memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  }
+  static float bf16_as_float(uint32_t h) { const uint32_t u = h << 16; float f; std::memcpy(&f, &u, 4); return f; }
+  int upload_bf_planes() {
+    if constexpr (sizeof(real) == 4) {
+      const long plane = (long)(n_weights / 2 + 4);
+      std::vector<uint32_t> pl((size_t)3 * plane, 0u);
+      for (const auto& o : ops) {
+        if (o.kind != DQMC_OP_LINEAR) continue;
+        const int32_t* i = o.i;
+        long ktot = 0;
+        for (int p = 0; p < i[0]; ++p) ktot += pad4(i[3 + 4 * p]);
+        const long ldw = pad4(i[21]), off = i[22];
+        if (off % 2 || (size_t)(off + ktot * ldw) > n_weights) continue;
+        for (long kp = 0; kp < ktot / 2; ++kp)
+          for (long c = 0; c < ldw; ++c) {
+            const float x0 = (float)wtmp[off + (2 * kp) * ldw + c], x1 = (float)wtmp[off + (2 * kp + 1) * ldw + c];
+            const uint32_t h0 = bf16_rne(x0), h1 = bf16_rne(x1);
+            const float r0 = x0 - bf16_as_float(h0), r1 = x1 - bf16_as_float(h1);
+            const uint32_t m0 = bf16_rne(r0), m1 = bf16_rne(r1);
+            const float s0 = r0 - bf16_as_float(m0), s1 = r1 - bf16_as_float(m1);
+            const long at = off / 2 + kp * ldw + c;
+            pl[at] = h0 | (h1 << 16);
+            pl[plane + at] = m0 | (m1 << 16);
+            pl[2 * plane + at] = bf16_rne(s0) | (bf16_rne(s1) << 16);
+          }
+      }
+      if (plane != wbf_plane) {
+        if (d_wbf) { HIP_TRY(hipFree(d_wbf)); d_wbf = nullptr; }
+        HIP_TRY(hipMalloc((void**)&d_wbf, sizeof(uint32_t) * pl.size()));
+        wbf_plane = plane;
+      }
+      HIP_TRY(hipMemcpyAsync(d_wbf, pl.data(), sizeof(uint32_t) * pl.size(), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
     return DQMC_OK;
   }
 
@@ -1683,6 +1729,7 @@ struct Engine : dqmc_ctx {
           }
           a.W = d_w + i[22];
           a.ldw = pad4(i[21]);
+          if (sizeof(real) == 4 && d_wbf && i[22] % 2 == 0) { a.Wbf = d_wbf + i[22] / 2; a.wbf_plane = wbf_plane; }
           a.bias = i[23] >= 0 ? d_w + i[23] : nullptr;
           a.dst = bptr(i[17]);
           a.ld_dst = bufs[i[17]].width; a.rpw_dst = bufs[i[17]].rows; a.r0_dst = i[18]; a.col0_dst = i[19];

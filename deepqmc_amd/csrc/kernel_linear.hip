@@ -568,7 +568,10 @@ __device__ __forceinline__ void sched_fence() {
 }
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 48-row x 64-column wave tiles of
 // the 48-lane groups need 172 registers unconstrained -- two waves per SIMD -- and fit three with 168)
-template <int MR, int NR, int GPW, int WN, int NP>
+// PRE: the weights arrive already split (LinArgs::Wbf: three planes of bf16 PAIRS along k, made on the host by
+// Engine::set_weights like the fused kernel's) -- the staging copies three 16-byte rows instead of splitting two float4
+// (44 VALU instructions per item and workgroup).
+template <int MR, int NR, int GPW, int WN, int NP, bool PRE = false>
 __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_linear_bf(const LinArgs<float> a) {
   typedef float real;
   constexpr int NT = 256 * WN;
@@ -637,7 +640,8 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT][2], rb_[NBI][2];
+    Vec4<real> ra[APT][2], rb_[PRE ? 1 : NBI][2];
+    BfFrag rp_[PRE ? NBI : 1][3];
     auto load_chunk = [&](int kc) {
 #pragma unroll
       for (int j = 0; j < APT; ++j)
@@ -652,12 +656,20 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
         const int f = tid + NT * j;
         const int kp = f / (BN / 4), n4 = f % (BN / 4);
         const int kk = kc * BK + 2 * kp, col = col_blk0 + 4 * n4;
+        if (PRE) {
+          const bool ok = f < (BK / 2) * (BN / 4) && kk < pc.K && col < a.ldw;      // (piece widths are multiples of 4: kk + 1 < K too)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (f < (BK / 2) * (BN / 4) && kk + h < pc.K && col < a.ldw)
-            rb_[j][h] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk + h) * a.ldw + col);
-          else
-            rb_[j][h] = Vec4<real>{{0, 0, 0, 0}};
+          for (int pl = 0; pl < 3; ++pl)
+            rp_[PRE ? j : 0][pl] = ok ? *reinterpret_cast<const BfFrag*>(a.Wbf + pl * a.wbf_plane + (long)((w_row0 + kk) >> 1) * a.ldw + col)
+                                      : BfFrag{{0u, 0u, 0u, 0u}};
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            if (f < (BK / 2) * (BN / 4) && kk + h < pc.K && col < a.ldw)
+              rb_[PRE ? 0 : j][h] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk + h) * a.ldw + col);
+            else
+              rb_[PRE ? 0 : j][h] = Vec4<real>{{0, 0, 0, 0}};
+          }
         }
       }
     };
@@ -677,21 +689,25 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
         const int f = tid + NT * j;
         if (f < (BK / 2) * (BN / 4)) {
           const int kp = f / (BN / 4), n4 = f % (BN / 4);
-          uint32_t w0[4], w1[4], w2[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {                          // column c of the item: k (low half) and k + 1 (high half)
-            const float x0 = rb_[j][0].v[c], x1 = rb_[j][1].v[c];
-            const uint32_t h = bf_pack2(x0, x1);
-            const float r0 = x0 - bf_lo_as_float(h), r1 = x1 - bf_hi_as_float(h);
-            const uint32_t m = bf_pack2(r0, r1);
-            w0[c] = h; w1[c] = m; w2[c] = bf_pack2(r0 - bf_lo_as_float(m), r1 - bf_hi_as_float(m));
-          }
           BfFrag* d0 = reinterpret_cast<BfFrag*>(&Bs[(0 * 16 + kp) * BSTR + 4 * n4]);
           BfFrag* d1 = reinterpret_cast<BfFrag*>(&Bs[(1 * 16 + kp) * BSTR + 4 * n4]);
           BfFrag* d2 = reinterpret_cast<BfFrag*>(&Bs[(2 * 16 + kp) * BSTR + 4 * n4]);
-          *d0 = BfFrag{{w0[0], w0[1], w0[2], w0[3]}};
-          *d1 = BfFrag{{w1[0], w1[1], w1[2], w1[3]}};
-          *d2 = BfFrag{{w2[0], w2[1], w2[2], w2[3]}};
+          if (PRE) {
+            *d0 = rp_[PRE ? j : 0][0]; *d1 = rp_[PRE ? j : 0][1]; *d2 = rp_[PRE ? j : 0][2];
+          } else {
+            uint32_t w0[4], w1[4], w2[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {                        // column c of the item: k (low half) and k + 1 (high half)
+              const float x0 = rb_[PRE ? 0 : j][0].v[c], x1 = rb_[PRE ? 0 : j][1].v[c];
+              const uint32_t h = bf_pack2(x0, x1);
+              const float r0 = x0 - bf_lo_as_float(h), r1 = x1 - bf_hi_as_float(h);
+              const uint32_t m = bf_pack2(r0, r1);
+              w0[c] = h; w1[c] = m; w2[c] = bf_pack2(r0 - bf_lo_as_float(m), r1 - bf_hi_as_float(m));
+            }
+            *d0 = BfFrag{{w0[0], w0[1], w0[2], w0[3]}};
+            *d1 = BfFrag{{w1[0], w1[1], w1[2], w1[3]}};
+            *d2 = BfFrag{{w2[0], w2[1], w2[2], w2[3]}};
+          }
         }
       }
       __syncthreads();
@@ -797,16 +813,25 @@ static bool bf_pays(const LinArgs<float>& a, int np) {
   for (int p = 0; p < a.n_pieces; ++p) { chunks += (a.piece[p].K + 31) / 32; ksteps += (a.piece[p].K + 3) / 4; }
   return a.cfg_bf != 0 && chunks * np * 16 + chunks * 12 < ksteps * 32;
 }
-template <int MR, int NR, int GPW, int WN> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
+template <int MR, int NR, int GPW, int WN, bool PRE = false> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   constexpr size_t lds = (size_t)BM * 34 * 4 + (size_t)3 * 16 * (BN + 4) * 4;
   constexpr int NP = GPW == 0 ? 6 : 9;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_bf<MR, NR, GPW, WN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_bf<MR, NR, GPW, WN, NP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_bf<MR, NR, GPW, WN, NP>), dim3(gx, gy), dim3(256 * WN), lds, st, a);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_bf<MR, NR, GPW, WN, NP, PRE>), dim3(gx, gy), dim3(256 * WN), lds, st, a);
+}
+// Value-only rows on the bf16 pipe (cfg_bf >= 3): 64 rows x 128 columns per workgroup, ONE A split (44 VALU) feeds eight column
+// blocks x six products = 768 matrix-pipe cycles, the weights come pre-split -- against 2048 cycles of v_mfma_f32_16x16x4_f32
+// for the same tile.  Layers of at least 128 columns whose weight block has pre-split planes.
+static bool launch_bf_value_rows(hipStream_t st, const LinArgs<float>& a) {
+  if (a.cfg_bf < 3 || a.Wbf == nullptr || a.ldw < 128 || a.TP != 1 || !bf_pays(a, 6)) return false;
+  const long rows = (long)a.B * a.nrows;
+  launch_bf<1, 8, 0, 1, true>(st, a, (unsigned)((rows + 63) / 64), (unsigned)((a.ldw + 127) / 128));
+  return true;
 }
 template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
   static bool run(hipStream_t, const LinArgs<real>&, unsigned, unsigned) { return false; }
@@ -814,8 +839,9 @@ template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
 template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
   static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
     if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
-    if (a.cfg_bf == 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
-    launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
+    if (a.cfg_bf >= 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2 / 3: only the 48-lane Laplacian tiles (measured faster there)
+    if (a.Wbf != nullptr && GPW > 0 && MR == 3 && WN == 1 && a.cfg_bf >= 3) launch_bf<MR, NR, GPW, WN, (GPW > 0 && MR == 3 && WN == 1)>(st, a, gx, gy);
+    else launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
     return true;
   }
 };
@@ -930,6 +956,7 @@ template <typename real, int MRH> static bool launch_split(hipStream_t st, const
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
     case 1: {
+      if constexpr (sizeof(real) == 4) { if (launch_bf_value_rows(st, a)) break; }
       // value-only rows (Metropolis sub-steps of the larger ansatzes): small batches would leave CUs idle with
       // 256-row tiles, so the tile height follows the row count (aim: >= 8 workgroups per CU)
       const long rows = (long)a.B * a.nrows;

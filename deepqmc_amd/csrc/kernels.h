@@ -43,6 +43,11 @@ template <typename real> struct LinArgs {
   LinPiece<real> piece[4];
   const real* W;      // [sum K][ldw]
   int ldw;            // pad4(Nout)
+  // float32 contexts: the same weight block split into three bf16 planes on the host (Engine::set_weights), PAIRS of
+  // consecutive k rows packed per 32-bit word: plane p, element (k pair, column) at Wbf[p * wbf_plane + (k / 2) * ldw + column];
+  // nullptr: not available for this layer
+  const uint32_t* Wbf;
+  long wbf_plane;
   const real* bias;   // [ldw] or nullptr (value lane only)
   real* dst;
   int ld_dst, rpw_dst, r0_dst, col0_dst;

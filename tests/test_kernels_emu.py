@@ -289,7 +289,7 @@ def test_linear_layers_on_the_bf16_pipe_match_float64():
     eng.set_option('fused', 0)                     # the layered value path: k_linear / k_linear_bf with value-only rows
     err = {}
     try:
-        for bf in (0, 1):
+        for bf in (0, 1, 3):       # 3: the default's Laplacian tiles + value-only rows as 64 x 128 tiles with PRE-SPLIT weight planes
             eng.set_option('linear_bf', bf)
             e = eng.local_energy(torch.as_tensor(r.astype(np.float32)))[0].numpy().astype(np.float64)
             err[bf] = np.abs(e - ref) / np.maximum(1.0, np.abs(ref))
@@ -299,6 +299,7 @@ def test_linear_layers_on_the_bf16_pipe_match_float64():
     finally:
         eng.set_option('linear_bf', 2)             # (process-wide switch: back to the default)
     assert np.median(err[1]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 1e-7
+    assert np.median(err[3]) < 5e-6
 
 
 def test_emu_column_tiles_share_an_xcd_mapping():
