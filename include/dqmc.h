@@ -306,7 +306,7 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * hardware's oldest-wave-first order (2: unit by unit, 0: off); "fused_bf" (float32 contexts; 1: the float32 layers of the
  * fused kernel whose pieces are whole octets wide run on the bf16 matrix pipe -- operands split into three bf16 pieces,
  * six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, float32-class results; 2: only the layers deep enough to pay by
- * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (2; process-wide): the same split with nine
+ * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (2): the same split with nine
  * products for the per-op linear kernel -- 2: only the Laplacian tiles of the 48-lane groups (11-15 electrons), where it is
  * faster; 1: every layer deep enough (measured slower elsewhere); 0: never; "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
@@ -319,6 +319,16 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
  * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set),
  * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
+ * Round 4: "linear_bf", "linear_bkx", "linear_f64_nr1" act on the calling context only (they were process-wide);
+ * "linear_bf" 3 = 2 + value-only rows as 64 x 128 tiles on the bf16 pipe with host-split weight planes (measured slower);
+ * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per
+ * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row
+ * block; "attention_ncb" (-1: kernel instance per number of key tiles in float32, four-tile instance in float64);
+ * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance, "mlp_dual" (0): two such MLPs
+ * on the same input rows in one launch (measured slower); "linear_bkx_big" / "linear_bkx_val" (0): 32-wide K chunks for the
+ * 128 x 128 tiles / value-only rows (measured slower / neutral); "ecp_mixed" (1), "ecp_heavy_e6" (10000), "ecp_skip_e12"
+ * (100): mixed-precision non-local ECP quadrature (dqmc_ecp_counts); "refine_defer" (0): dqmc_refine_finish;
+ * passes of fewer than 64 walkers are never captured into graphs.
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 
