@@ -82,27 +82,112 @@ template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 1
 // chained two-layer MLP (k_linear<..., CHAIN = true>): row-major [BM][HS], zero where the row / column does not exist,
 // so that the second layer can multiply whole chunks.
 template <typename real> struct HbmSink {
-  const LinArgs<real>& a;
+  // (the fields it needs, by value: a reference to the kernel's argument struct kept the whole struct in scratch)
+  real* dst;
+  const real* res;
+  real res_scale;
+  int ld_dst, ld_res, col0_dst, rpw_dst, r0_dst, rpw_res, r0_res, TP, nrows;
   long drow0[2], rrow0[2];
-  __device__ __forceinline__ HbmSink(const LinArgs<real>& a_) : a(a_) {}
+  __device__ __forceinline__ HbmSink(const LinArgs<real>& a)
+      : dst(a.dst), res(a.res), res_scale(a.res_scale), ld_dst(a.ld_dst), ld_res(a.ld_res), col0_dst(a.col0_dst), rpw_dst(a.rpw_dst),
+        r0_dst(a.r0_dst), rpw_res(a.rpw_res), r0_res(a.r0_res), TP(a.TP), nrows(a.nrows) {}
+  // first destination / residual row of group g = (walker, row)
+  __device__ __forceinline__ void rows(int g, long& d, long& r) const {
+    const int b = g / nrows, rr = g - b * nrows;
+    d = ((long)b * rpw_dst + r0_dst + rr) * TP;
+    r = res ? ((long)b * rpw_res + r0_res + rr) * TP : 0;
+  }
   __device__ __forceinline__ void group(int slot, int g) {
-    const int b = g / a.nrows, rr = g - b * a.nrows;
-    drow0[slot] = ((long)b * a.rpw_dst + a.r0_dst + rr) * a.TP;
-    rrow0[slot] = a.res ? ((long)b * a.rpw_res + a.r0_res + rr) * a.TP : 0;
+    long d, r;
+    rows(g, d, r);
+    if (slot) { drow0[1] = d; rrow0[1] = r; } else { drow0[0] = d; rrow0[0] = r; }      // (selects: a per-lane index would put the arrays in scratch)
   }
-  __device__ __forceinline__ void put(int slot, int t, int /*tile_row*/, int col, real o, bool ok) {
+  // The residual of one element (0 without one).  Callers fetch a BATCH of elements before they store the batch: the
+  // destination may alias the residual buffer, so the compiler never moves a residual load above an earlier store itself
+  // -- element by element (load, wait for it, add, store) every lane paid one memory latency per element (value rows of
+  // a 256 x 128 tile: 64 in a row, 2.2 ms for a launch whose products take 0.6).
+  __device__ __forceinline__ real fetch_at(long rrow, int col, bool ok) const {
+    if (res == nullptr || !ok) return (real)0;
+    return res[rrow * ld_res + col0_dst + col];
+  }
+  __device__ __forceinline__ void put_at(long drow, int /*tile_row*/, int col, real o, real r, bool ok) {
     if (!ok) return;
-    const long dr = slot ? drow0[1] : drow0[0], rr = slot ? rrow0[1] : rrow0[0];      // (selects: a per-lane index would put the arrays in scratch)
-    if (a.res != nullptr) o = (a.res[(rr + t) * a.ld_res + a.col0_dst + col] + o) * a.res_scale;
-    a.dst[(dr + t) * a.ld_dst + a.col0_dst + col] = o;
+    if (res != nullptr) o = (r + o) * res_scale;
+    dst[drow * ld_dst + col0_dst + col] = o;
   }
+  __device__ __forceinline__ real fetch(int slot, int t, int col, bool ok) const { return fetch_at((slot ? rrow0[1] : rrow0[0]) + t, col, ok); }
+  __device__ __forceinline__ void put(int slot, int t, int tile_row, int col, real o, real r, bool ok) { put_at((slot ? drow0[1] : drow0[0]) + t, tile_row, col, o, r, ok); }
 };
 template <typename real> struct LdsSink {
   real* hs;
   int stride;
+  __device__ __forceinline__ void rows(int, long& d, long& r) const { d = 0; r = 0; }
   __device__ __forceinline__ void group(int, int) {}
-  __device__ __forceinline__ void put(int, int, int tile_row, int col, real o, bool ok) { hs[tile_row * stride + col] = ok ? o : (real)0; }
+  __device__ __forceinline__ real fetch_at(long, int, bool) const { return (real)0; }
+  __device__ __forceinline__ void put_at(long, int tile_row, int col, real o, real, bool ok) { hs[tile_row * stride + col] = ok ? o : (real)0; }
+  __device__ __forceinline__ real fetch(int, int, int, bool) const { return (real)0; }
+  __device__ __forceinline__ void put(int, int, int tile_row, int col, real o, real, bool ok) { put_at(0, tile_row, col, o, (real)0, ok); }
 };
+
+// the nonlinearity alone, for a compile-time activation code (value rows: no derivatives, no per-element dispatch)
+template <typename real, int ACT> __device__ __forceinline__ real act_value(real v) {
+  real y, d1, d2;
+  act_derivs<real>(ACT, v, y, d1, d2);
+  return y;
+}
+
+// Value-only rows (GPW = 0): every accumulator row is a (walker, row) of its own.  Per row block: the four row addresses of
+// a lane once, then ALL residual / per-walker pre-activation loads of the block, then the arithmetic and the stores.
+template <typename real, int MR, int NR, int ACT, typename Sink>
+__device__ __forceinline__ void value_rows_epilogue(typename Mfma<real>::acc_t (&acc)[MR][NR], int nrows, int ld_pre, const real* bias,
+                                                    int ldw, const real* pre, int col_w0, int wm, int n_groups, Sink& sink, int bx) {
+  constexpr int BM = 64 * MR;
+  const int lane = threadIdx.x & 63, cl = lane & 15;
+  real bv[NR];
+  bool col_ok[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) {
+    const int col = col_w0 + n * 16 + cl;
+    col_ok[n] = col < ldw;
+    bv[n] = (bias != nullptr && col_ok[n]) ? bias[col] : (real)0;
+  }
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int r0 = 0; r0 < 4; r0 += 2) {       // two of a lane's four rows at a time: 2 NR loads of each kind in flight, few live registers
+      bool m_ok[2];
+      int b[2];
+      long drow[2], rrow[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int m = bx * BM + wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, r0 + q);
+        m_ok[q] = m < n_groups;
+        b[q] = (m_ok[q] ? m : 0) / nrows;
+        sink.rows(m_ok[q] ? m : 0, drow[q], rrow[q]);
+      }
+      real rres[2][NR], rpre[2][NR];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_w0 + n * 16 + cl;
+          rres[q][n] = sink.fetch_at(rrow[q], col, col_ok[n] && m_ok[q]);
+          rpre[q][n] = (pre != nullptr && col_ok[n]) ? pre[(long)b[q] * ld_pre + col] : (real)0;
+        }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int tile_row = wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, r0 + q);
+#pragma unroll
+        for (int n = 0; n < NR; ++n) {
+          const int col = col_w0 + n * 16 + cl;
+          real v = acc[i][n][r0 + q];
+          if (pre != nullptr && col_ok[n]) v += rpre[q][n];
+          if (bias != nullptr && col_ok[n]) v += bv[n];
+          sink.put_at(drow[q], tile_row, col, act_value<real, ACT>(v), rres[q][n], col_ok[n] && m_ok[q]);
+        }
+      }
+    }
+}
 
 // bias + nonlinearity with the forward-Laplacian chain rule on the accumulators of one wave (header comment), results to
 // `sink`.  MR x NR accumulator tiles; wave `wm` of the workgroup's M stack; col_w0 = first column of the wave's tile.
@@ -113,7 +198,6 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
   constexpr bool HALF = GPW == -1;
   constexpr bool SPLIT = GPW == -2;
   constexpr int GB = GPW > 0 ? MR / GPW : 1;
-  constexpr int BM = 64 * MR;
   const int lane = threadIdx.x & 63, cl = lane & 15;
   if (HALF) {
     // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15); a lane's four rows
@@ -128,6 +212,14 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         g_ok[h] = g < n_groups;
         sink.group(h, g_ok[h] ? g : 0);
       }
+      real rres[NR][4];                       // (residuals of the whole row block before its first store: HbmSink::fetch)
+#pragma unroll
+      for (int n = 0; n < NR; ++n)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, col = col_w0 + n * 16 + cl;
+          rres[n][rg] = sink.fetch(h, row & 7, col, col < ldw && (h ? g_ok[1] : g_ok[0]));
+        }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
         const int col = col_w0 + n * 16 + cl;
@@ -159,7 +251,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           else if (tt < a.T - 1) o = d1h * x;
           else if (tt == a.T - 1) o = d1h * x + d2h * Sh;
           else o = 0;
-          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, col_ok && (h ? g_ok[1] : g_ok[0]));
+          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, rres[n][rg], col_ok && (h ? g_ok[1] : g_ok[0]));
         }
       }
     }
@@ -217,6 +309,11 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
       real v = xv[n * 16 + cl];
       if (bias != nullptr && col_ok) v += bias[col];
       const real S = xs[n * 16 + cl] + xs[NR * 16 + n * 16 + cl];
+      real rres[MR][4];
+#pragma unroll
+      for (int tb = 0; tb < MR; ++tb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) rres[tb][rg] = sink.fetch(0, t0 + tb * 16 + Mfma<real>::row_of(lane, rg), col, col_ok && g_ok);
       real y, d1, d2;
       act_derivs<real>(act, v, y, d1, d2);
 #pragma unroll
@@ -231,7 +328,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           else if (t < a.T - 1) o = d1 * x;
           else if (t == a.T - 1) o = d1 * x + d2 * S;
           else o = 0;
-          sink.put(0, t, wm * (16 * MR) + tb * 16 + row, col, o, col_ok && g_ok);
+          sink.put(0, t, wm * (16 * MR) + tb * 16 + row, col, o, rres[tb][rg], col_ok && g_ok);
         }
     }
   } else if (GPW > 0) {
@@ -274,44 +371,42 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         const real S = quad_sum<real>(s_part);
         real y, d1, d2;
         act_derivs<real>(act, v, y, d1, d2);
+        // residuals in batches of FB row blocks ahead of that batch's stores (HbmSink::fetch); float64: two row blocks, the
+        // tall tiles have no registers to spare
+        constexpr int FB = ((sizeof(real) == 8 && GB > 2) || GB == 4) ? 2 : GB;      // (GB = 4 in float32: 16 more registers would cost the 64-lane tiles a workgroup per CU)
 #pragma unroll
-        for (int tb = 0; tb < GB; ++tb)
+        for (int tb0 = 0; tb0 < GB; tb0 += FB) {
+          real rres[FB][4];
 #pragma unroll
-          for (int rg = 0; rg < 4; ++rg) {
-            const int row = Mfma<real>::row_of(lane, rg);
-            const int t = tb * 16 + row;
-            const real x = acc[gj * GB + tb][n][rg];
-            real o;
-            if (t == 0) o = y;
-            else if (t < a.T - 1) o = d1 * x;
-            else if (t == a.T - 1) o = d1 * x + d2 * S;
-            else o = 0;
-            sink.put(0, t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, col_ok && g_ok);
-          }
+          for (int tb = 0; tb < FB; ++tb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              rres[tb][rg] = (tb0 + tb < GB) ? sink.fetch(0, (tb0 + tb) * 16 + Mfma<real>::row_of(lane, rg), col, col_ok && g_ok) : (real)0;
+#pragma unroll
+          for (int tb = tb0; tb < tb0 + FB && tb < GB; ++tb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int row = Mfma<real>::row_of(lane, rg);
+              const int t = tb * 16 + row;
+              const real x = acc[gj * GB + tb][n][rg];
+              real o;
+              if (t == 0) o = y;
+              else if (t < a.T - 1) o = d1 * x;
+              else if (t == a.T - 1) o = d1 * x + d2 * S;
+              else o = 0;
+              sink.put(0, t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, rres[tb - tb0][rg], col_ok && g_ok);
+            }
+        }
       }
     }
   } else {
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int tile_row = wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg);
-        const int m = bx * BM + tile_row;
-        const bool m_ok = m < n_groups;
-        const int b = (m_ok ? m : 0) / a.nrows;
-        sink.group(0, m_ok ? m : 0);
-#pragma unroll
-        for (int n = 0; n < NR; ++n) {
-          const int col = col_w0 + n * 16 + cl;
-          const bool col_ok = col < ldw;
-          real v = acc[i][n][rg];
-          if (pre != nullptr && col_ok) v += pre[(long)b * a.ld_pre + col];
-          if (bias != nullptr && col_ok) v += bias[col];
-          real y, d1, d2;
-          act_derivs<real>(act, v, y, d1, d2);
-          sink.put(0, 0, tile_row, col, y, col_ok && m_ok);
-        }
-      }
+    switch (act) {          // (wave-uniform; one unrolled, branch-free body per activation)
+      case 1: value_rows_epilogue<real, MR, NR, 1>(acc, a.nrows, a.ld_pre, bias, ldw, pre, col_w0, wm, n_groups, sink, bx); break;
+      case 2: value_rows_epilogue<real, MR, NR, 2>(acc, a.nrows, a.ld_pre, bias, ldw, pre, col_w0, wm, n_groups, sink, bx); break;
+      case 3: value_rows_epilogue<real, MR, NR, 3>(acc, a.nrows, a.ld_pre, bias, ldw, pre, col_w0, wm, n_groups, sink, bx); break;
+      case 4: value_rows_epilogue<real, MR, NR, 4>(acc, a.nrows, a.ld_pre, bias, ldw, pre, col_w0, wm, n_groups, sink, bx); break;
+      default: value_rows_epilogue<real, MR, NR, 0>(acc, a.nrows, a.ld_pre, bias, ldw, pre, col_w0, wm, n_groups, sink, bx); break;
+    }
   }
 }
 
@@ -339,7 +434,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // pass through the LDS tile one after the other.  The second MLP's pointers are LinArgs::*_b; shapes, activations and the
 // destination geometry are those of the first.
 template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1, bool DUAL = false>
-__global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : 1) k_linear(const LinArgs<real> a) {
+__global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && MR == 4 && NR == 4 && WN == 2 && sizeof(real) == 4) ? 4 : 1) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
   constexpr int AS = BK + 2, BS = BStride<BN>::v;
