@@ -49,13 +49,8 @@ typedef const DQMC_UNIFORM ::dqmc_op* OpPtr;
 // e -> 0 gives -1); the epilogues were 30 % of this kernel's VALU instructions, its most contended pipe.
 template <typename real> __device__ __forceinline__ real fast_tanh(real x);
 template <> __device__ __forceinline__ float fast_tanh<float>(float x) {
-#if defined(__HIPCC__)
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);       // e^{2x}
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
-#else
-  const float e = exp2f(x * 2.8853900817779268f);
-  return fmaf(-2.0f, 1.0f / (e + 1.0f), 1.0f);
-#endif
 }
 template <> __device__ __forceinline__ double fast_tanh<double>(double x) { return tanh(x); }
 

@@ -426,7 +426,8 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // stream their rows once) are bound by the latency of the chunk loads, not by bandwidth or MFMA rate -- each thread has
 // one 16-byte A load and one B load in flight per chunk; BKX = 2 doubles the bytes in flight per workgroup and halves
 // the number of load -> barrier -> multiply round trips.
-// (second launch bound = waves per SIMD the register allocation must leave room for: the split-group tiles exist to run
+// (second launch bound = waves per SIMD the register allocation must leave room for; the 8-wave value-row tiles -- 256 x 128
+// in float32, 128 x 128 in float64 -- are to run two workgroups per CU = four waves per SIMD; the split-group tiles exist to run
 // two waves per SIMD -- unconstrained, the 4 x 4 float64 tile takes 200 + 128 registers and one wave remains)
 // DUAL (CHAIN only): TWO such MLPs on the same input rows -- the node MLPs h of the two edge types of a message-passing layer
 // (reference gnn/electron_gnn.py:139-160: one subnet per edge type, each applied to the same node embeddings) -- in one
@@ -434,7 +435,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // pass through the LDS tile one after the other.  The second MLP's pointers are LinArgs::*_b; shapes, activations and the
 // destination geometry are those of the first.
 template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1, bool DUAL = false>
-__global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && MR == 4 && NR == 4 && WN == 2 && sizeof(real) == 4) ? 4 : 1) k_linear(const LinArgs<real> a) {
+__global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4 && WN == 2 && MR * sizeof(real) == 16) ? 4 : 1) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
   constexpr int AS = BK + 2, BS = BStride<BN>::v;
@@ -1058,6 +1059,11 @@ template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>&
       const long col_blocks = (a.ldw + 127) / 128;
       // (measured on N2 / FermiNet, 57 k rows x 256 columns: 64-row tiles 35.5 ms of linear time per step, 128-row 36.9,
       // 256-row 49.1 -- the tall tiles pay only when there are thousands of them)
+      if constexpr (sizeof(real) == 8) {
+        // float64 value rows by the hundred thousand (the heavy pairs of an ECP quadrature): 128 x 128 tiles on 8 waves --
+        // launch_nr's 32-column float64 tiles stream the A rows of a 256-wide layer eight times (38 TF/s measured)
+        if (a.ldw > 64 && (rows + 127) / 128 * col_blocks >= 1024) { launch_cfg<real, 2, 4, 0, 2>(st, a); break; }
+      }
       if ((rows + 255) / 256 * col_blocks >= 2048) launch_nr<real, 4, 0>(st, a);
       else if ((rows + 127) / 128 * col_blocks >= 2048) launch_nr<real, 2, 0>(st, a);
       else launch_nr<real, 1, 0>(st, a);

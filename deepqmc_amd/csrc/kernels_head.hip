@@ -27,36 +27,66 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
   const int N = li.N, KN = K * N;
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)B * N * KN;
-  if (idx >= total) return;
-  const int kmu = (int)(idx % KN);
-  const long q = idx / KN;
-  const int i = (int)(q % N);
-  const int b = (int)(q / N);
-  const int k = kmu / N, mu = kmu - k * N;
-  const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc * n_env;
-  const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc * n_env;
-  double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
   const bool need_d = li.T > 1;
-  // The table rows of neighbouring threads (orbitals) are L = n_nuc*n_env elements apart, so scalar reads touch
-  // 64 cache lines per wave load; rows with L % 4 == 0 are fetched as float4 (4x fewer requests -- this, not the
-  // exponentials, bounded the value-mode launches of the larger systems).
   const int L = n_nuc * n_env;
-  const bool vec = (L & 3) == 0;
-  const real* rp = r + ((long)b * N + i) * 3;
   if (!need_d && sizeof(real) == 4) {
-    // value-only evaluation of the float32 build (Metropolis sub-steps, ECP quadrature walkers) on the f32 exp unit
+    // Value-only evaluation of the float32 build (Metropolis sub-steps, ECP quadrature walkers: hundreds of thousands of
+    // rows per launch).  The launch was bound by its arithmetic -- every thread took n_nuc square roots and L libm
+    // exponentials (~ 540 instructions for benzene, 6.8 ms per 690 k rows) for 8 bytes of traffic.  Now: the block's
+    // electron-nucleus distances once, into LDS (a block of 256 orbitals spans 1 + 256 / KN electrons); exponentials
+    // on the hardware exp2 unit with the rounding error of x log2(e) carried along (1-2 ulp, as accurate as expf).
+    constexpr int RHO_CAP = 2048;
+    __shared__ float rho_s[RHO_CAP];
+    const long idx0 = (long)blockIdx.x * blockDim.x;
+    const long idx1 = idx0 + blockDim.x < total ? idx0 + blockDim.x : total;      // (idx0 < total: the grid is sized to it)
+    const long q0 = idx0 / KN, q1 = (idx1 - 1) / KN;
+    const int nq = (int)(q1 - q0 + 1);
+    const bool staged = (long)nq * n_nuc <= RHO_CAP;      // (uniform over the block)
+    if (staged) {
+      for (int e = threadIdx.x; e < nq * n_nuc; e += blockDim.x) {
+        const int qq = e / n_nuc, nuc = e - qq * n_nuc;
+        const real* rq = r + (q0 + qq) * 3;
+        float d2 = (float)eps;
+        for (int c = 0; c < 3; ++c) { const float d = (float)rq[c] - (float)R[nuc * 3 + c]; d2 += d * d; }
+        rho_s[e] = sqrtf(d2);
+      }
+      __syncthreads();
+    }
+    if (idx >= total) return;
+    // (64-bit divisions are ~100 instructions each: one pair per block on uniform values, 32-bit arithmetic per thread)
+    const int lo = (int)(idx0 - q0 * KN) + (int)threadIdx.x;
+    const int dq = lo / KN, kmu = lo - dq * KN;
+    const long q = q0 + dq;
+    const long b0 = q0 / N;
+    const int ii = (int)(q0 - b0 * N) + dq;
+    const int b = (int)b0 + ii / N, i = ii % N;
+    const int k = kmu / N, mu = kmu - k * N;
+    const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * L;
+    const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * L;
+    const real* rp = r + q * 3;
+    const float* rho_q = rho_s + (q - q0) * n_nuc;
     float acc = 0.f, rho = 0.f;
     int nuc = 0, ev = 0;
     auto entry = [&](float pa, float za) {
       if (ev == 0) {
-        float d2 = (float)eps;
-        for (int c = 0; c < 3; ++c) { const float d = (float)rp[c] - (float)R[nuc * 3 + c]; d2 += d * d; }
-        rho = sqrtf(d2);
+        if (staged) {
+          rho = rho_q[nuc];
+        } else {
+          float d2 = (float)eps;
+          for (int c = 0; c < 3; ++c) { const float d = (float)rp[c] - (float)R[nuc * 3 + c]; d2 += d * d; }
+          rho = sqrtf(d2);
+        }
       }
-      acc += pa * expf(-fabsf(za) * rho);
+      const float x = -fabsf(za) * rho;
+      const float t = x * 1.44269504f;
+      const float e = __builtin_fmaf(x, 1.44269504f, -t) + x * 1.92596303e-8f;      // x log2(e) = t + e
+      const float p2 = __builtin_amdgcn_exp2f(t);
+      acc += pa * __builtin_fmaf(p2, e * 0.693147181f, p2);
       if (++ev == n_env) { ev = 0; ++nuc; }
     };
-    if (vec) {
+    // The table rows of neighbouring threads (orbitals) are L elements apart, so scalar reads touch 64 cache lines per
+    // wave load; rows with L % 4 == 0 are fetched as float4 (4x fewer requests).
+    if ((L & 3) == 0) {
       for (int a4 = 0; a4 < L; a4 += 4) {
         const Vec4<real> p4 = *reinterpret_cast<const Vec4<real>*>(pi + a4), z4 = *reinterpret_cast<const Vec4<real>*>(ze + a4);
 #pragma unroll
@@ -69,6 +99,18 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
         (real)(acc * (float)bf[(((long)b * N + i) * li.TP) * bf_width + kmu]);
     return;
   }
+  if (idx >= total) return;
+  const int kmu = (int)(idx % KN);
+  const long q = idx / KN;
+  const int i = (int)(q % N);
+  const int b = (int)(q / N);
+  const int k = kmu / N, mu = kmu - k * N;
+  const real* pi = (i < n_up ? pi_up : pi_dn) + (long)kmu * n_nuc * n_env;
+  const real* ze = (i < n_up ? ze_up : ze_dn) + (long)kmu * n_nuc * n_env;
+  double e0 = 0, eL = 0, eJ[3] = {0, 0, 0};
+  // (table rows as float4 where L % 4 == 0: see the value-only branch)
+  const bool vec = (L & 3) == 0;
+  const real* rp = r + ((long)b * N + i) * 3;
   {
     const double* Q = phq ? phq + ((long)b * N + i) * PH_STRIDE : nullptr;
     double rho = 0, u[3] = {0, 0, 0}, g2 = 0, lr = 0;
@@ -412,7 +454,6 @@ __global__ void __launch_bounds__(256, 2) k_slogdet_mfma(const real* __restrict_
   double* Inv = A + N16 * NS;                           // [N16][NS] (A operand), zero outside N x N
   double* Mx = Inv + N16 * NS;                          // [N16][NS] M_c
   double* colp = Mx + N16 * NS;                         // [N16]
-  double* red = colp + N16;                             // [2][8] block reductions, double buffered
   __shared__ int piv_s;
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -682,6 +723,62 @@ __global__ void __launch_bounds__(256) k_slogdet_lu16(const real* __restrict__ o
       const double f = (used || piv == 0) ? 0.0 : a[p] / piv;
 #pragma unroll
       for (int j = p + 1; j < 16; ++j) {
+        if (j < N) {
+          const double pj = __shfl(a[j], ql, 64);
+          a[j] -= f * pj;
+        }
+      }
+    }
+  }
+  if (live && row == 0) {
+    logdet[bk * li.TP] = logabs;
+    sign_k[bk] = sgn;
+  }
+}
+
+// Value-only variant for 17..44 electrons: the register scheme of k_slogdet_lu16 with LPM = 32 (two matrices per wave,
+// N <= 32) or 64 lanes per matrix, lane i keeps row i (NC >= N columns) in registers.  The LDS-resident k_slogdet_lu
+// above spends two workgroup barriers and a 64-wide reduction per pivot on a matrix that fits the register file: 4.9 ms
+// for the 368 k 30 x 30 determinants of one quadrature batch of benzene + ECP.  Same pivoting rule (first maximum in
+// getrf's swapped order), same sign convention.
+template <typename real, int NC, int LPM>
+__global__ void __launch_bounds__(256) k_slogdet_reg(const real* __restrict__ orb, int orb_width, double* __restrict__ logdet,
+                                                     int32_t* __restrict__ sign_k, long n_mat, LaneInfo li) {
+  const int N = li.N;
+  const int lane = threadIdx.x & 63, row = lane & (LPM - 1), g0 = lane & ~(LPM - 1);      // g0: first lane of this matrix's group
+  const long bk_raw = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPM;
+  const bool live = bk_raw < n_mat;
+  const long bk = live ? bk_raw : n_mat - 1;               // idle groups shadow the last matrix (all lanes stay in the shuffles)
+  const real* base = orb + bk * li.TP * orb_width;
+  double a[NC];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) a[j] = (row < N && j < N) ? (double)base[row * N + j] : 0.0;
+  int pos = row;                                           // current position of this row in getrf's swapped order
+  bool used = row >= N;
+  double logabs = 0.0;
+  int sgn = 1;
+#pragma unroll
+  for (int p = 0; p < NC; ++p) {
+    if (p < N) {                                           // (uniform over the launch)
+      double bv = used ? -1.0 : fabs(a[p]);
+      int bpos = used ? 1 << 20 : pos, bl = row;
+#pragma unroll
+      for (int m = 1; m < LPM; m <<= 1) {
+        const double ov = __shfl_xor(bv, m, 64);
+        const int op = __shfl_xor(bpos, m, 64), ol = __shfl_xor(bl, m, 64);
+        if (ov > bv || (ov == bv && op < bpos)) { bv = ov; bpos = op; bl = ol; }
+      }
+      const int ql = g0 + bl;                              // lane holding the pivot row
+      const double piv = __shfl(a[p], ql, 64);
+      if (bpos != p) sgn = -sgn;                           // getrf swaps rows p and bpos
+      if (pos == p && row != bl) pos = bpos;               // the row that sat at position p moves to where the pivot row was
+      if (row == bl) { pos = p; used = true; }
+      logabs += log(fabs(piv));
+      if (piv < 0) sgn = -sgn;
+      if (piv == 0) sgn = 0;
+      const double f = (used || piv == 0) ? 0.0 : a[p] / piv;
+#pragma unroll
+      for (int j = p + 1; j < NC; ++j) {
         if (j < N) {
           const double pj = __shfl(a[j], ql, 64);
           a[j] -= f * pj;
@@ -1023,6 +1120,12 @@ void launch_slogdet(hipStream_t st, const real* orb, int orb_width, double* logd
                        sign_k, n_mat, li, cond);
   else if (li.T == 1 && li.N <= 16 && slogdet_use_mfma != 3)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu16<real>), dim3((unsigned)((n_mat * 16 + 255) / 256)), dim3(256), 0, st, orb, orb_width,
+                       logdet, sign_k, n_mat, li);
+  else if (li.T == 1 && li.N <= 32 && slogdet_use_mfma != 3)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_reg<real, 32, 32>), dim3((unsigned)((n_mat * 32 + 255) / 256)), dim3(256), 0, st, orb, orb_width,
+                       logdet, sign_k, n_mat, li);
+  else if (li.T == 1 && li.N <= 44 && slogdet_use_mfma != 3)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_reg<real, 44, 64>), dim3((unsigned)((n_mat * 64 + 255) / 256)), dim3(256), 0, st, orb, orb_width,
                        logdet, sign_k, n_mat, li);
   else if (li.T == 1)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slogdet_lu<real>), dim3(grid), dim3(64), sizeof(double) * li.N * (li.N | 1), st,

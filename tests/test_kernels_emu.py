@@ -124,8 +124,8 @@ def test_emu_rng_moments():
 
 
 def test_emu_value_slogdet_lu_n2():
-    """Value-only psi of N2 (14 electrons): the wave-per-matrix LU kernel (k_slogdet_lu: wave arg-max pivot
-    search, 8x8 trailing update) against numpy slogdet -- log|det| and the bit-exact sign of every determinant."""
+    """Value-only psi of N2 (14 electrons): the sixteen-lanes-per-matrix LU kernel (k_slogdet_lu16) against the oracle's
+    slogdet -- log|det| and the bit-exact sign of every determinant."""
     import dataclasses
     spec = dataclasses.replace(ferminet(), embedding_dim=16, n_interactions=1, n_determinants=3)
     mol = Molecule.from_name('N2')
@@ -142,6 +142,31 @@ def test_emu_value_slogdet_lu_n2():
     np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-10, atol=1e-10)
     np.testing.assert_array_equal(sign.numpy(), val['sign'])
     np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize('molname', ['cyclobutadiene_square', 'benzene'])
+def test_emu_value_slogdet_register_lu(molname):
+    """Value-only determinants of 28 and 42 electrons: the register-resident LU (k_slogdet_reg: 32 lanes per matrix up to
+    32 electrons, 64 up to 44) and the LDS-resident k_slogdet_lu it replaces (option slogdet_mfma 3) against the oracle --
+    log|det| and the bit-exact sign of every determinant."""
+    import dataclasses
+    spec = dataclasses.replace(ferminet(), embedding_dim=16, n_interactions=1, n_determinants=2)
+    mol = Molecule.from_name(molname)
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=3, perturb_envelopes=0.3)
+    eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    eng.set_option('fused', 0)
+    B = 3                                              # (an odd count: the second half of the last wave of the 32-lane kernel idles)
+    r = make_walkers(mol, h.n_elec, B)
+    it = Interp(eng.program, mol.charges, geom.F32_EPS)
+    val = it.run(r, mol.coords, laplacian=False)
+    for opt in (1, 3):
+        eng.set_option('slogdet_mfma', opt)
+        sign, logpsi = eng.wf_eval(torch.as_tensor(r))
+        np.testing.assert_array_equal(eng.debug_read('sign_k', B), it.sign_k)
+        np.testing.assert_allclose(eng.debug_read('logdet', B), it.logdet, rtol=1e-10, atol=1e-10)
+        np.testing.assert_array_equal(sign.numpy(), val['sign'])
+        np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-10, atol=1e-10)
 
 
 @pytest.mark.parametrize('spec_fn', [paulinet, ferminet])
