@@ -17,4 +17,6 @@ tools/prof_cfg.sh n2 --molecule N2 --ansatz ferminet --n-sub 10 --steps 2 --warm
 tools/prof_cfg.sh benzene --molecule benzene --ansatz psiformer --walkers 256 --n-sub 10 --steps 1 --warmup 1 --repeats 1 > gpurun_out/prof_benzene.txt 2>&1
 tools/prof_cfg.sh c4h4 --molecule cyclobutadiene_square --ansatz transpsiformer --walkers 512 --steps 1 --warmup 1 --repeats 1 > gpurun_out/prof_c4h4.txt 2>&1
 tools/gpu_trace_eloc.sh 1 > /dev/null 2>&1
+tools/prof_cfg.sh ecp --molecule benzene --ansatz psiformer --ecp --walkers 256 --n-sub 10 --steps 1 --warmup 1 --repeats 1 --equilibrate 100 > gpurun_out/prof_ecp.txt 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1
 tail -3 gpurun_out/smoke.log; tail -4 gpurun_out/pytest_gpu.log; grep '^{' gpurun_out/bench.log | tail -1 | cut -c1-700; tail -3 gpurun_out/traffic_eloc.log; cat gpurun_out/other_configs.txt | cut -c1-260
