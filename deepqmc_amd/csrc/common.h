@@ -128,11 +128,7 @@ template <> __device__ __forceinline__ double r_exp<double>(double x) { return e
 // The hardware executes a wave's LDS operations in order, so only the compiler (and the CPU emulation harness,
 // where lanes are fibers) needs a barrier here.
 __device__ __forceinline__ void wave_lds_fence() {
-#if defined(__HIPCC__)
   __builtin_amdgcn_wave_barrier();
-#else
-  (void)__shfl(0, 0, 64);
-#endif
 }
 
 // Sum over the four 16-lane quads of a wave (same lane&15).

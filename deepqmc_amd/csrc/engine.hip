@@ -279,11 +279,7 @@ struct Engine : dqmc_ctx {
   double* d_thresh = nullptr;           // device copy of refine_thresh (read by k_final: graphs must not bake it in)
   double thresh_uploaded = -1.0;
   bool graphs_active() const {
-#if defined(__HIPCC__)
     return pass_graph && !graph_broken && !timing && !fused_dbg && ph_n == 0 && ecp_n_nl == 0;
-#else
-    return false;                         // (the SIMT emulation harness has no graph API)
-#endif
   }
   // ... and only passes that are launch-bound: up to 2 GiB of activations per pass (LiH / PauliNet: 4096 walkers in
   // float32, the twin's few hundred in float64).  The passes of the larger systems run for milliseconds per kernel: a
@@ -296,10 +292,8 @@ struct Engine : dqmc_ctx {
     return graphs_active() && B >= 64 && (double)ws_bytes_per_walker(TP) * (double)B <= 2147483648.0;
   }
   void drop_graphs() {
-#if defined(__HIPCC__)
     if (st_g && !pgraphs.empty()) (void)hipStreamSynchronize(st_g);      // (a replay may still be running)
     for (auto& g : pgraphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
-#endif
     pgraphs.clear();
   }
   int ahead_cap = 0, ahead_pos = 0;
@@ -1522,10 +1516,8 @@ struct Engine : dqmc_ctx {
     if (chunk < 1) chunk = 1;
     if (laplacian) last_chunks[0] = chunk >= B ? 1 : (int)((B + chunk - 1) / chunk);
     if (chunk >= B) {
-#if defined(__HIPCC__)
       if (laplacian && graph_fits(B))
         return run_graphed(r, R, B, logpsi, sign, e_loc, stats, grad);
-#endif
       return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
     }
     for (int b0 = 0; b0 < B; b0 += (int)chunk) {
@@ -1537,7 +1529,6 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
 
-#if defined(__HIPCC__)
   // one forward-Laplacian pass through its captured graph (see pass_graph above)
   int run_graphed(const real* r, const real* R, int B, real* logpsi, int32_t* sign, real* e_loc, real* stats, real* grad) {
     if (std::find(graph_warm.begin(), graph_warm.end(), B) == graph_warm.end()) {
@@ -1605,7 +1596,6 @@ struct Engine : dqmc_ctx {
     // addresses what the graph wrote; the slab is already large enough (the graph was captured on it), nothing is reallocated
     return plan(B, (3 * N + 2 + 15) / 16 * 16);
   }
-#endif
 
   int run_chunk(const real* r, const real* R, int B, bool laplacian, real* logpsi, int32_t* sign, real* e_loc, real* stats,
                 long stats_ld, real* grad, int b_offset) {
@@ -1851,7 +1841,7 @@ struct Engine : dqmc_ctx {
         case DQMC_OP_ATTENTION: {
           // algorithmic flops: S, dP v0 / P v_c, dP_c v_c contractions per lane
           t_begin("attention", 2.0 * B * i[4] * (double)N * (N + i[6]) * i[5] * (li.T == 1 ? 2.0 : 5.0 * li.T));
-          int rc2;
+          int rc2 = DQMC_OK;
           const bool att_mfma = attention_mfma && dqmc::attention_mfma_supported<real>(N, i[5], i[6]) &&
                                 (attention_mfma >= 2 || dqmc::attention_mfma_profitable(N));
           // (float64 only: the float32 instance of the split kernel agrees with float64 in the emulator but sent a whole benzene

@@ -26,10 +26,8 @@
 #include "common.h"
 #include "kernels.h"
 
-#if defined(__HIPCC__)
+#ifndef DQMC_UNIFORM
 #define DQMC_UNIFORM __attribute__((address_space(4)))   // constant address space: uniform loads are scalar
-#else
-#define DQMC_UNIFORM
 #endif
 
 namespace dqmc {
@@ -857,14 +855,9 @@ template <typename real, bool MA1>
 __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   HIP_DYNAMIC_SHARED(char, smem_raw)
   real* smem = reinterpret_cast<real*>(smem_raw);
-#if defined(__HIPCC__)
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#else
-  const int wave = (int)(threadIdx.x >> 6);
-#endif
   const int w0 = blockIdx.x * a.WT;
   const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
-#if defined(__HIPCC__)
   if (a.prof_wg && threadIdx.x == 0 && blockIdx.x < 8192) a.prof_wg[2 * blockIdx.x] = (long long)wall_clock64();
   if (a.stagger > 0) {
     // The workgroups that share a CU start together and would walk through the program in lockstep: all in an MFMA-
@@ -874,7 +867,6 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     const int ph = (int)(blockIdx.x / (unsigned)a.stagger_div) & 3;
     for (int i = 0; i < ph * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
-#endif
   {
     // positions of the tile -> LDS; in sub-step mode the proposal r' = r + tau * xi (electron_samplers.py:102-104)
     real* rs = smem + a.scratch_off;
@@ -918,18 +910,15 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   const bool stamp = a.prof != nullptr && blockIdx.x == 0 && (threadIdx.x & 63) == 0;
   int n_d = 0;
   if (stamp) a.prof[wave * 256] = clock64();
-#if defined(__HIPCC__)
   // The arbiter of a SIMD serves its oldest wave first, so of the four tiles that share a CU the first placed runs at
   // nearly the speed of a lone tile and the last placed absorbs all the waiting (89 / 101 / 116 / 129 us) -- and the CU runs
   // three, two, one tile(s) for the last 40 us.  Rotating the issue priority among the co-resident tiles lets them advance
   // together (workgroup b is the (b / n_cu)-th placed on its CU: dispatch fills the CUs breadth-first).
   const int prio_slot = a.prio_mode ? (int)(blockIdx.x / (unsigned)a.stagger_div) & 3 : 0;
   int prio_tick = 0;
-#endif
   for (;; ++d) {
     const int kind = d->kind;
     if (kind == 0) break;
-#if defined(__HIPCC__)
     if (a.prio_mode && (kind == 2 || a.prio_mode == 2)) {
       ++prio_tick;
       const int pv = prio_slot + prio_tick;
@@ -940,7 +929,6 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
         default: __builtin_amdgcn_s_setprio(3); break;
       }
     }
-#endif
     if (kind == 2) {
       __syncthreads();
     } else if (kind == 4) {
@@ -977,9 +965,7 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   if (a.mc.enabled) {
     fused2_mc_tail<real>(a, nw, stamp ? a.prof + wave * 256 + n_d + 1 : nullptr);     // every wave list ends with a barrier
   }
-#if defined(__HIPCC__)
   if (a.prof_wg && threadIdx.x == 0 && blockIdx.x < 8192) a.prof_wg[2 * blockIdx.x + 1] = (long long)wall_clock64();
-#endif
 }
 
 // OCC = workgroups (of 4 waves) the register allocation must leave room for per CU.

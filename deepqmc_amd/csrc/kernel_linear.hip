@@ -657,11 +657,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 //   * NP = 9: all products of the pieces, the result is a float32 product sum with FEWER roundings than the
 //     v_mfma_f32_16x16x4_f32 chain (144 instead of 256 matrix-pipe cycles per 16 x 16 x 32 block) -- the Laplacian
 //     pass, whose derivative lanes cancel; NP = 6 (96 cycles) drops the three terms below 2^-24: value-only rows.
-__device__ __forceinline__ void sched_fence() {
-#if defined(__HIPCC__)
-  __builtin_amdgcn_sched_barrier(0);
-#endif
-}
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 48-row x 64-column wave tiles of
 // the 48-lane groups need 172 registers unconstrained -- two waves per SIMD -- and fit three with 168)
 // PRE: the weights arrive already split (LinArgs::Wbf: three planes of bf16 PAIRS along k, made on the host by

@@ -165,7 +165,11 @@ __global__ void __launch_bounds__(256) k_orbitals(const real* __restrict__ r, co
     const double bt = (double)brow[(long)t * bf_width];
     double o = e0 * bt;
     const int c = t - 1;
-    if (c / 3 == i) { o += eJ[c - 3 * i] * b0; lap_cross += 2.0 * eJ[c - 3 * i] * bt; }
+    if (c / 3 == i) {
+      const int c3 = c - 3 * i;
+      const double ej = c3 == 0 ? eJ[0] : c3 == 1 ? eJ[1] : eJ[2];      // (selects: a runtime index would put eJ in scratch)
+      o += ej * b0; lap_cross += 2.0 * ej * bt;
+    }
     orow[(long)t * orb_width] = (real)o;
   }
   const int tl = li.T - 1;

@@ -33,6 +33,7 @@ extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 typedef int hipError_t;
 #define hipSuccess 0
+#define hipErrorNotSupported 801
 typedef struct simt_stream* hipStream_t;
 typedef struct simt_event { double t; }* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -97,6 +98,26 @@ template <typename T> inline T __shfl_xor(T v, int mask, int = 64) {
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline void __threadfence() {}
+inline long long wall_clock64() { return 0; }
+// scheduling / scalarisation hints of the device build: no-ops on the host
+inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+// (lanes are fibers here: the wave-level ordering point has to yield to the other lanes, which a shuffle does)
+inline void __builtin_amdgcn_wave_barrier() { (void)__shfl(0, 0, 64); }
+// constant address space qualifier of the fused kernel's descriptor pointers
+#define DQMC_UNIFORM
+// No graph API in the harness: capture is refused, the engine falls back to eager launches (Engine::graph_broken).
+typedef struct simt_graph* hipGraph_t;
+typedef struct simt_graph_exec* hipGraphExec_t;
+#define hipStreamCaptureModeRelaxed 2
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t, void*, void*, size_t) { *e = nullptr; return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 inline long long clock64() { static long long t = 0; return ++t; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p += v; return o; }
 inline float atomicAdd(float* p, float v) { float o = *p; *p += v; return o; }
