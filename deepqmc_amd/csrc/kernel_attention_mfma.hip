@@ -63,9 +63,11 @@ k_attention_mfma(const real* __restrict__ q, const real* __restrict__ k, const r
   const int M16 = n_cb * 16, N16 = n_rb * 16;
   const int SA = M16 + 2;                             // row stride of the per-wave [16][keys] A-operand tile
   const int nkd = hd / 4, nkm = M16 / 4;              // k-steps of the S-phase / of the O-phase
+  // (value-only launches have no current-lane k / v tiles: the launcher allocates 30 instead of 47 KB for 30 electrons x 64,
+  // five instead of three workgroups share a CU -- the launch is bound by the latency of its tile loads)
   real* k0 = sm;                real* v0 = k0 + M16 * S;
-  real* qc = v0 + M16 * S;      real* kc = qc + N16 * S;   real* vc = kc + M16 * S;
-  real* DA = vc + M16 * S;                            // [n_rb waves][16][SA]  dP_t (and once P) as A operand
+  real* qc = v0 + M16 * S;      real* kc = qc + N16 * S;   real* vc = kc + (T > 1 ? M16 * S : 0);
+  real* DA = vc + (T > 1 ? M16 * S : 0);              // [n_rb waves][16][SA]  dP_t (and once P) as A operand
   const real sc = (real)(1.0 / sqrt((double)hd));
   const long row0 = (long)b * N * TP;
   const int col0 = h * hd;
@@ -653,7 +655,11 @@ static int launch_attention_mfma_ncb(hipStream_t st, const real* q, const real* 
 template <typename real>
 int launch_attention_mfma(hipStream_t st, const real* q, const real* k, const real* v, real* out, int width, int H,
                           int hd, int B, LaneInfo li, int n_const, const real* k_const, const real* v_const, int exact_tiles) {
-  const size_t lds = attention_mfma_lds_bytes<real>(li.N, hd, n_const);
+  size_t lds = attention_mfma_lds_bytes<real>(li.N, hd, n_const);
+  if (li.T == 1) {                                   // value-only: k0, v0, q and the per-wave P tiles (the kernel lays DA behind q)
+    const size_t M16 = ((size_t)li.N + n_const + 15) / 16 * 16, N16 = ((size_t)li.N + 15) / 16 * 16;
+    lds = sizeof(real) * ((N16 + 2 * M16) * (hd + 2) + (N16 / 16) * 16 * (M16 + 2));
+  }
   const int n_cb = exact_tiles ? (li.N + n_const + 15) / 16 : 4;
   if (n_cb <= 2) return launch_attention_mfma_ncb<real, 2>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
   if (n_cb == 3) return launch_attention_mfma_ncb<real, 3>(st, q, k, v, out, width, H, hd, B, li, n_const, k_const, v_const, lds);
