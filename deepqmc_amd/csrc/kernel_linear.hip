@@ -212,7 +212,10 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         g_ok[h] = g < n_groups;
         sink.group(h, g_ok[h] ? g : 0);
       }
-      real rres[NR][4];                       // (residuals of the whole row block before its first store: HbmSink::fetch)
+      real bvh[NR];                           // (bias columns and the residuals of the whole row block before its first store: HbmSink::fetch)
+#pragma unroll
+      for (int n = 0; n < NR; ++n) { const int col = col_w0 + n * 16 + cl; bvh[n] = (bias != nullptr && col < ldw) ? bias[col] : (real)0; }
+      real rres[NR][4];
 #pragma unroll
       for (int n = 0; n < NR; ++n)
 #pragma unroll
@@ -238,7 +241,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         for (int h = 0; h < 2; ++h) {
           real v = quad_sum<real>(v_part[h]);
           S[h] = quad_sum<real>(s_part[h]);
-          if (bias != nullptr && col_ok) v += bias[col];
+          if (bias != nullptr && col_ok) v += bvh[n];
           act_derivs<real>(act, v, y[h], d1[h], d2[h]);
         }
 #pragma unroll
@@ -332,13 +335,45 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         }
     }
   } else if (GPW > 0) {
+    constexpr int NG = GPW > 0 ? GPW : 1;
+    // Everything the stores of this tile depend on is requested BEFORE the first store (a load cannot pass an earlier store
+    // to a possibly aliasing buffer): bias columns always; the residuals of the whole tile where they fit (HOIST: at most 32
+    // registers -- the 16- / 32- / 48-lane tiles of the small and mid-size systems), else per column block in batches of FB
+    // row blocks.
+    constexpr bool HOIST = NG * GB * NR * 4 * (int)(sizeof(real) / 4) <= 32;
+    long drow[NG], rrow[NG];
+    bool g_ok[NG];
+    int bw[NG];
 #pragma unroll
-    for (int gj = 0; gj < (GPW > 0 ? GPW : 1); ++gj) {
+    for (int gj = 0; gj < NG; ++gj) {
       const int g = (bx * 4 + wm) * GPW + gj;
-      const bool g_ok = g < n_groups;        // wave-uniform
-      const int b = (g_ok ? g : 0) / a.nrows;
-      sink.group(0, g_ok ? g : 0);
-      if (pre != nullptr && g_ok) {  // per-walker part of the pre-activation (all lanes: the layer is linear in them)
+      g_ok[gj] = g < n_groups;               // wave-uniform
+      bw[gj] = (g_ok[gj] ? g : 0) / a.nrows;
+      sink.rows(g_ok[gj] ? g : 0, drow[gj], rrow[gj]);
+    }
+    real bv[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      const int col = col_w0 + n * 16 + cl;
+      bv[n] = (bias != nullptr && col < ldw) ? bias[col] : (real)0;
+    }
+    real rall[HOIST ? NG : 1][HOIST ? NR : 1][HOIST ? GB : 1][4];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int gj = 0; gj < NG; ++gj)
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+          for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              const int col = col_w0 + n * 16 + cl;
+              rall[gj][n][tb][rg] = sink.fetch_at(rrow[gj] + tb * 16 + Mfma<real>::row_of(lane, rg), col, col < ldw && g_ok[gj]);
+            }
+    }
+#pragma unroll
+    for (int gj = 0; gj < NG; ++gj) {
+      if (pre != nullptr && g_ok[gj]) {  // per-walker part of the pre-activation (all lanes: the layer is linear in them)
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
           const int col = col_w0 + n * 16 + cl;
@@ -348,7 +383,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 #pragma unroll
               for (int rg = 0; rg < 4; ++rg) {
                 const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
-                acc[gj * GB + tb][n][rg] += pre[((long)b * a.TP + t) * a.ld_pre + col];
+                acc[gj * GB + tb][n][rg] += pre[((long)bw[gj] * a.TP + t) * a.ld_pre + col];
               }
           }
         }
@@ -358,7 +393,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         const int col = col_w0 + n * 16 + cl;
         const bool col_ok = col < ldw;
         real v = __shfl(acc[gj * GB][n][0], cl, 64);
-        if (bias != nullptr && col_ok) v += bias[col];
+        if (bias != nullptr && col_ok) v += bv[n];
         real s_part = 0;
 #pragma unroll
         for (int tb = 0; tb < GB; ++tb)
@@ -371,17 +406,19 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
         const real S = quad_sum<real>(s_part);
         real y, d1, d2;
         act_derivs<real>(act, v, y, d1, d2);
-        // residuals in batches of FB row blocks ahead of that batch's stores (HbmSink::fetch); float64: two row blocks, the
-        // tall tiles have no registers to spare
-        constexpr int FB = ((sizeof(real) == 8 && GB > 2) || GB == 4) ? 2 : GB;      // (GB = 4 in float32: 16 more registers would cost the 64-lane tiles a workgroup per CU)
+        // (not hoisted: float64 two row blocks at a time -- the tall tiles have no registers to spare; GB = 4 in float32 too:
+        // 16 more registers would cost the 64-lane tiles a workgroup per CU)
+        constexpr int FB = HOIST ? GB : (((sizeof(real) == 8 && GB > 2) || GB == 4) ? 2 : GB);
 #pragma unroll
         for (int tb0 = 0; tb0 < GB; tb0 += FB) {
           real rres[FB][4];
 #pragma unroll
           for (int tb = 0; tb < FB; ++tb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg)
-              rres[tb][rg] = (tb0 + tb < GB) ? sink.fetch(0, (tb0 + tb) * 16 + Mfma<real>::row_of(lane, rg), col, col_ok && g_ok) : (real)0;
+            for (int rg = 0; rg < 4; ++rg) {
+              if constexpr (HOIST) rres[tb][rg] = rall[gj][n][tb][rg];
+              else rres[tb][rg] = (tb0 + tb < GB) ? sink.fetch_at(rrow[gj] + (tb0 + tb) * 16 + Mfma<real>::row_of(lane, rg), col, col_ok && g_ok[gj]) : (real)0;
+            }
 #pragma unroll
           for (int tb = tb0; tb < tb0 + FB && tb < GB; ++tb)
 #pragma unroll
@@ -394,7 +431,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
               else if (t < a.T - 1) o = d1 * x;
               else if (t == a.T - 1) o = d1 * x + d2 * S;
               else o = 0;
-              sink.put(0, t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, rres[tb - tb0][rg], col_ok && g_ok);
+              sink.put_at(drow[gj] + t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, rres[tb - tb0][rg], col_ok && g_ok[gj]);
             }
         }
       }
@@ -598,6 +635,22 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there (DUAL: once per MLP) ----
   auto second_layer = [&](acc_t (&h)[MR][NR], const real* bias1, const real* W2, const real* bias2, const LinArgs<real>& out, bool first) {
     if (!first) __syncthreads();                            // the first MLP's second product has read the hidden tile
+    // W2 (<= 16 NR rows x 16 NR2 columns: one 4-vector per thread and chunk) is requested NOW, ahead of the hidden layer's
+    // epilogue, and waits in registers: fetched chunk by chunk between the barriers of the loop below, every chunk cost one
+    // L2 round trip that nothing overlapped
+    static_assert(BK2 * BN2 / 4 <= NT, "one W2 vector per thread and chunk");
+    const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
+    const int n_chunks2 = (K2 + BK2 - 1) / BK2;             // <= NR: the hidden tile is BN = 16 NR columns wide
+    real w2r[NR][4];                                        // (scalars, not Vec4 structs: the over-aligned float64 struct array stayed in scratch)
+#pragma unroll
+    for (int kc = 0; kc < NR; ++kc) {
+      const int k = tid / (BN2 / 4), n4 = tid % (BN2 / 4);
+      const int kk = kc * BK2 + k, col = 4 * n4;
+      Vec4<real> t{{0, 0, 0, 0}};
+      if (tid < BK2 * BN2 / 4 && kc < n_chunks2 && kk < K2 && col < a.ldw2) t = *reinterpret_cast<const Vec4<real>*>(W2 + (long)kk * a.ldw2 + col);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) w2r[kc][x] = t.v[x];
+    }
     {
       LdsSink<real> hsink{Hs, HS};
       lin_epilogue<real, MR, NR, GPW>(h, a, bias1, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink, bx);
@@ -607,24 +660,19 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < NR2; ++j) acc2[i][j] = acc_t{0, 0, 0, 0};
-    const int K2 = a.ldw;                                   // hidden width (a multiple of 4, zero padded in Hs up to BN)
-    const int n_chunks2 = (K2 + BK2 - 1) / BK2;
-    for (int kc = 0; kc < n_chunks2; ++kc) {
+#pragma unroll
+    for (int kc = 0; kc < NR; ++kc) {
+      if (kc < n_chunks2) {                                 // (block-uniform; a guard, not a break: the unrolled kc indexes w2r in registers)
       __syncthreads();                                      // hidden tile complete (kc = 0) / previous chunk of W2 consumed
-      for (int f = tid; f < BK2 * BN2 / 4; f += NT) {
-        const int k = f / (BN2 / 4), n4 = f % (BN2 / 4);
-        const int kk = kc * BK2 + k, col = 4 * n4;
-        Vec4<real> v;
-        if (kk < K2 && col < a.ldw2) v = *reinterpret_cast<const Vec4<real>*>(W2 + (long)kk * a.ldw2 + col);
-        else v = Vec4<real>{{0, 0, 0, 0}};
-        *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = v;
+      if (tid < BK2 * BN2 / 4) {
+        const int k = tid / (BN2 / 4), n4 = tid % (BN2 / 4);
+        *reinterpret_cast<Vec4<real>*>(&Bs2[k * BS2 + 4 * n4]) = Vec4<real>{{w2r[kc][0], w2r[kc][1], w2r[kc][2], w2r[kc][3]}};
       }
       __syncthreads();
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int kcol = kk * 4 + (lane >> 4);
-        if (kc * BK2 + kk * 4 >= BN) break;                  // (the hidden tile is BN columns wide)
-        real fa[MR], fb[NR2];
+        real fa[MR], fb[NR2];                                // (kc < NR: every k-step lies inside the BN = 16 NR columns of the hidden tile)
 #pragma unroll
         for (int i = 0; i < MR; ++i) fa[i] = Hs[(wm * (16 * MR) + i * 16 + (lane & 15)) * HS + kc * BK2 + kcol];
 #pragma unroll
@@ -633,6 +681,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR2; ++j) acc2[i][j] = Mfma<real>::run(fa[i], fb[j], acc2[i][j]);
+      }
       }
     }
     HbmSink<real> sink(out);
