@@ -255,6 +255,7 @@ struct Engine : dqmc_ctx {
   double refine_thresh = 200.0;
   double refine_target = 7e-6;
   int refine_probe = 32;
+  int refine_sample = 64;        // walkers of the calibration sample (option "refine_sample": c is the 90th percentile of a sample this large)
   // enqueue the float64 pass at a capacity before the flagged count is known on the host (option "refine_ahead"; off by
   // default: the twin's kernels, not their launches, are what costs -- at 1.5 x headroom the larger pass loses 0.2 ms of a
   // 6.3 ms step on LiH / PauliNet against the synchronous path, measured in one call)
@@ -827,6 +828,7 @@ struct Engine : dqmc_ctx {
     if (s == "twin_full_budget") { twin_full_budget = value; if (twin) twin->option("ws_budget_mb", (int)((value ? ws_budget : ws_budget / 2) >> 20)); return DQMC_OK; }
     if (s == "refine_ahead") { refine_ahead = value; return DQMC_OK; }
     if (s == "refine_defer") { if (!value) { const int rcj = refine_finish(); if (rcj) return rcj; } refine_defer = value; return DQMC_OK; }
+    if (s == "refine_sample") { if (value < 2) return fail(DQMC_E_ARG, "refine_sample must be >= 2"); refine_sample = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_probe") { if (value < 0) return fail(DQMC_E_ARG, "refine_probe must be >= 0"); refine_probe = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
@@ -2330,7 +2332,7 @@ struct Engine : dqmc_ctx {
       for (int32_t b : flagged) if (b >= 0 && b < B) done[b] = 1;
       // calibration sample: a strided subset of the WHOLE batch (flagged or not: every walker is an (error, score) pair; a
       // system whose walkers all sit above the current threshold must still be able to move it)
-      const int ns = B < 64 ? B : 64;
+      const int ns = B < refine_sample ? B : refine_sample;
       std::vector<int32_t> sample, list(flagged);
       std::vector<int> sample_pos;                 // position of each sample walker in `list`
       {

@@ -317,7 +317,9 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * replays (callers passing fresh buffers every time) returns to eager launches; 0: always eager;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
- * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set),
+ * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set), "refine_sample" (64): walkers of
+ * the calibration sample (the threshold of a batch at the edge of the whole-batch float64 mode moves with the draw: DESIGN.md,
+ * "calibration spread"),
  * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
  * Round 4: "linear_bf", "linear_bkx", "linear_f64_nr1" act on the calling context only (they were process-wide);
  * "linear_bf" 3 = 2 + value-only rows as 64 x 128 tiles on the bf16 pipe with host-split weight planes (measured slower);

@@ -166,6 +166,19 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     np.testing.assert_array_equal(e_auto.numpy()[~above], e_plain.numpy()[~above])       # sample walkers are not written back
     e_again, _ = auto.local_energy(r)                  # no probe this time: same threshold, same result
     np.testing.assert_array_equal(e_again.numpy(), e_auto.numpy())
+    # a smaller calibration sample (option refine_sample): the probe still runs and what a walker gets still depends on its
+    # score and the derived threshold alone
+    small = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    small.set_option('refine_sample', 3)
+    small.set_option('refine_thresh', 10 ** 6)
+    small.set_option('refine_target_e7', 1)
+    e_small, _ = small.local_energy(r)
+    thr_small = small.refine_info()['score_threshold']
+    assert small.refine_info()['error_per_score'] > 0 and thr_small < 10 ** 6
+    above_s = ratio > thr_small
+    assert small.last_refined() == int(above_s.sum())
+    np.testing.assert_array_equal(e_small.numpy()[above_s], e_d.numpy()[above_s].astype(np.float32))
+    np.testing.assert_array_equal(e_small.numpy()[~above_s], e_plain.numpy()[~above_s])
     loose = Engine(wf32.spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     loose.set_option('refine_probe', 0)
     loose.set_option('refine_thresh', 10 ** 9)
