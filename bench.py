@@ -204,9 +204,6 @@ def main():
     ap.add_argument('--opt', action='append', default=[], help='library option name=value (dqmc_set_option), repeatable')
     ap.add_argument('--repeats', type=int, default=0, help='timed blocks of --steps steps (0: as many as fill --min-seconds, at least 10)')
     ap.add_argument('--min-seconds', type=float, default=10.0, help='steady-state time the timed blocks must cover')
-    ap.add_argument('--defer-refine', action='store_true', help='library option refine_defer: the float64 pass of step k on a side stream '
-                    'beside the float32 pass of step k + 1, energy statistics of step k reduced one step later, last step drained inside '
-                    'the timed region.  Measured SLOWER on the MI355X (5.37 -> 5.71 ms per step: the two passes contend, DESIGN section 4): opt-in')
     ap.add_argument('--torch-reduce', action='store_true', help='reduce the energy statistics through torch.distributed on the host '
                     '(default: one ncclAllGather inside the library on the context\'s stream)')
     ap.add_argument('--emulated', action='store_true', help='TEST ONLY: CPU SIMT emulation of the kernels + gloo (exercises the '
@@ -375,12 +372,6 @@ def main():
         return state, stats
 
     refined = []           # walkers re-evaluated in float64 per step (host-side counter of the library, no sync)
-    # deferred refinement: software pipelining of the float64 pass (same work per step, bit-identical energies)
-    defer = (args.defer_refine and not args.emulated and S == 1 and not args.ecp and not args.overlap and args.dtype == 'f32'
-             and args.refine in (-1, 1))
-    if defer:
-        eng.set_option('refine_defer', 1)
-    held = {'e': None}
 
     def vmc_step(step, state):
         if S > 1:
@@ -392,19 +383,8 @@ def main():
             r = state['r']
         e, _ = loc_ene(step, params, r)
         refined.append(eng.last_refined())
-        if defer:          # e of THIS step is final after the next local-energy call: reduce the previous step's now
-            prev, held['e'] = held['e'], e
-            return state, (reduce_stats(eng, prev) if prev is not None else None)
         stats = reduce_stats(eng, e)
         return state, stats
-
-    def drain_deferred():
-        if held['e'] is None:
-            return None
-        eng.refine_finish()
-        out_ = reduce_stats(eng, held['e'])
-        held['e'] = None
-        return out_
 
     # ---- software-pipelined variant: E_loc(k) runs on a second stream while the sub-steps of step k+1 run ----
     pipe = {'e': None, 'stats': None}
@@ -454,8 +434,6 @@ def main():
         state, stats = step_fn(s, state)
     if args.overlap:
         stats = drain()
-    if defer:
-        stats = drain_deferred() or stats
 
     def timed_block(first_step):
         nonlocal state, stats
@@ -465,8 +443,6 @@ def main():
             state, stats = step_fn(first_step + s, state)
         if args.overlap:
             stats = drain()          # the last step's E_loc and reduction are inside the timed region
-        if defer:
-            stats = drain_deferred() or stats      # ... and so are the last step's float64 pass and its reduction
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -500,16 +476,6 @@ def main():
         off = [timed_block(10_000 + (k + 1) * args.steps) for k in range(max(3, min(len(blocks), 10)))]
         ms_refine_off = 1e3 * float(np.median(off)) / args.steps
         eng.set_option('refine', 1)
-    # ---- the same loop with the float64 pass inside each call (no software pipelining) ----
-    ms_sync_refine = None
-    if defer:
-        eng.set_option('refine_defer', 0)
-        defer = False
-        timed_block(20_000)
-        sy = [timed_block(20_000 + (k + 1) * args.steps) for k in range(max(3, min(len(blocks), 10)))]
-        ms_sync_refine = 1e3 * float(np.median(sy)) / args.steps
-        eng.set_option('refine_defer', 1)
-        defer = True
     eloc_only, roofline = None, None
     if not args.emulated:       # (the emulated test harness only exercises launch / shard / reduce)
         # ---- pure E_loc throughput (n_sub = 0), not the headline ----
@@ -521,8 +487,6 @@ def main():
         n_rep = max(5, args.steps)
         for k in range(n_rep):
             loc_ene(k, params, r)
-        if defer:
-            eng.refine_finish()
         sync()
         eloc_only = B * world / ((time.perf_counter() - t0) / n_rep)
 
@@ -532,8 +496,6 @@ def main():
         for s in range(3):
             state, stats_t = vmc_step(10_000_000 + s, state)
             stats = stats_t or stats
-        if defer:
-            stats = drain_deferred() or stats
         sync()
         rep = eng.timing_report()
         eng.timing(False)
@@ -554,7 +516,9 @@ def main():
             'bound': 'mfma', 'kernel': names[dom],
             'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
             'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
-            'traffic': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
+            # (counters cannot be collected inside the timed process: the figure is read from the committed rocprofv3 --pmc passes
+            # of the same workload, not measured by this run -- hence the key's name; `traffic` itself stays null)
+            'traffic': None, 'traffic_from_profile': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
             'avg_launch_us': 1e3 * lin['ms'] / max(lin['launches'], 1), 'launches_per_step': lin['launches'] / 3,
             'share_of_kernel_time': lin['ms'] / total_ms,
             'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in rep.items() if not k.startswith('f64.')},
@@ -598,14 +562,13 @@ def main():
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'timed_blocks': len(blocks), 'timed_seconds': float(np.sum(blocks)),
             'ms_per_step_min': 1e3 * float(np.min(blocks)) / args.steps, 'ms_per_step_max': 1e3 * float(np.max(blocks)) / args.steps,
-            'n_ranks_seen': n_ranks_seen, 'ms_per_step_refine_off': ms_refine_off, 'ms_per_step_sync_refine': ms_sync_refine,
+            'n_ranks_seen': n_ranks_seen, 'ms_per_step_refine_off': ms_refine_off,
             'dtype': args.dtype, 'data': 'synthetic walkers, random-init weights',
             'config': {'workload': f'{args.molecule} ({hamil.n_elec} e-), {args.ansatz} ansatz, '
                                    + (f'{S} electronic states x ' if S > 1 else '') + f'{B} walkers/GPU, '
                                    f'{args.n_sub} Metropolis sub-steps + local energy + RCCL energy stats'
                                    + (f' + {S}x{S} psi-ratio matrix + overlap penalty' if S > 1 else ''),
                        'walkers_per_gpu': B, 'n_sub': args.n_sub, 'states': S, 'parallelism': f'walker-dp{world}',
-                       'refine_deferred': bool(defer),
                        'reduction': ('in-library: dqmc_energy_stats_allgather (one ncclAllGather of 7 doubles per rank on the '
                                      'context stream)' if comm is not None else 'host: torch.distributed.all_gather of the 7-double record'),
                        'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers, self-calibrated threshold)', 0: 'off',

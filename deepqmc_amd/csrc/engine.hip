@@ -68,8 +68,10 @@ struct dqmc_ctx {
   virtual int energy_stats_dev(const void* e, const void* w, int B, double** rec_dev) = 0;
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
+  virtual int refine_scores(double* out, int n) { (void)out; (void)n; return DQMC_E_UNSUPPORTED; }
+  int64_t refine_counters[4] = {0, 0, 0, 0};   // local-energy / psi_grad calls; of them whole-batch float64; probe calls; walkers refined (sum)
   virtual dqmc_ctx* twin_ctx() { return nullptr; }
-  virtual int refine_finish() { return DQMC_OK; }       // join a deferred float64 pass (option "refine_defer")     // the float64 refinement twin of a float32 context, once it exists
+                                                         // (the float64 refinement twin of a float32 context, once it exists)
   int last_TP = 0;
   bool ph_skip = false;     // set on a float64 twin while it serves a plain-gradient call (no pseudo-Hamiltonian seeding)
   bool ecp_skip_nl = false; // ... and no non-local ECP quadrature
@@ -171,16 +173,8 @@ struct Engine : dqmc_ctx {
   // of the LINEAR op k, or -1; mlp_skip[k]: op k is such a second layer (executed with its parent)
   std::vector<int> mlp_child;
   std::vector<char> mlp_skip;
-  // mlp_dual[k] = LINEAR op m > k: ops k and m are both first layers of chained MLPs over the SAME input rows with the same
-  // shapes (the node MLPs h of the two edge types of a message-passing layer): one dual launch at k's position
-  // Measured on the MI355X (LiH / PauliNet, 4096 walkers): SLOWER than the two chained launches running side by side on two
-  // streams -- E_loc pass 1.59 -> 1.64 ms, VMC step 5.32 -> 5.44 ms: the pass is not bound by the 0.27 GB of input reads
-  // this saves, and one workgroup now carries both epilogue -> LDS -> second-product chains back to back.  Option
-  // "mlp_dual" (default 0).
-  std::vector<int> mlp_dual;
-  int mlp_dual_on = 0;
   int mlp_fuse = 1;
-  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_nr1 = 0, linear_f64_split = 1, linear_bkx_big = 0, linear_bkx_val = 0;   // LinArgs::cfg_*
+  int linear_bf = dqmc::LINEAR_BF_DEFAULT, linear_bkx = dqmc::LINEAR_BKX_DEFAULT, linear_f64_split = 1;   // LinArgs::cfg_*
   std::vector<std::vector<int>> pair_rs;   // per compact buffer: [2*row] = recv, [2*row+1] = send
   // descriptor-driven fused kernel (kernel_fused2.hip): the default when its plan exists
   int fused2_WT = 0, fused2_shift = 0, fused_sched_wt = 4, fused_substep = 1;
@@ -190,7 +184,6 @@ struct Engine : dqmc_ctx {
   std::vector<dqmc::FusedBuf> fbufs2_h;
   bool fused2_ma1 = false;       // every unit of the plan has ma == 1
   bool fbufs2_uploaded = false;
-  int fused_always_upload = 0;   // experiment: re-upload the table before every launch (what round 1 did)
   // Laplacian pass on two HIP streams: the two-particle (edge) stream does not depend on the node stream (reference
   // gnn/electron_gnn.py:160-276: edges are updated from edges), its launches are HBM bound while the node layers are
   // MFMA bound, so they run on a companion stream and the node stream waits (event) only where a convolution or an
@@ -207,14 +200,11 @@ struct Engine : dqmc_ctx {
   hipStream_t st2 = nullptr;
   std::vector<hipEvent_t> buf_ev;      // per buffer: last write on the companion stream (nullptr: none pending)
   hipEvent_t ev_fork = nullptr;
-  int fused_stagger_div = 256;
-  int fused_stagger = 0;         // option "fused_stagger": start delay between the co-resident workgroups of a CU (x 8128 cycles)
+  int fused_stagger_div = 256;   // workgroups per dispatch wave (= CUs): workgroup b is the (b / 256)-th placed on its CU
   int fused_prio = 1;            // option "fused_prio": issue priority rotates among the tiles that share a CU (1: per level, 2: per unit, 0: off)
   int fused_lean = 1;            // option "fused_lean": lean unit body for small layers
   int fused_bf = 1;              // option "fused_bf": float32 layers of the value path on the bf16 matrix pipe (three-piece split, six products; float engines only)
   std::vector<char> op_bf;       // per scheduled op: packed in the bf16 plane layout
-  int fused_chain = 0;           // option "fused_chain" (off: measured 150 -> 159 us, the chained units lose the parallelism across waves): second layers of row-wise MLPs follow their first layer in the same wave
-  std::vector<int> chain_parent; // per op: the op whose output rows it consumes inside the same level and wave, or -1
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
   dqmc::FDesc* d_descs = nullptr;
   int32_t* d_wave_begin = nullptr;
@@ -238,6 +228,9 @@ struct Engine : dqmc_ctx {
   int ecp_mixed_on = 1;
   bool ecp_defer = false;       // set while lap_refined_core runs for a call whose quadrature follows in ecp_mixed
   double ecp_w_heavy = 1e-2, ecp_w_skip = 1e-10;
+  // float32 error of log|psi(r)| up to which a walker counts as ordinary ("ecp_dlog_floor_e6", in 1e-6; 0: weights alone
+  // decide, the round-4 rule): beyond it the walker's float64 bound tightens in proportion (kernels.h: EcpMixArgs::l32)
+  double ecp_dlog_floor = 1e-4;
   char* d_ecpm = nullptr;
   size_t ecpm_bytes = 0;
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch
@@ -246,8 +239,8 @@ struct Engine : dqmc_ctx {
   // re-evaluated by a float64 twin of this context and their results replace the float32 ones
   int refine = 1;
   // Flag rule: score > refine_thresh (kernels.h: FinalArgs).  The threshold is SELF-CALIBRATED: every refine_probe-th
-  // local-energy call (and the first) a strided sample of <= 64 walkers is evaluated by the float64 twin as well, the
-  // measured float32 error per unit of score -- its 90th percentile c over the sample -- sets
+  // local-energy call (and the first) a strided sample of <= refine_sample (256) walkers is evaluated by the float64 twin
+  // as well, the measured float32 error per unit of score -- its 90th percentile c over the sample -- sets
   // refine_thresh = refine_target / c, i.e. the score at which the expected error reaches refine_target (7e-6
   // relative, 0.7 of the tolerance of the north star).  Deep / ill-conditioned systems (Psiformer, a random-init
   // TransPsiformer) measure a large c, flag most walkers and fall into the direct float64 pass by themselves; a
@@ -255,12 +248,17 @@ struct Engine : dqmc_ctx {
   double refine_thresh = 200.0;
   double refine_target = 7e-6;
   int refine_probe = 32;
-  int refine_sample = 64;        // walkers of the calibration sample (option "refine_sample": c is the 90th percentile of a sample this large)
-  // enqueue the float64 pass at a capacity before the flagged count is known on the host (option "refine_ahead"; off by
-  // default: the twin's kernels, not their launches, are what costs -- at 1.5 x headroom the larger pass loses 0.2 ms of a
-  // 6.3 ms step on LiH / PauliNet against the synchronous path, measured in one call)
+  int refine_sample = 256;       // walkers of the calibration sample (option "refine_sample": c is the 90th percentile of a sample this
+                                 // large; 64 until round 4 -- six seeds on benzene then drew thresholds that flagged 36-50 % of the batch)
+  // Whole-batch float64 ("direct") mode, with hysteresis: a context ENTERS it when more than refine_direct_enter of a batch
+  // lies above the threshold (the float32 pass would mostly be wasted: f32(B) + f64(p B) costs more than f64(B) from
+  // p ~ 0.6 on, the float64 pass being ~2.5-3 x the float32 one per walker), runs 15 calls there, then looks again with a
+  // float32 pass and LEAVES only if the flagged fraction has fallen below refine_direct_exit.  One draw near a single
+  // 50 % line used to flip the mode -- and the cost of a benzene step between 166 and 207 ms -- from run to run.
+  double refine_direct_enter = 0.60, refine_direct_exit = 0.45;
+  bool was_direct = false;       // the last mode decision was "direct"
+
   int twin_full_budget = 1;      // the twin's activation workspace may be as large as this context's (option "twin_full_budget")
-  int refine_ahead = 0;
   // option "pass_graph" (1): a forward-Laplacian pass that fits one workspace chunk is captured ONCE per (buffers, batch
   // size) into a hipGraph -- its ~40 launches, and the event records / waits that spread them over four streams -- and
   // replayed with one hipGraphLaunch per call.  The pass is launch-bound at the batch sizes it is used for (LiH, 4096
@@ -297,8 +295,6 @@ struct Engine : dqmc_ctx {
     for (auto& g : pgraphs) if (g.exec) (void)hipGraphExecDestroy((hipGraphExec_t)g.exec);
     pgraphs.clear();
   }
-  int ahead_cap = 0, ahead_pos = 0;
-  int ahead_hist[4] = {0, 0, 0, 0};
   int calls_since_probe = -1;    // -1: never probed
   double probe_c = 0.0;          // last measured error per unit of score (0: none yet)
   bool flag_on = false;
@@ -322,29 +318,7 @@ struct Engine : dqmc_ctx {
   size_t flag_cap = 0;
   char* d_ref = nullptr;
   size_t ref_bytes = 0;
-  // Deferred refinement (option "refine_defer"): the float64 pass over the flagged walkers of call k is enqueued on a
-  // stream of its own at the START of call k + 1 (i.e. behind whatever the caller put on the context's stream in between:
-  // the Metropolis sub-steps of the next VMC step, which leave no LDS for other kernels) and runs beside the float32 pass
-  // of call k + 1; the context's stream joins it before call k + 1 returns.  The flag list and the gather / result scratch
-  // of a pending pass belong to it, the following call works on the alternates.
-  int refine_defer = 0;
   size_t score_cap = 0;
-  int32_t* d_flag_alt = nullptr;
-  size_t flag_cap_alt = 0;
-  char* d_ref_alt = nullptr;
-  size_t ref_bytes_alt = 0;
-  struct PendingRefine {
-    bool on = false, launched = false, use_count = false;
-    long call = 0;
-    int n = 0, n_pad = 0, B = 0;
-    const real* r = nullptr; const real* R = nullptr;
-    real* e_loc = nullptr; real* stats = nullptr; real* grad = nullptr; real* logpsi = nullptr; int32_t* sign = nullptr;
-    int32_t* flag = nullptr; size_t flag_cap = 0;
-    char* ref = nullptr; size_t ref_bytes = 0;
-  } pend;
-  long lap_calls = 0;
-  hipStream_t st_tw = nullptr;
-  hipEvent_t ev_tw_go = nullptr, ev_tw_done = nullptr;
   const double* ref_e64 = nullptr;   // float64 local energies of the last refine_listed pass (device)
   std::vector<double> probe_sample_e;          // ... of the calibration sample of a probe call (host)
   std::function<void()> probe_rethreshold;     // set by the probe call: derives refine_thresh from probe_sample_e
@@ -365,12 +339,6 @@ struct Engine : dqmc_ctx {
     if (d_flag) (void)hipFree(d_flag);
     if (d_score) (void)hipFree(d_score);
     if (d_ref) (void)hipFree(d_ref);
-    if (pend.on) { if (pend.flag) (void)hipFree(pend.flag); if (pend.ref) (void)hipFree(pend.ref); }
-    if (d_flag_alt) (void)hipFree(d_flag_alt);
-    if (d_ref_alt) (void)hipFree(d_ref_alt);
-    if (st_tw) (void)hipStreamDestroy(st_tw);
-    if (ev_tw_go) (void)hipEventDestroy(ev_tw_go);
-    if (ev_tw_done) (void)hipEventDestroy(ev_tw_done);
     if (d_descs) (void)hipFree(d_descs);
     if (d_wave_begin) (void)hipFree(d_wave_begin);
     if (d_fbufs2) (void)hipFree(d_fbufs2);
@@ -382,7 +350,6 @@ struct Engine : dqmc_ctx {
     if (d_ph_nuc) (void)hipFree(d_ph_nuc);
     if (d_ecp) (void)hipFree(d_ecp);
     if (d_ecpm) (void)hipFree(d_ecpm);
-    if (d_wbf) (void)hipFree(d_wbf);
     for (auto e : ev_pool) (void)hipEventDestroy(e);
     if (d_w) (void)hipFree(d_w);
     if (d_it) (void)hipFree(d_it);
@@ -507,7 +474,6 @@ struct Engine : dqmc_ctx {
     const int no = (int)ops.size(), nb = (int)bufs.size();
     mlp_child.assign(no, -1);
     mlp_skip.assign(no, 0);
-    mlp_dual.assign(no, -1);
     if (!mlp_fuse) return;
     std::vector<int> rd, wr;
     std::vector<std::vector<int>> writers(nb), readers(nb);
@@ -536,42 +502,6 @@ struct Engine : dqmc_ctx {
       if (!ok) continue;
       mlp_child[p] = c;
       mlp_skip[c] = 1;
-    }
-    // pairs of chained MLPs on the same input
-    mlp_dual.assign(no, -1);
-    if (!mlp_dual_on) return;
-    std::vector<char> taken(no, 0);
-    for (int k = 0; k < no; ++k) {
-      if (mlp_child[k] < 0 || taken[k]) continue;
-      const int32_t* ki = ops[k].i;
-      const int32_t* kc = ops[mlp_child[k]].i;
-      if (ki[0] != 1) continue;                                                              // one input piece
-      for (int m = k + 1; m < no; ++m) {
-        if (mlp_child[m] < 0 || taken[m]) continue;
-        const int32_t* mi = ops[m].i;
-        const int32_t* mc = ops[mlp_child[m]].i;
-        bool same = mi[0] == 1 && (mi[23] >= 0) == (ki[23] >= 0) && (mc[23] >= 0) == (kc[23] >= 0);
-        for (int q = 1; q <= 4 && same; ++q) same = mi[q] == ki[q];                        // input buffer, first row, width, broadcast flag
-        same = same && mi[18] == ki[18] && mi[20] == ki[20] && mi[21] == ki[21] && mi[24] == ki[24];                  // rows, hidden width, activation
-        same = same && mc[3] == kc[3] && mc[18] == kc[18] && mc[19] == kc[19] && mc[20] == kc[20] && mc[21] == kc[21] && mc[24] == kc[24] && mc[27] == kc[27];
-        same = same && bufs[mc[17]].width == bufs[kc[17]].width && bufs[mc[17]].rows == bufs[kc[17]].rows && mc[17] != kc[17];
-        same = same && (mc[25] >= 0) == (kc[25] >= 0);
-        if (same && mc[25] >= 0) same = mc[26] == kc[26] && bufs[mc[25]].width == bufs[kc[25]].width && bufs[mc[25]].rows == bufs[kc[25]].rows;
-        if (!same) continue;
-        // legal to run m's MLP at k's position: nothing in (k, child(m)] other than the two MLPs themselves touches m's
-        // hidden / output buffers or writes the shared input, and m's residual input is complete before k
-        bool ok = true;
-        if (mc[25] >= 0) for (int w : writers[mc[25]]) ok = ok && w < k;
-        for (int x = k + 1; x <= mlp_child[m] && ok; ++x) {
-          if (x == m || x == mlp_child[m] || x == mlp_child[k]) continue;
-          op_io(ops[x], rd, wr);
-          for (int b : rd) ok = ok && b != mc[17] && b != mi[17];
-          for (int b : wr) ok = ok && b != mc[17] && b != mi[17] && b != ki[1];
-        }
-        if (!ok) continue;
-        mlp_dual[k] = m; taken[k] = taken[m] = 1;
-        break;
-      }
     }
   }
 
@@ -720,7 +650,6 @@ struct Engine : dqmc_ctx {
 
   int set_weights(const double* w, size_t n) override {
     if (n != n_weights) return fail(DQMC_E_ARG, "weight buffer length differs from the one given at creation");
-    { const int rcj = refine_finish(); if (rcj) return rcj; }      // (a deferred float64 pass belongs to the old weights)
     ++graph_epoch;
     wtmp.resize(n);
     for (size_t k = 0; k < n; ++k) wtmp[k] = (real)w[k];
@@ -730,55 +659,9 @@ struct Engine : dqmc_ctx {
     }
     HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    { const int rcb = upload_bf_planes(); if (rcb) return rcb; }
     if (fused_n_ops > 0) return pack_fused_weights();
     return DQMC_OK;
   }
-  // Pre-split weight planes for k_linear_bf (float32 contexts): every LINEAR op's block W[K][ldw] as three planes of bf16
-  // pairs along k (round-to-nearest-even pieces, exactly what the device split produces), at word offset (W offset) / 2.
-  uint32_t* d_wbf = nullptr;
-  long wbf_plane = 0;
-  static uint32_t bf16_rne(float x) {
-    uint32_t u; std::memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-  }
-  static float bf16_as_float(uint32_t h) { const uint32_t u = h << 16; float f; std::memcpy(&f, &u, 4); return f; }
-  int upload_bf_planes() {
-    if constexpr (sizeof(real) == 4) {
-      const long plane = (long)(n_weights / 2 + 4);
-      std::vector<uint32_t> pl((size_t)3 * plane, 0u);
-      for (const auto& o : ops) {
-        if (o.kind != DQMC_OP_LINEAR) continue;
-        const int32_t* i = o.i;
-        long ktot = 0;
-        for (int p = 0; p < i[0]; ++p) ktot += pad4(i[3 + 4 * p]);
-        const long ldw = pad4(i[21]), off = i[22];
-        if (off % 2 || (size_t)(off + ktot * ldw) > n_weights) continue;
-        for (long kp = 0; kp < ktot / 2; ++kp)
-          for (long c = 0; c < ldw; ++c) {
-            const float x0 = (float)wtmp[off + (2 * kp) * ldw + c], x1 = (float)wtmp[off + (2 * kp + 1) * ldw + c];
-            const uint32_t h0 = bf16_rne(x0), h1 = bf16_rne(x1);
-            const float r0 = x0 - bf16_as_float(h0), r1 = x1 - bf16_as_float(h1);
-            const uint32_t m0 = bf16_rne(r0), m1 = bf16_rne(r1);
-            const float s0 = r0 - bf16_as_float(m0), s1 = r1 - bf16_as_float(m1);
-            const long at = off / 2 + kp * ldw + c;
-            pl[at] = h0 | (h1 << 16);
-            pl[plane + at] = m0 | (m1 << 16);
-            pl[2 * plane + at] = bf16_rne(s0) | (bf16_rne(s1) << 16);
-          }
-      }
-      if (plane != wbf_plane) {
-        if (d_wbf) { HIP_TRY(hipFree(d_wbf)); d_wbf = nullptr; }
-        HIP_TRY(hipMalloc((void**)&d_wbf, sizeof(uint32_t) * pl.size()));
-        wbf_plane = plane;
-      }
-      HIP_TRY(hipMemcpyAsync(d_wbf, pl.data(), sizeof(uint32_t) * pl.size(), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));
-    }
-    return DQMC_OK;
-  }
-
   // ---- fused value-only evaluation (kernel_fused2.hip) ----------------------------------
   // Ops [0, fused_n_ops) (everything up to and including ORBITALS) run in one kernel on a tile
   // of WT walkers with LDS-resident buffers; buffers read by later ops stay in the workspace.
@@ -788,7 +671,6 @@ struct Engine : dqmc_ctx {
       twin_opts.emplace_back(s.substr(5), value);
       return twin ? twin->option(s.c_str() + 5, value) : DQMC_OK;
     }
-    { const int rcj = refine_finish(); if (rcj) return rcj; }      // (a deferred float64 pass runs with the settings it was deferred under)
     ++graph_epoch;                             // (any switch may change what a captured pass would launch)
     if (s == "pass_graph") { pass_graph = value; if (!value) drop_graphs(); if (twin) twin->option("pass_graph", value); twin_opts.emplace_back(s, value); return DQMC_OK; }
     if (s == "fused") { fused_enabled = value; return DQMC_OK; }
@@ -800,22 +682,14 @@ struct Engine : dqmc_ctx {
     if (s == "ws_budget_mb") { if (value < 1) return fail(DQMC_E_ARG, "ws_budget_mb must be positive"); ws_budget = (size_t)value << 20; return DQMC_OK; }
     if (s == "slogdet_mfma") { slogdet_mfma = value; return DQMC_OK; }
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
-    if (s == "linear_f64_nr1") { linear_f64_nr1 = value; return DQMC_OK; }
     if (s == "linear_f64_split") { linear_f64_split = value; return DQMC_OK; }
-    if (s == "linear_bkx_big") { linear_bkx_big = value; return DQMC_OK; }
-    if (s == "linear_bkx_val") { linear_bkx_val = value; return DQMC_OK; }
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
-    if (s == "mlp_dual") { mlp_dual_on = value; analyse_chains(); return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "multi_stream") { multi_stream = value; return DQMC_OK; }
-    if (s == "fused_chain") { fused_chain = value; return build_fused_plan(); }
-    if (s == "fused_always_upload") { fused_always_upload = value; return DQMC_OK; }
     if (s == "fused_prio") { fused_prio = value; return DQMC_OK; }
-    if (s == "fused_stagger") { fused_stagger = value; return DQMC_OK; }
-    if (s == "fused_stagger_div") { fused_stagger_div = value > 0 ? value : 256; return DQMC_OK; }
     if (s == "fused_lean") { fused_lean = value; return build_fused_plan(); }
     if (s == "fused_bf") { fused_bf = value; return build_fused_plan(); }
     if (s == "linear_bf") { linear_bf = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
@@ -826,11 +700,11 @@ struct Engine : dqmc_ctx {
     }
     if (s == "refine") { refine = value; return DQMC_OK; }
     if (s == "twin_full_budget") { twin_full_budget = value; if (twin) twin->option("ws_budget_mb", (int)((value ? ws_budget : ws_budget / 2) >> 20)); return DQMC_OK; }
-    if (s == "refine_ahead") { refine_ahead = value; return DQMC_OK; }
-    if (s == "refine_defer") { if (!value) { const int rcj = refine_finish(); if (rcj) return rcj; } refine_defer = value; return DQMC_OK; }
     if (s == "refine_sample") { if (value < 2) return fail(DQMC_E_ARG, "refine_sample must be >= 2"); refine_sample = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_probe") { if (value < 0) return fail(DQMC_E_ARG, "refine_probe must be >= 0"); refine_probe = value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
+    if (s == "refine_direct_pct") { if (value < 1 || value > 100) return fail(DQMC_E_ARG, "refine_direct_pct must be 1..100"); refine_direct_enter = 0.01 * value; if (refine_direct_exit > refine_direct_enter) refine_direct_exit = refine_direct_enter; return DQMC_OK; }
+    if (s == "refine_direct_exit_pct") { if (value < 0 || value > 100) return fail(DQMC_E_ARG, "refine_direct_exit_pct must be 0..100"); refine_direct_exit = 0.01 * value; if (refine_direct_exit > refine_direct_enter) refine_direct_enter = refine_direct_exit; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }
     if (s == "fused_sched_kb") { fused_sched_budget = (size_t)value * 1024; return build_fused_plan(); }
     if (s == "fused_print") {   // plan summary on stderr (tuning aid)
@@ -849,6 +723,7 @@ struct Engine : dqmc_ctx {
     }
     if (s == "ecp_mixed") { ecp_mixed_on = value; return DQMC_OK; }
     if (s == "ecp_heavy_e6") { if (value < 0) return fail(DQMC_E_ARG, "ecp_heavy_e6 must be >= 0"); ecp_w_heavy = 1e-6 * value; return DQMC_OK; }
+    if (s == "ecp_dlog_floor_e6") { if (value < 0) return fail(DQMC_E_ARG, "ecp_dlog_floor_e6 must be >= 0"); ecp_dlog_floor = 1e-6 * value; return DQMC_OK; }
     if (s == "ecp_skip_e12") { if (value < 0) return fail(DQMC_E_ARG, "ecp_skip_e12 must be >= 0"); ecp_w_skip = 1e-12 * value; return DQMC_OK; }
     if (s == "ecp_max_cfg") { if (value < 1) return fail(DQMC_E_ARG, "ecp_max_cfg must be positive"); ecp_max_cfg = (size_t)value; return DQMC_OK; }
     if (s == "fused_sched") { fused_sched_mode = value; return build_fused_plan(); }
@@ -999,44 +874,9 @@ struct Engine : dqmc_ctx {
       }
       lvl = alap;
     }
-    // Row-wise two-layer MLPs (edge MLPs w / u, node MLP h): the second layer of a row block needs only the hidden rows
-    // of the SAME row block, so a wave that computed them can go on without a workgroup barrier.  Such a child op is
-    // pulled into its parent's level (its units follow the parent's in the same wave behind a wave-local LDS fence,
-    // build_fused2_plan); levels that become empty disappear.
-    chain_parent.assign(ops.size(), -1);
-    if (fused_chain) {
-      std::vector<std::vector<int>> writers(nb), readers(nb);
-      for (int k = 0; k < (int)ops.size(); ++k) { op_io(ops[k], rd, wr); for (int b : wr) writers[b].push_back(k); for (int b : rd) readers[b].push_back(k); }
-      std::vector<char> has_child(ops.size(), 0);
-      for (int k = 0; k < no; ++k) {
-        const int32_t* c = ops[k].i;
-        if (ops[k].kind != DQMC_OP_LINEAR || c[0] != 1 || c[4]) continue;          // one non-broadcast piece
-        const int sb = c[1];
-        if (writers[sb].size() != 1 || readers[sb].size() != 1) continue;            // a private hidden buffer
-        const int p = writers[sb][0];
-        if (p >= no || ops[p].kind != DQMC_OP_LINEAR || chain_parent[p] >= 0 || has_child[p]) continue;
-        const int32_t* pi = ops[p].i;
-        if (pi[18] != c[2] || pi[20] != c[20] || pi[19] != 0 || pad4(c[3]) > pad4(pi[21])) continue;   // same rows, whole width
-        if (lvl[k] != lvl[p] + 1) continue;
-        bool ok = true;
-        if (c[25] >= 0) for (int w : writers[c[25]]) ok = ok && w < no && lvl[w] < lvl[p];   // residual input complete before the level
-        for (int b2 : {c[17]}) for (int r2 : readers[b2]) ok = ok && (r2 >= no || lvl[r2] > lvl[k]);
-        if (!ok) continue;
-        lvl[k] = lvl[p];
-        chain_parent[k] = p;
-        has_child[p] = 1;
-      }
-      // drop empty levels
-      int L = 0;
-      for (int k = 0; k < no; ++k) L = lvl[k] + 1 > L ? lvl[k] + 1 : L;
-      std::vector<int> used(L, 0), remap(L, 0);
-      for (int k = 0; k < no; ++k) used[lvl[k]] = 1;
-      for (int l = 0, nl = 0; l < L; ++l) { remap[l] = nl; nl += used[l]; }
-      for (int k = 0; k < no; ++k) lvl[k] = remap[lvl[k]];
-    }
     f_order.resize(no);
     for (int k = 0; k < no; ++k) f_order[k] = k;
-    // a chained child sorts right behind ... its own level; within a level the program order is kept (parents first)
+    // (within a level the program order is kept)
     std::stable_sort(f_order.begin(), f_order.end(), [&](int x, int y) { return lvl[x] < lvl[y]; });
     f_level.assign(no, 0);
     for (int j = 0; j < no; ++j) f_level[j] = lvl[f_order[j]];
@@ -1172,36 +1012,14 @@ struct Engine : dqmc_ctx {
     std::vector<Unit> level_units;
     std::vector<int> level_generic;
     auto flush_level = [&]() {
-      // jobs: a unit, or -- for a chained MLP -- all units of one row block of the parent layer, a wave-local fence,
-      // and the child layer's units of that row block; jobs go longest first onto the least loaded wave
-      struct Job { std::vector<dqmc::FDesc> d; long cost; };
-      std::vector<Job> jobs;
-      std::vector<char> taken(level_units.size(), 0);
-      for (size_t a = 0; a < level_units.size(); ++a) {
-        if (taken[a]) continue;
-        const int op_a = level_units[a].opidx;
-        if (chain_parent[op_a] >= 0) continue;                    // placed with its parent's job
-        int child = -1;
-        for (size_t c = 0; c < level_units.size(); ++c) if (chain_parent[level_units[c].opidx] == op_a) child = level_units[c].opidx;
-        Job jb{{}, 0};
-        if (child < 0) {
-          jb.d.push_back(level_units[a].d); jb.cost = level_units[a].cost; taken[a] = 1;
-        } else {
-          const int row0 = level_units[a].d.row0;
-          for (size_t c = 0; c < level_units.size(); ++c)
-            if (!taken[c] && level_units[c].opidx == op_a && level_units[c].d.row0 == row0) { jb.d.push_back(level_units[c].d); jb.cost += level_units[c].cost; taken[c] = 1; }
-          dqmc::FDesc f{}; f.kind = 4; jb.d.push_back(f);
-          for (size_t c = 0; c < level_units.size(); ++c)
-            if (!taken[c] && level_units[c].opidx == child && level_units[c].d.row0 == row0) { jb.d.push_back(level_units[c].d); jb.cost += level_units[c].cost; taken[c] = 1; }
-        }
-        jobs.push_back(jb);
-      }
-      std::stable_sort(jobs.begin(), jobs.end(), [](const Job& x, const Job& y) { return x.cost > y.cost; });
+      // units go longest first onto the least loaded wave
+      std::vector<Unit> jobs(level_units);
+      std::stable_sort(jobs.begin(), jobs.end(), [](const Unit& x, const Unit& y) { return x.cost > y.cost; });
       long load[4] = {0, 0, 0, 0};
-      for (const Job& jb : jobs) {
+      for (const Unit& jb : jobs) {
         int best = 0;
         for (int w = 1; w < n_waves; ++w) if (load[w] < load[best]) best = w;
-        lists[best].insert(lists[best].end(), jb.d.begin(), jb.d.end());
+        lists[best].push_back(jb.d);
         load[best] += jb.cost;
       }
       for (int j : level_generic)
@@ -1219,12 +1037,6 @@ struct Engine : dqmc_ctx {
         const int NRB = (Rtot + 15) / 16, NCB = (ldw + 15) / 16, n_cg = (NCB + 1) / 2;
         int rpu = NRB * n_cg / n_waves;
         rpu = rpu < 1 ? 1 : (rpu > 4 ? 4 : rpu);
-        {   // chained layers are cut into single row blocks (parent and child units must cover the same rows)
-          const int me = f_order[j];
-          bool chained = chain_parent[me] >= 0;
-          for (int k2 = 0; k2 < fused_n_ops && !chained; ++k2) chained = chain_parent[k2] == me;
-          if (chained) rpu = 1;
-        }
         dqmc::FDesc t{};
         t.kind = 1; t.op = j; t.n_pieces = i[0]; t.rtot = Rtot; t.ldw = ldw;
         long kq = 0;
@@ -1336,7 +1148,7 @@ struct Engine : dqmc_ctx {
   }
 
   int run_fused2(const real* r, const real* R, int B, dqmc::LaneInfo li, const dqmc::FusedMc* mc = nullptr) {
-    bool changed = !fbufs2_uploaded || fused_always_upload;       // the buffer table goes to the device only when an offset moved (not once per sub-step)
+    bool changed = !fbufs2_uploaded;       // the buffer table goes to the device only when an offset moved (not once per sub-step)
     for (size_t b = 0; b < bufs.size(); ++b) {
       if (fbufs2_h[b].goff != (long)buf_off[b]) changed = true;
       fbufs2_h[b].goff = (long)buf_off[b];
@@ -1356,7 +1168,7 @@ struct Engine : dqmc_ctx {
     a.it_off = (int)(fused2_lds - (size_t)((4 * n_itable + 15) / 16 * 16));
     a.n_it = (int)n_itable;
     a.ma1 = fused2_ma1 ? 1 : 0;
-    a.stagger = fused_stagger; a.stagger_div = fused_stagger_div; a.prio_mode = fused_prio;
+    a.stagger_div = fused_stagger_div; a.prio_mode = fused_prio;
     if (mc) a.mc = *mc;
     double flops = 0;
     for (int k = 0; k < fused_n_ops; ++k)
@@ -1703,7 +1515,7 @@ struct Engine : dqmc_ctx {
           break;
         case DQMC_OP_LINEAR: {
           dqmc::LinArgs<real> a{};
-          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_nr1 = linear_f64_nr1; a.cfg_f64_split = linear_f64_split; a.cfg_bkx_big = linear_bkx_big; a.cfg_bkx_val = linear_bkx_val;
+          a.cfg_bf = linear_bf; a.cfg_bkx = linear_bkx; a.cfg_f64_split = linear_f64_split;
           a.n_pieces = i[0];
           int ktot = 0, w_row = 0, n_bc = 0;
           for (int p = 0; p < i[0]; ++p) {
@@ -1721,7 +1533,6 @@ struct Engine : dqmc_ctx {
           }
           a.W = d_w + i[22];
           a.ldw = pad4(i[21]);
-          if (sizeof(real) == 4 && d_wbf && i[22] % 2 == 0) { a.Wbf = d_wbf + i[22] / 2; a.wbf_plane = wbf_plane; }
           a.bias = i[23] >= 0 ? d_w + i[23] : nullptr;
           a.dst = bptr(i[17]);
           a.ld_dst = bufs[i[17]].width; a.rpw_dst = bufs[i[17]].rows; a.r0_dst = i[18]; a.col0_dst = i[19];
@@ -1742,27 +1553,6 @@ struct Engine : dqmc_ctx {
             a.res = c[25] >= 0 ? bptr(c[25]) : nullptr;
             if (c[25] >= 0) { a.ld_res = bufs[c[25]].width; a.rpw_res = bufs[c[25]].rows; a.r0_res = c[26]; }
             a.res_scale = c[27] ? (real)0.70710678118654752440 : (real)1;
-            const int mate = mlp_dual.size() == ops.size() ? mlp_dual[opi] : -1;
-            if (mate >= 0 && dqmc::linear_chain_dual_supported(a.TP, a.ldw, a.ldw2) && compact[ops[mate].i[17]] == compact[i[17]] &&
-                compact[ops[mlp_child[mate]].i[17]] == compact[i[17]]) {
-              // the other MLP on the same rows rides along: the input tile is fetched and staged once for both
-              const dqmc_op& mo = ops[mate];
-              const dqmc_op& mch = ops[mlp_child[mate]];
-              { const int rcb = before(mo, sid); if (rcb) return rcb; }
-              { const int rcb = before(mch, sid); if (rcb) return rcb; }
-              a.W_b = d_w + mo.i[22]; a.bias_b = mo.i[23] >= 0 ? d_w + mo.i[23] : nullptr;
-              a.W2_b = d_w + mch.i[22]; a.bias2_b = mch.i[23] >= 0 ? d_w + mch.i[23] : nullptr;
-              a.dst_b = bptr(mch.i[17]); a.res_b = mch.i[25] >= 0 ? bptr(mch.i[25]) : nullptr;
-              t_begin("linear", 4.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
-              dqmc::launch_linear_chain_dual<real>(so, a);
-              t_end();
-              ran_with_parent[mlp_child[opi]] = 1; ran_with_parent[mate] = 1; ran_with_parent[mlp_child[mate]] = 1;
-              { const int rca = after(op, sid); if (rca) return rca; }
-              { const int rca = after(ch, sid); if (rca) return rca; }
-              { const int rca = after(mo, sid); if (rca) return rca; }
-              { const int rca = after(mch, sid); if (rca) return rca; }
-              continue;
-            }
             t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
             dqmc::launch_linear_chain<real>(so, a);
             t_end();
@@ -1977,13 +1767,10 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
   // float64 results of the n walkers listed in d_flag[1..n] replace the float32 ones.  d_count != nullptr: the list is
-  // still being produced on the device, n is the capacity of this pass (kernels_mcmc.hip: k_refine_gather).
-  // phase 0: gather, float64 pass and write-back; 1: gather only (the rest is deferred: `pend`); 2: float64 pass and
-  // write-back of the pending gather (d_ref / d_flag are the pending pass's own at that moment)
+  // holds fewer than n entries -- the count is read on the device, n is the (padded) size of this pass (kernels_mcmc.hip:
+  // k_refine_gather).
   int refine_listed(const real* r, const real* R, int B, int n, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign,
-                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr, int n_scatter = -1, bool use_score = false,
-                    int phase = 0) {
-    if (phase == 0) { const int rcj = refine_finish(); if (rcj) return rcj; }      // (one float64 pass at a time on the twin)
+                    const int32_t* d_count = nullptr, const int32_t* d_list = nullptr, int n_scatter = -1, bool use_score = false) {
     if (!d_list) d_list = d_flag + 1;
     if (n_scatter < 0) n_scatter = n;
     const int n3 = 3 * N, nR3 = 3 * sys.n_nuc;
@@ -2000,12 +1787,9 @@ struct Engine : dqmc_ctx {
     double* r64 = (double*)(d_ref + o_r); double* R64 = (double*)(d_ref + o_R); double* e64 = (double*)(d_ref + o_e);
     double* s64 = (double*)(d_ref + o_s); double* g64 = (double*)(d_ref + o_g); double* l64 = (double*)(d_ref + o_l);
     int32_t* sg64 = (int32_t*)(d_ref + o_sg);
-    if (phase != 2) {
-      t_begin("refine", 0);
-      dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
-      t_end();
-    }
-    if (phase == 1) return DQMC_OK;
+    t_begin("refine", 0);
+    dqmc::launch_refine_gather(st, (const float*)r, (const float*)R, d_list, d_count, n, n3, nR3, r64, R64);
+    t_end();
     twin->ph_skip = (e_loc == nullptr);       // psi_grad / Langevin: the plain gradient, no pseudo-Hamiltonian seeding
     // a Hamiltonian with a non-local ECP: the twin runs the quadrature of its walkers in float64 with the rotation angles
     // of the walkers they stand for (its psi ratios carry the float64 value path's accuracy: float32 ratios alone put
@@ -2039,63 +1823,14 @@ struct Engine : dqmc_ctx {
     if (!d_count && !use_score) last_refined += n_scatter;
     return DQMC_OK;
   }
-  // Enqueue the pending float64 pass on its own stream, gated by everything the context's stream holds at this moment.
-  int refine_launch() {
-    if constexpr (sizeof(real) == 4) {
-      if (!pend.on || pend.launched) return DQMC_OK;
-      if (!st_tw) {
-        HIP_TRY(hipStreamCreateWithFlags(&st_tw, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ev_tw_go, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&ev_tw_done, hipEventDisableTiming));
-      }
-      HIP_TRY(hipEventRecord(ev_tw_go, st));
-      HIP_TRY(hipStreamWaitEvent(st_tw, ev_tw_go, 0));
-      // the pass works on the pending call's own flag list and scratch, on the side stream
-      std::swap(d_flag, pend.flag); std::swap(flag_cap, pend.flag_cap);
-      std::swap(d_ref, pend.ref); std::swap(ref_bytes, pend.ref_bytes);
-      hipStream_t keep = st, keep_t = twin->st;
-      const bool keep_timing = timing, keep_timing_t = twin->timing;
-      st = st_tw; twin->st = st_tw; timing = false; twin->timing = false;        // (HIP-event timing assumes the context's stream)
-      const int save_refined = last_refined;
-      const int rc = refine_listed(pend.r, pend.R, pend.B, pend.n_pad, pend.e_loc, pend.stats, pend.grad, pend.logpsi, pend.sign,
-                                   pend.use_count ? d_flag : nullptr, nullptr, -1, false, 2);
-      last_refined = save_refined;
-      hipError_t ee = hipEventRecord(ev_tw_done, st_tw);
-      st = keep; twin->st = keep_t; timing = keep_timing; twin->timing = keep_timing_t;
-      std::swap(d_flag, pend.flag); std::swap(flag_cap, pend.flag_cap);
-      std::swap(d_ref, pend.ref); std::swap(ref_bytes, pend.ref_bytes);
-      if (rc) return rc;
-      HIP_TRY(ee);
-      pend.launched = true;
-    }
+  // error-predictor scores of the last float32 pass that flagged (host copy; walkers of that call, in order)
+  int last_score_B = 0;
+  int refine_scores(double* out, int n) override {
+    if (sizeof(real) != 4 || !d_score || last_score_B < 1) return fail(DQMC_E_UNSUPPORTED, "no float32 pass with the error predictor has run on this context");
+    if (n > last_score_B) return fail(DQMC_E_ARG, "more scores requested than the last flagged pass had walkers");
+    HIP_TRY(hipMemcpyAsync(out, d_score, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return DQMC_OK;
-  }
-  // The context's stream waits for the pending float64 pass (enqueueing it first if need be): whatever the caller puts on
-  // the stream next sees the refined values.
-  int refine_finish() override {
-    if constexpr (sizeof(real) == 4) {
-      if (!pend.on) return DQMC_OK;
-      const int rc = refine_launch();
-      if (rc) return rc;
-      HIP_TRY(hipStreamWaitEvent(st, ev_tw_done, 0));
-      pend.on = false;
-      // its flag list and scratch become the alternates of the next deferral
-      if (d_flag_alt) HIP_TRY(hipFree(d_flag_alt));
-      if (d_ref_alt) HIP_TRY(hipFree(d_ref_alt));
-      d_flag_alt = pend.flag; flag_cap_alt = pend.flag_cap; d_ref_alt = pend.ref; ref_bytes_alt = pend.ref_bytes;
-      pend.flag = nullptr; pend.ref = nullptr; pend.flag_cap = pend.ref_bytes = 0;
-    }
-    return DQMC_OK;
-  }
-  // capacity of the enqueue-ahead float64 pass: 1.5 x the largest of the last counts, in steps of 32 (small batches: 8) walkers
-  void update_ahead_cap(int n, int B) {
-    ahead_hist[ahead_pos++ & 3] = n;
-    int mx = 0;
-    for (int k = 0; k < 4; ++k) mx = ahead_hist[k] > mx ? ahead_hist[k] : mx;
-    const long step = B >= 512 ? 32 : 8;
-    long cap = refine_ahead >= 2 ? ((long)mx + mx / 8 + 63) / 64 * 64 : ((long)mx * 3 / 2 + step - 1) / step * step;      // (2: tight capacity in the steps the captured twin passes use)
-    if (cap < step) cap = step;
-    ahead_cap = (2 * cap > B) ? 0 : (int)cap;        // a large share of the batch: the plain path decides (direct float64 mode)
   }
   int upload_list(const std::vector<int32_t>& idx) {
     std::vector<int32_t> buf(idx.size() + 1);
@@ -2106,20 +1841,9 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
   int lap_refined(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
-    const int rc = lap_refined_(r, R, B, e_loc, stats, grad, logpsi, sign);
+    const int rc = lap_refined_ecp(r, R, B, e_loc, stats, grad, logpsi, sign);
     refine_info[0] = sizeof(real) == 8 ? 0 : refine; refine_info[1] = refine_thresh; refine_info[2] = probe_c; refine_info[3] = refine_all_calls;
     return rc;
-  }
-  int lap_refined_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
-    ++lap_calls;
-    if (pend.on) {       // the float64 pass deferred by the previous call: start it now, beside this call's float32 pass ...
-      const int rcl = refine_launch();
-      if (rcl) return rcl;
-    }
-    const int rc0 = lap_refined_ecp(r, R, B, e_loc, stats, grad, logpsi, sign);
-    if (rc0) return rc0;
-    if (pend.on && pend.call < lap_calls) return refine_finish();      // ... and join it before this call returns
-    return DQMC_OK;
   }
   int lap_refined_ecp(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     if constexpr (sizeof(real) == 4) {
@@ -2138,8 +1862,12 @@ struct Engine : dqmc_ctx {
   // Non-local ECP term of a float32 context with per-pair precision (kernels_ecp.hip: "mixed-precision quadrature"):
   // added to e_loc, stored in stats[3].
   int ecp_mixed(const float* r, const float* R, int B, float* e_loc, float* stats) {
+    // No float64 twin for this program (its float64 kernel set does not exist: DQMC_E_UNSUPPORTED -- lap_refined_core has
+    // switched the refinement off for the same reason): the quadrature runs entirely in float32, as local_energy_ecp would
+    // (every kept pair in the float32 class; the pair cut-off stays).  Any other failure is an error of the call.
     int rc = ensure_twin();
-    if (rc) return rc;
+    const bool have_twin = rc == DQMC_OK;
+    if (rc && rc != DQMC_E_UNSUPPORTED) return rc;
     const size_t per_walker = (size_t)ecp_n_nl * N * 12, triples_pw = (size_t)ecp_n_nl * N;
     int nbw = (int)(ecp_max_cfg / per_walker);
     nbw = nbw < 1 ? 1 : (nbw > B ? B : nbw);
@@ -2160,15 +1888,30 @@ struct Engine : dqmc_ctx {
     float* rq32 = (float*)(d_ecpm + o_r32); float* lq32 = (float*)(d_ecpm + o_l32); int32_t* sq32 = (int32_t*)(d_ecpm + o_s32);
     double* rq64 = (double*)(d_ecpm + o_r64); double* lq64 = (double*)(d_ecpm + o_l64); int32_t* sq64 = (int32_t*)(d_ecpm + o_s64);
     double* R64 = (double*)(d_ecpm + o_R64);
-    dqmc::launch_refine_gather(st, r, R, nullptr, nullptr, 0, 3 * N, 3 * sys.n_nuc, nullptr, R64);      // (widens R only)
+    if (have_twin) dqmc::launch_refine_gather(st, r, R, nullptr, nullptr, 0, 3 * N, 3 * sys.n_nuc, nullptr, R64);      // (widens R only)
     dqmc::EcpMixArgs a{};
     a.r = r; a.R = R; a.nl_nuc = d_ecp_nuc; a.nl = d_ecp_nl; a.phi = (const float*)ecp_phi; a.seed = ecp_seed;
     a.B = B; a.N = N; a.n_nl = ecp_n_nl; a.L = ecp_L; a.n_t = ecp_nt_nl;
-    a.w_heavy = ecp_w_heavy; a.w_skip = ecp_w_skip;
+    a.w_heavy = have_twin ? ecp_w_heavy : HUGE_VAL; a.w_skip = ecp_w_skip;
+    a.dlog_floor = ecp_dlog_floor;
     ecp_last_counts[0] = ecp_last_counts[1] = ecp_last_counts[2] = 0;
     for (int b0 = 0; b0 < B; b0 += nbw) {
       a.b0 = b0; a.nb = (B - b0) < nbw ? (B - b0) : nbw;
       HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int32_t), st));
+      a.l32 = nullptr;
+      if (have_twin && ecp_dlog_floor > 0) {
+        // psi(r) of the chunk's own walkers by both value paths, ahead of the classification (the lists are empty: the
+        // configurations are the nb walkers themselves); their disagreement is each walker's float32 error
+        t_begin("ecp", 0);
+        dqmc::launch_ecp_points_list<float>(st, a, list_l, 0, rq32);
+        dqmc::launch_ecp_points_list<double>(st, a, list_h, 0, rq64);
+        t_end();
+        rc = run((const real*)rq32, (const real*)R, a.nb, false, (real*)lq32, sq32, nullptr, nullptr, nullptr);
+        if (rc) return rc;
+        rc = twin->wf_eval(rq64, R64, a.nb, lq64, sq64);
+        if (rc) return rc;
+        a.l32 = lq32; a.l64 = lq64; a.s32 = sq32; a.s64 = sq64;
+      }
       t_begin("ecp", 0);
       dqmc::launch_ecp_classify(st, a, cls, list_l, list_h, cnt);
       t_end();
@@ -2179,12 +1922,16 @@ struct Engine : dqmc_ctx {
       ecp_last_counts[2] += (long)a.nb * (long)triples_pw - n2[0] - n2[1];
       t_begin("ecp", 0);
       dqmc::launch_ecp_points_list<float>(st, a, list_l, n2[0], rq32);
-      dqmc::launch_ecp_points_list<double>(st, a, list_h, n2[1], rq64);
+      if (have_twin) dqmc::launch_ecp_points_list<double>(st, a, list_h, n2[1], rq64);
       t_end();
       rc = run((const real*)rq32, (const real*)R, a.nb + 12 * n2[0], false, (real*)lq32, sq32, nullptr, nullptr, nullptr);
       if (rc) return rc;
-      rc = twin->wf_eval(rq64, R64, a.nb + 12 * n2[1], lq64, sq64);
-      if (rc) return rc;
+      if (have_twin) {
+        rc = twin->wf_eval(rq64, R64, a.nb + 12 * n2[1], lq64, sq64);
+        if (rc) return rc;
+      } else if (n2[1] != 0) {
+        return fail(DQMC_E_HIP, "ECP classification produced float64 pairs without a float64 twin");
+      }
       t_begin("ecp", 0);
       dqmc::launch_ecp_reduce_mixed(st, a, cls, lq32, sq32, lq64, sq64, e_loc, stats);
       t_end();
@@ -2193,7 +1940,20 @@ struct Engine : dqmc_ctx {
     return DQMC_OK;
   }
   int lap_refined_core(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
+    const int rc = lap_refined_core_(r, R, B, e_loc, stats, grad, logpsi, sign);
+    refine_counters[3] += last_refined;
+    return rc;
+  }
+  // more than this many of B walkers above the threshold: the batch goes to float64 whole (hysteresis: see refine_direct_enter)
+  bool mostly_flagged(long n_above, int B) {
+    const double lim = was_direct ? refine_direct_exit : refine_direct_enter;
+    const bool yes = B >= 16 && (double)n_above > lim * (double)B;
+    was_direct = yes;
+    return yes;
+  }
+  int lap_refined_core_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     last_refined = 0;
+    ++refine_counters[0];
     if constexpr (sizeof(real) == 8) {
       return pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
     } else {
@@ -2217,6 +1977,8 @@ struct Engine : dqmc_ctx {
       const bool direct = refine >= 2 || (refine == 1 && refine_all_calls > 0 && twin);
       if (refine == 1 && refine_all_calls > 0) --refine_all_calls;
       if (direct) {                // the whole forward-Laplacian pass in float64 (float32 stays the sampling dtype)
+        ++refine_counters[1];
+        last_score_B = 0;          // (no float32 pass, no scores)
         rc = ensure_twin();
         if (rc) return rc;
         std::vector<int32_t> iota((size_t)B);
@@ -2235,53 +1997,23 @@ struct Engine : dqmc_ctx {
       flag_on = true;
       rc = pass_own(r, R, B, logpsi, sign, e_loc, stats, grad);
       flag_on = false;
+      last_score_B = rc ? 0 : B;
       if (rc) return rc;
       const bool probe = refine == 1 && refine_probe > 0 && e_loc && (calls_since_probe < 0 || calls_since_probe + 1 >= refine_probe);
       if (calls_since_probe >= 0) ++calls_since_probe;
       int32_t n = 0;
-      if (!probe && refine_ahead && twin && ahead_cap > 0 && ahead_cap <= B) {
-        // The float64 pass is enqueued BEFORE the host knows how many walkers were flagged: it runs at a capacity derived
-        // from the recent counts, the gather / scatter kernels read the count on the device.  The ~100 launches of the
-        // twin are issued while the GPU still executes the float32 pass (they used to start only after a host round trip,
-        // with the GPU idle in between); the count is read once everything is enqueued.  An overflow (count > capacity:
-        // rare, the capacity carries 50 % headroom) is finished by a second pass over the remainder.
-        const int cap = ahead_cap;
-        rc = refine_listed(r, R, B, cap, e_loc, stats, grad, logpsi, sign, d_flag);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (n > B) n = B;
-        last_refined = n < cap ? n : cap;
-        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) {
-          // most of the batch is beyond float32: like the synchronous path, this call and the next 15 go to float64 whole
-          refine_all_calls = 15;
-          std::vector<int32_t> iota((size_t)B);
-          for (int k = 0; k < B; ++k) iota[k] = k;
-          rc = upload_list(iota);
-          if (rc) return rc;
-          last_refined = 0;
-          rc = refine_listed(r, R, B, B, e_loc, stats, grad, logpsi, sign);
-          if (rc) return rc;
-        } else if (n > cap) {
-          rc = refine_listed(r, R, B, n - cap, e_loc, stats, grad, logpsi, sign, nullptr, d_flag + 1 + cap);
-          if (rc) return rc;
-        }
-        update_ahead_cap(n, B);
-        HIP_TRY(hipGetLastError());
-        return DQMC_OK;
-      }
       HIP_TRY(hipMemcpyAsync(&n, d_flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if (n > B) n = B;
-      if (!probe) update_ahead_cap(n, B);
       if (!probe) {
         if (n <= 0) return DQMC_OK;
         rc = ensure_twin();
         if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }   // no float64 kernel set for this program: float32 stands
         if (rc) return rc;
-        if (refine == 1 && 2 * (long)n > (long)B && B >= 16) {
+        if (refine == 1 && mostly_flagged(n, B)) {
           // most of the batch is beyond float32: this call and the next 15 evaluate everything in float64
           refine_all_calls = 15;
+          ++refine_counters[1];
           std::vector<int32_t> iota((size_t)B);
           for (int k = 0; k < B; ++k) iota[k] = k;
           rc = upload_list(iota);
@@ -2295,22 +2027,6 @@ struct Engine : dqmc_ctx {
         int n_eval = padded ? (n + 63) / 64 * 64 : n;
         if (n_eval > B) n_eval = B;
         const int32_t* d_cnt = padded ? d_flag : nullptr;
-        if (refine_defer && e_loc && ecp_n_nl == 0 && !timing && n < B) {
-          // deferred: gather the flagged walkers now (the caller may move them before the pass runs), hand flag list and
-          // scratch to the pending pass, continue on the alternates
-          rc = refine_finish();
-          if (rc) return rc;
-          rc = refine_listed(r, R, B, n_eval, e_loc, stats, grad, logpsi, sign, d_cnt, nullptr, -1, false, 1);
-          if (rc) return rc;
-          pend.on = true; pend.launched = false; pend.call = lap_calls; pend.n = n; pend.n_pad = n_eval; pend.B = B; pend.use_count = padded;
-          pend.r = r; pend.R = R; pend.e_loc = e_loc; pend.stats = stats; pend.grad = grad; pend.logpsi = logpsi; pend.sign = sign;
-          pend.flag = d_flag; pend.flag_cap = flag_cap; pend.ref = d_ref; pend.ref_bytes = ref_bytes;
-          d_flag = d_flag_alt; flag_cap = flag_cap_alt; d_flag_alt = nullptr; flag_cap_alt = 0;
-          d_ref = d_ref_alt; ref_bytes = ref_bytes_alt; d_ref_alt = nullptr; ref_bytes_alt = 0;
-          last_refined = n;
-          HIP_TRY(hipGetLastError());
-          return DQMC_OK;
-        }
         rc = refine_listed(r, R, B, n_eval, e_loc, stats, grad, logpsi, sign, d_cnt);
         last_refined = n;
         HIP_TRY(hipGetLastError());
@@ -2318,6 +2034,7 @@ struct Engine : dqmc_ctx {
       }
       // ---- probe call: measure the float32 error per unit of score on a strided sample, re-derive the threshold, and
       // apply it to THIS call as well (a caller that evaluates once gets the calibrated result)
+      ++refine_counters[2];
       rc = ensure_twin();
       if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }
       if (rc) return rc;
@@ -2372,10 +2089,11 @@ struct Engine : dqmc_ctx {
       long n_above = 0;
       for (int b = 0; b < B; ++b) if (!(score[b] <= refine_thresh)) ++n_above;
       std::vector<int32_t> more;
-      if (refine == 1 && 2 * n_above > (long)B && B >= 16) {
+      if (refine == 1 && mostly_flagged(n_above, B)) {
         // most of the batch is beyond float32: the next calls go to float64 directly, and so does the rest of this one
         // (the few walkers below the threshold of such a system are not reliably predicted either)
         refine_all_calls = 15;
+        ++refine_counters[1];
         for (int b = 0; b < B; ++b) if (!done[b] || score[b] <= refine_thresh) more.push_back(b);     // not yet written back
         last_refined = B - (int)more.size();
       } else {
@@ -2965,11 +2683,6 @@ int dqmc_debug_read(dqmc_ctx* ctx, int buf, double* out, size_t n) {
 }
 int dqmc_debug_lanes(dqmc_ctx* ctx) { return ctx ? ctx->last_TP : 0; }
 int dqmc_last_refined(dqmc_ctx* ctx) { return ctx ? ctx->last_refined : 0; }
-int dqmc_refine_finish(dqmc_ctx* ctx) {
-  if (!ctx) return fail(DQMC_E_ARG, "null argument");
-  HIP_TRY(hipSetDevice(ctx->device));
-  return ctx->refine_finish();
-}
 int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3) {
   if (!ctx || !out3) return DQMC_E_ARG;
   for (int k = 0; k < 3; ++k) out3[k] = ctx->ecp_last_counts[k];
@@ -2984,6 +2697,16 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4) {
   if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");
   for (int k = 0; k < 4; ++k) out4[k] = ctx->refine_info[k];
   return DQMC_OK;
+}
+int dqmc_refine_counters(dqmc_ctx* ctx, int64_t* out4) {
+  if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");
+  for (int k = 0; k < 4; ++k) out4[k] = ctx->refine_counters[k];
+  return DQMC_OK;
+}
+int dqmc_refine_scores(dqmc_ctx* ctx, double* out, int n) {
+  if (!ctx || !out || n < 1) return fail(DQMC_E_ARG, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  return ctx->refine_scores(out, n);
 }
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(DQMC_E_ARG, "null argument");

@@ -859,14 +859,6 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
   const int w0 = blockIdx.x * a.WT;
   const int nw = (a.B - w0) < a.WT ? (a.B - w0) : a.WT;
   if (a.prof_wg && threadIdx.x == 0 && blockIdx.x < 8192) a.prof_wg[2 * blockIdx.x] = (long long)wall_clock64();
-  if (a.stagger > 0) {
-    // The workgroups that share a CU start together and would walk through the program in lockstep: all in an MFMA-
-    // heavy layer at once (each getting a quarter of the matrix pipe), then all in an issue-bound phase with the pipe
-    // idle.  Delaying the k-th resident workgroup of a CU by k * stagger * 8 k cycles (dispatch fills the CUs
-    // breadth-first: workgroup b is the (b / n_cu)-th on its CU) lets their phases interleave.
-    const int ph = (int)(blockIdx.x / (unsigned)a.stagger_div) & 3;
-    for (int i = 0; i < ph * a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  }
   {
     // positions of the tile -> LDS; in sub-step mode the proposal r' = r + tau * xi (electron_samplers.py:102-104)
     real* rs = smem + a.scratch_off;
@@ -931,8 +923,6 @@ __device__ __forceinline__ void fused2_body(const Fused2Args<real>& a) {
     }
     if (kind == 2) {
       __syncthreads();
-    } else if (kind == 4) {
-      wave_lds_fence();          // chained MLP layer: the rows this wave just stored are the rows it reads next
     } else if (kind == 5) {
       fused2_unit_lean<real>(a, d, nxt);
     } else if (kind == 7) {

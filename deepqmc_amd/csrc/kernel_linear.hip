@@ -466,12 +466,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
 // (second launch bound = waves per SIMD the register allocation must leave room for; the 8-wave value-row tiles -- 256 x 128
 // in float32, 128 x 128 in float64 -- are to run two workgroups per CU = four waves per SIMD; the split-group tiles exist to run
 // two waves per SIMD -- unconstrained, the 4 x 4 float64 tile takes 200 + 128 registers and one wave remains)
-// DUAL (CHAIN only): TWO such MLPs on the same input rows -- the node MLPs h of the two edge types of a message-passing layer
-// (reference gnn/electron_gnn.py:139-160: one subnet per edge type, each applied to the same node embeddings) -- in one
-// launch: the A tile is fetched and staged once and multiplied by both first-layer weight matrices, then the two hidden tiles
-// pass through the LDS tile one after the other.  The second MLP's pointers are LinArgs::*_b; shapes, activations and the
-// destination geometry are those of the first.
-template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1, bool DUAL = false>
+template <typename real, int MR, int NR, int GPW, int WN, bool CHAIN = false, int NR2 = 2, int BKX = 1>
 __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4 && WN == 2 && MR * sizeof(real) == 16) ? 4 : 1) k_linear(const LinArgs<real> a) {
   constexpr int NT = 256 * WN;
   constexpr int BM = 64 * MR, BN = 16 * NR * WN, BK = 16 * BKX, BK2 = 16;
@@ -485,12 +480,10 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
-  static_assert(!DUAL || CHAIN, "dual MLPs are chained MLPs");
-  constexpr int ND = DUAL ? 2 : 1;
   static_assert(!SPLIT || (!CHAIN && WN == 1 && 6 * NR * 16 <= BM * AS), "split groups: plain layers, one column tile per workgroup");
   typedef typename Mfma<real>::acc_t acc_t;
   __shared__ real As[BM * AS];
-  __shared__ real Bs[ND * BK * BS];
+  __shared__ real Bs[BK * BS];
   __shared__ real Hs[CHAIN ? BM * HS : 1];
   __shared__ real Bs2[CHAIN ? BK2 * BS2 : 1];
 
@@ -531,16 +524,10 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   }
 
   acc_t acc[MR][NR];
-  acc_t accb[DUAL ? MR : 1][DUAL ? NR : 1];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
-  if (DUAL)
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int j = 0; j < NR; ++j) accb[DUAL ? i : 0][DUAL ? j : 0] = acc_t{0, 0, 0, 0};
 
   for (int p = 0; p < a.n_pieces; ++p) {
     const LinPiece<real> pc = a.piece[p];
@@ -557,7 +544,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT][BKX], rb_[NBV], rbb_[DUAL ? NBV : 1];
+    Vec4<real> ra[APT][BKX], rb_[NBV];
     auto load_chunk = [&](int kc) {
 #pragma unroll
       for (int j = 0; j < APT; ++j)
@@ -574,10 +561,8 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         const int kk = kc * BK + k, col = col_blk0 + 4 * n4;
         if (f < BK * BN / 4 && kk < pc.K && col < a.ldw) {
           rb_[j] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk) * a.ldw + col);
-          if (DUAL) rbb_[DUAL ? j : 0] = *reinterpret_cast<const Vec4<real>*>(a.W_b + (long)(w_row0 + kk) * a.ldw + col);
         } else {
           rb_[j] = Vec4<real>{{0, 0, 0, 0}};
-          if (DUAL) rbb_[DUAL ? j : 0] = Vec4<real>{{0, 0, 0, 0}};
         }
       }
     };
@@ -598,7 +583,6 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         if (f < BK * BN / 4) {
           const int k = f / (BN / 4), n4 = f % (BN / 4);
           *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = rb_[j];
-          if (DUAL) *reinterpret_cast<Vec4<real>*>(&Bs[BK * BS + k * BS + 4 * n4]) = rbb_[DUAL ? j : 0];
         }
       }
       __syncthreads();
@@ -615,14 +599,6 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
-        if (DUAL) {
-#pragma unroll
-          for (int j = 0; j < NR; ++j) fb[j] = Bs[BK * BS + kcol * BS + wn * (16 * NR) + j * 16 + (lane & 15)];
-#pragma unroll
-          for (int i = 0; i < MR; ++i)
-#pragma unroll
-            for (int j = 0; j < NR; ++j) accb[DUAL ? i : 0][DUAL ? j : 0] = Mfma<real>::run(fa[i], fb[j], accb[DUAL ? i : 0][DUAL ? j : 0]);
-        }
       }
     }
   }
@@ -632,9 +608,8 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
     lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx, As);
     return;
   }
-  // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there (DUAL: once per MLP) ----
-  auto second_layer = [&](acc_t (&h)[MR][NR], const real* bias1, const real* W2, const real* bias2, const LinArgs<real>& out, bool first) {
-    if (!first) __syncthreads();                            // the first MLP's second product has read the hidden tile
+  // ---- chained second layer: hidden tile -> LDS, then Y = act2(H W2 + b2) from there ----
+  auto second_layer = [&](acc_t (&h)[MR][NR], const real* bias1, const real* W2, const real* bias2, const LinArgs<real>& out) {
     // W2 (<= 16 NR rows x 16 NR2 columns: one 4-vector per thread and chunk) is requested NOW, ahead of the hidden layer's
     // epilogue, and waits in registers: fetched chunk by chunk between the barriers of the loop below, every chunk cost one
     // L2 round trip that nothing overlapped
@@ -687,12 +662,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
     HbmSink<real> sink(out);
     lin_epilogue<real, MR, NR2, GPW>(acc2, out, bias2, a.act2, a.ldw2, (const real*)nullptr, 0, wm, n_groups, sink, bx);
   };
-  second_layer(acc, a.bias, a.W2, a.bias2, a, true);
-  if constexpr (DUAL) {
-    LinArgs<real> ab = a;                                   // the second MLP's destination and residual, same geometry
-    ab.dst = a.dst_b; ab.res = a.res_b;
-    second_layer(accb, a.bias_b, a.W2_b, a.bias2_b, ab, false);
-  }
+  second_layer(acc, a.bias, a.W2, a.bias2, a);
 }
 
 // ---- float32 layers on the bf16 matrix pipe (common.h: "float32 products on the bf16 matrix pipe") ----
@@ -709,10 +679,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // (second launch bound = waves per SIMD the register allocation must leave room for: the 48-row x 64-column wave tiles of
 // the 48-lane groups need 172 registers unconstrained -- two waves per SIMD -- and fit three with 168)
-// PRE: the weights arrive already split (LinArgs::Wbf: three planes of bf16 PAIRS along k, made on the host by
-// Engine::set_weights like the fused kernel's) -- the staging copies three 16-byte rows instead of splitting two float4
-// (44 VALU instructions per item and workgroup).
-template <int MR, int NR, int GPW, int WN, int NP, bool PRE = false>
+template <int MR, int NR, int GPW, int WN, int NP>
 __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_linear_bf(const LinArgs<float> a) {
   typedef float real;
   constexpr int NT = 256 * WN;
@@ -781,8 +748,7 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT][2], rb_[PRE ? 1 : NBI][2];
-    BfFrag rp_[PRE ? NBI : 1][3];
+    Vec4<real> ra[APT][2], rb_[NBI][2];
     auto load_chunk = [&](int kc) {
 #pragma unroll
       for (int j = 0; j < APT; ++j)
@@ -797,20 +763,12 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
         const int f = tid + NT * j;
         const int kp = f / (BN / 4), n4 = f % (BN / 4);
         const int kk = kc * BK + 2 * kp, col = col_blk0 + 4 * n4;
-        if (PRE) {
-          const bool ok = f < (BK / 2) * (BN / 4) && kk < pc.K && col < a.ldw;      // (piece widths are multiples of 4: kk + 1 < K too)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
-            rp_[PRE ? j : 0][pl] = ok ? *reinterpret_cast<const BfFrag*>(a.Wbf + pl * a.wbf_plane + (long)((w_row0 + kk) >> 1) * a.ldw + col)
-                                      : BfFrag{{0u, 0u, 0u, 0u}};
-        } else {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            if (f < (BK / 2) * (BN / 4) && kk + h < pc.K && col < a.ldw)
-              rb_[PRE ? 0 : j][h] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk + h) * a.ldw + col);
-            else
-              rb_[PRE ? 0 : j][h] = Vec4<real>{{0, 0, 0, 0}};
-          }
+        for (int h = 0; h < 2; ++h) {
+          if (f < (BK / 2) * (BN / 4) && kk + h < pc.K && col < a.ldw)
+            rb_[j][h] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk + h) * a.ldw + col);
+          else
+            rb_[j][h] = Vec4<real>{{0, 0, 0, 0}};
         }
       }
     };
@@ -833,22 +791,18 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
           BfFrag* d0 = reinterpret_cast<BfFrag*>(&Bs[(0 * 16 + kp) * BSTR + 4 * n4]);
           BfFrag* d1 = reinterpret_cast<BfFrag*>(&Bs[(1 * 16 + kp) * BSTR + 4 * n4]);
           BfFrag* d2 = reinterpret_cast<BfFrag*>(&Bs[(2 * 16 + kp) * BSTR + 4 * n4]);
-          if (PRE) {
-            *d0 = rp_[PRE ? j : 0][0]; *d1 = rp_[PRE ? j : 0][1]; *d2 = rp_[PRE ? j : 0][2];
-          } else {
-            uint32_t w0[4], w1[4], w2[4];
+          uint32_t w0[4], w1[4], w2[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {                        // column c of the item: k (low half) and k + 1 (high half)
-              const float x0 = rb_[PRE ? 0 : j][0].v[c], x1 = rb_[PRE ? 0 : j][1].v[c];
-              const uint32_t h = bf_pack2(x0, x1);
-              const float r0 = x0 - bf_lo_as_float(h), r1 = x1 - bf_hi_as_float(h);
-              const uint32_t m = bf_pack2(r0, r1);
-              w0[c] = h; w1[c] = m; w2[c] = bf_pack2(r0 - bf_lo_as_float(m), r1 - bf_hi_as_float(m));
-            }
-            *d0 = BfFrag{{w0[0], w0[1], w0[2], w0[3]}};
-            *d1 = BfFrag{{w1[0], w1[1], w1[2], w1[3]}};
-            *d2 = BfFrag{{w2[0], w2[1], w2[2], w2[3]}};
+          for (int c = 0; c < 4; ++c) {                        // column c of the item: k (low half) and k + 1 (high half)
+            const float x0 = rb_[j][0].v[c], x1 = rb_[j][1].v[c];
+            const uint32_t h = bf_pack2(x0, x1);
+            const float r0 = x0 - bf_lo_as_float(h), r1 = x1 - bf_hi_as_float(h);
+            const uint32_t m = bf_pack2(r0, r1);
+            w0[c] = h; w1[c] = m; w2[c] = bf_pack2(r0 - bf_lo_as_float(m), r1 - bf_hi_as_float(m));
           }
+          *d0 = BfFrag{{w0[0], w0[1], w0[2], w0[3]}};
+          *d1 = BfFrag{{w1[0], w1[1], w1[2], w1[3]}};
+          *d2 = BfFrag{{w2[0], w2[1], w2[2], w2[3]}};
         }
       }
       __syncthreads();
@@ -954,25 +908,16 @@ static bool bf_pays(const LinArgs<float>& a, int np) {
   for (int p = 0; p < a.n_pieces; ++p) { chunks += (a.piece[p].K + 31) / 32; ksteps += (a.piece[p].K + 3) / 4; }
   return a.cfg_bf != 0 && chunks * np * 16 + chunks * 12 < ksteps * 32;
 }
-template <int MR, int NR, int GPW, int WN, bool PRE = false> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
+template <int MR, int NR, int GPW, int WN> static void launch_bf(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
   constexpr int BM = 64 * MR, BN = 16 * NR * WN;
   constexpr size_t lds = (size_t)BM * 34 * 4 + (size_t)3 * 16 * (BN + 4) * 4;
   constexpr int NP = GPW == 0 ? 6 : 9;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_bf<MR, NR, GPW, WN, NP, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_linear_bf<MR, NR, GPW, WN, NP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_bf<MR, NR, GPW, WN, NP, PRE>), dim3(gx, gy), dim3(256 * WN), lds, st, a);
-}
-// Value-only rows on the bf16 pipe (cfg_bf >= 3): 64 rows x 128 columns per workgroup, ONE A split (44 VALU) feeds eight column
-// blocks x six products = 768 matrix-pipe cycles, the weights come pre-split -- against 2048 cycles of v_mfma_f32_16x16x4_f32
-// for the same tile.  Layers of at least 128 columns whose weight block has pre-split planes.
-static bool launch_bf_value_rows(hipStream_t st, const LinArgs<float>& a) {
-  if (a.cfg_bf < 3 || a.Wbf == nullptr || a.ldw < 128 || a.TP != 1 || !bf_pays(a, 6)) return false;
-  const long rows = (long)a.B * a.nrows;
-  launch_bf<1, 8, 0, 1, true>(st, a, (unsigned)((rows + 63) / 64), (unsigned)((a.ldw + 127) / 128));
-  return true;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear_bf<MR, NR, GPW, WN, NP>), dim3(gx, gy), dim3(256 * WN), lds, st, a);
 }
 template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
   static bool run(hipStream_t, const LinArgs<real>&, unsigned, unsigned) { return false; }
@@ -980,9 +925,8 @@ template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
 template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
   static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
     if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
-    if (a.cfg_bf >= 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2 / 3: only the 48-lane Laplacian tiles (measured faster there)
-    if (a.Wbf != nullptr && GPW > 0 && MR == 3 && WN == 1 && a.cfg_bf >= 3) launch_bf<MR, NR, GPW, WN, (GPW > 0 && MR == 3 && WN == 1)>(st, a, gx, gy);
-    else launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
+    if (a.cfg_bf >= 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
+    launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
     return true;
   }
 };
@@ -990,13 +934,7 @@ template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, W
 // A/B hook (dqmc_set_option "linear_bkx", per context: LinArgs::cfg_bkx): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
 // 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
 // float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
-// alone are 96 / 128 registers and ONE wave per SIMD remains; one column block per wave (option "linear_f64_nr1")
-// doubles the waves per SIMD at the price of reading the A rows twice as often
-template <typename real> static int kmax_of(const LinArgs<real>& a) {
-  int kmax = 0;
-  for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
-  return kmax;
-}
+// alone are 96 / 128 registers and ONE wave per SIMD remains (hence the split groups below)
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {
   int kmax = 0;
   for (int p = 0; p < a.n_pieces; ++p) kmax = a.piece[p].K > kmax ? a.piece[p].K : kmax;
@@ -1011,17 +949,8 @@ template <typename real, int MR, int NR, int GPW, int WN> static void launch_cfg
                       : GPW > 0 ? (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW)) : (unsigned)((n_groups + BM - 1) / BM);
   const unsigned gy = (unsigned)((a.ldw + BN - 1) / BN);
   if (BfLaunch<real, MR, NR, GPW, WN>::run(st, a, gx, gy)) return;
-  constexpr bool BIG16 = sizeof(real) == 4 && MR == 2 && NR == 4 && GPW == 2 && WN == 2;      // the 128 x 128 tiles of the 16-lane g layers
   if (MR == 1 && WN == 1 && GPW != 0 && wide_chunks(a))
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW != 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
-  else if (MR == 1 && WN == 1 && GPW == 0 && a.cfg_bkx_val && kmax_of(a) >= 64)
-    // value-only rows of the mid-size ansatzes (Metropolis sub-steps of a few hundred walkers, the quadrature walkers of an
-    // ECP): 64-row tiles, K = 256 -- sixteen load -> barrier -> 16 MFMAs round trips of one chunk each; 32-wide chunks halve them
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, (MR == 1 && WN == 1 && GPW == 0) ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
-  else if (BIG16 && a.cfg_bkx_big)
-    // K chunks of 32: a chunk of 16 is 1024 matrix-pipe cycles per wave between two barriers, less than one HBM round trip
-    // with a single chunk of prefetch
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN, false, 2, BIG16 ? 2 : 1>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, WN>), dim3(gx, gy), dim3(256 * WN), 0, st, a);
 }
@@ -1035,11 +964,6 @@ template <typename real, int MR, int NR, int GPW> static void launch_chain_cfg(h
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2>), dim3(gx, 1), dim3(256), 0, st, a);
 }
-template <typename real, int MR, int NR, int GPW> static void launch_chain_dual(hipStream_t st, const LinArgs<real>& a) {
-  const long n_groups = (long)a.B * a.nrows;
-  const unsigned gx = (unsigned)((n_groups + 4 * GPW - 1) / (4 * GPW));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linear<real, MR, NR, GPW, 1, true, 2, 1, true>), dim3(gx, 1), dim3(256), 0, st, a);
-}
 template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_t st, const LinArgs<real>& a) {
   if (a.ldw > 32) launch_chain_cfg<real, MR, 4, GPW>(st, a);
   else if (a.ldw > 16) launch_chain_cfg<real, MR, 2, GPW>(st, a);
@@ -1049,14 +973,6 @@ template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_
 // value-only rows.
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out) {
   return (TP == 1 || TP == 8 || TP == 16 || TP == 32) && ldw_hidden <= 64 && ldw_out <= 32;
-}
-// Two chained MLPs on the same rows in one launch (k_linear DUAL): 16- / 32-lane groups, hidden width 33..64, output <= 32.
-bool linear_chain_dual_supported(int TP, int ldw_hidden, int ldw_out) {
-  return (TP == 16 || TP == 32) && ldw_hidden > 32 && ldw_hidden <= 64 && ldw_out <= 32;
-}
-template <typename real> void launch_linear_chain_dual(hipStream_t st, const LinArgs<real>& a) {
-  if (a.TP == 16) launch_chain_dual<real, 1, 4, 1>(st, a);
-  else launch_chain_dual<real, 2, 4, 1>(st, a);
 }
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
@@ -1073,7 +989,7 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
   constexpr bool WIDE = sizeof(real) == 4 && MR % 2 == 0;   // 8 waves, BN = 128: the A rows of a wide layer are read half as often
   if (a.ldw > 64 && WIDE) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, (WIDE ? 2 : 1)>(st, a);
   else if (a.ldw > 32 && NR_MAX >= 4) launch_cfg<real, MR, (NR_MAX >= 4 ? 4 : 2), GPW, 1>(st, a);
-  else if (a.ldw > 16 && !(sizeof(real) == 8 && MR >= 6 && a.cfg_f64_nr1)) launch_cfg<real, MR, 2, GPW, 1>(st, a);
+  else if (a.ldw > 16) launch_cfg<real, MR, 2, GPW, 1>(st, a);
   else launch_cfg<real, MR, 1, GPW, 1>(st, a);
 }
 
@@ -1097,7 +1013,6 @@ template <typename real, int MRH> static bool launch_split(hipStream_t st, const
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
   switch (a.TP) {
     case 1: {
-      if constexpr (sizeof(real) == 4) { if (launch_bf_value_rows(st, a)) break; }
       // value-only rows (Metropolis sub-steps of the larger ansatzes): small batches would leave CUs idle with
       // 256-row tiles, so the tile height follows the row count (aim: >= 8 workgroups per CU)
       const long rows = (long)a.B * a.nrows;
@@ -1141,7 +1056,5 @@ template void launch_linear<float>(hipStream_t, const LinArgs<float>&);
 template void launch_linear<double>(hipStream_t, const LinArgs<double>&);
 template void launch_linear_chain<float>(hipStream_t, const LinArgs<float>&);
 template void launch_linear_chain<double>(hipStream_t, const LinArgs<double>&);
-template void launch_linear_chain_dual<float>(hipStream_t, const LinArgs<float>&);
-template void launch_linear_chain_dual<double>(hipStream_t, const LinArgs<double>&);
 
 }  // namespace dqmc

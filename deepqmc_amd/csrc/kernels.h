@@ -43,11 +43,6 @@ template <typename real> struct LinArgs {
   LinPiece<real> piece[4];
   const real* W;      // [sum K][ldw]
   int ldw;            // pad4(Nout)
-  // float32 contexts: the same weight block split into three bf16 planes on the host (Engine::set_weights), PAIRS of
-  // consecutive k rows packed per 32-bit word: plane p, element (k pair, column) at Wbf[p * wbf_plane + (k / 2) * ldw + column];
-  // nullptr: not available for this layer
-  const uint32_t* Wbf;
-  long wbf_plane;
   const real* bias;   // [ldw] or nullptr (value lane only)
   real* dst;
   int ld_dst, rpw_dst, r0_dst, col0_dst;
@@ -66,24 +61,14 @@ template <typename real> struct LinArgs {
   int ldw2;           // pad4(Nout of the second layer)
   const real* bias2;
   int act2;
-  // second MLP of a dual chained launch (launch_linear_chain_dual): same input rows, shapes, activations and destination
-  // geometry as the first; its own weights, destination and residual
-  const real* W_b;
-  const real* bias_b;
-  const real* W2_b;
-  const real* bias2_b;
-  real* dst_b;
-  const real* res_b;
-  // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_nr1";
+  // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_split";
   // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
   // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
-  int cfg_bf, cfg_bkx, cfg_f64_nr1, cfg_f64_split, cfg_bkx_big, cfg_bkx_val;
+  int cfg_bf, cfg_bkx, cfg_f64_split;
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
-template <typename real> void launch_linear_chain_dual(hipStream_t st, const LinArgs<real>& a);
-bool linear_chain_dual_supported(int TP, int ldw_hidden, int ldw_out);
 constexpr int LINEAR_BF_DEFAULT = 2, LINEAR_BKX_DEFAULT = 3;      // (kernel_linear.hip: what the values select)
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
@@ -172,7 +157,7 @@ template <typename real> struct Fused2Args {
   int it_off, n_it;         // LDS byte offset and length of the staged int table
   int ma1;                  // every unit is one row block high: launch the specialised kernel
   int prio_mode;            // 0: hardware default (oldest wave first); 1/2: issue priority rotates among the co-resident workgroups per level / per unit
-  int stagger, stagger_div; // start delay of the k-th co-resident workgroup of a CU: k * stagger * 8128 cycles; workgroups per dispatch wave
+  int stagger_div;          // workgroups per dispatch wave (the co-resident tiles of a CU are blockIdx / stagger_div apart)
   FusedMc mc;
   long long* prof;          // optional clock stamps of workgroup 0: [wave][256]
   long long* prof_wg;       // optional constant-rate (100 MHz) stamps of EVERY workgroup: [n_blocks][2] start, end
@@ -290,6 +275,13 @@ struct EcpMixArgs {
   int B, N, n_nl, L, n_t;
   int b0, nb;              // walker chunk of this launch
   double w_heavy, w_skip;  // class bounds on w = max_l (2l+1) |V_l(r_ia)|
+  // Measured float32 error of log|psi(r)| of the chunk's own walkers (both value paths evaluate them before the pairs are
+  // classified): l32 / l64 [nb] and their signs, or nullptr.  psi(r) is the denominator of every ratio of a walker, and near
+  // a node it is the quantity float32 cannot resolve (while the ratios themselves grow like 1 / psi(r)): the float64 bound
+  // of a walker's pairs tightens in proportion, w x max(1, |l32 - l64| / dlog_floor) > w_heavy; a sign mismatch sends
+  // every kept pair of the walker to float64.
+  const float* l32; const double* l64; const int32_t* s32; const int32_t* s64;
+  double dlog_floor;
 };
 void launch_ecp_classify(hipStream_t st, const EcpMixArgs& a, int32_t* cls, int32_t* list_l, int32_t* list_h, int32_t* counts);
 template <typename real_out> void launch_ecp_points_list(hipStream_t st, const EcpMixArgs& a, const int32_t* list, int n_list, real_out* rq);

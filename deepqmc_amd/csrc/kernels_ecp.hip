@@ -167,7 +167,12 @@ __global__ void __launch_bounds__(256) k_ecp_classify(const EcpMixArgs a, int32_
     w = fmax(w, (2 * l + 1) * fabs(vl));
   }
   if (!(w > a.w_skip)) { cls[t] = ECP_SKIP; return; }
-  if (w > a.w_heavy) { const int pos = atomicAdd(&counts[1], 1); list_h[pos] = t; cls[t] = -(pos + 1); }
+  double amp = 1.0;            // how much worse than ordinary float32 this walker's psi(r) is (EcpMixArgs::l32)
+  if (a.l32 != nullptr) {
+    const double dl = fabs((double)a.l32[bl] - a.l64[bl]);
+    amp = (a.s32[bl] != a.s64[bl] || !(dl == dl)) ? HUGE_VAL : fmax(1.0, dl / a.dlog_floor);
+  }
+  if (w * amp > a.w_heavy) { const int pos = atomicAdd(&counts[1], 1); list_h[pos] = t; cls[t] = -(pos + 1); }
   else { const int pos = atomicAdd(&counts[0], 1); list_l[pos] = t; cls[t] = pos; }
 }
 // configurations of one class: [0, nb) the walkers of the chunk themselves, then 12 per listed triple.  One thread per coordinate.

@@ -164,14 +164,8 @@ class Engine:
         e = torch.empty(B, dtype=self.dtype, device=self.device)
         st = torch.empty(6, B, dtype=self.dtype, device=self.device)
         grad = torch.empty(B, 3 * self.N, dtype=self.dtype, device=self.device) if return_grad else None
-        # option 'refine_defer': the float64 pass of the PREVIOUS call still writes into that call's output tensors on a side
-        # stream until this call has returned -- they are kept alive here whatever the caller did with them (a block handed
-        # back to the caching allocator could otherwise be reused for the tensors above while it is still being written)
-        prev_outputs = getattr(self, '_deferred_outputs', None)
         self._check(self.lib.dqmc_local_energy(self._ctx, r.data_ptr(), self._R(R).data_ptr(), B, e.data_ptr(),
                                                st.data_ptr(), grad.data_ptr() if return_grad else None, None, None))
-        self._deferred_outputs = (e, st, grad) if getattr(self, '_refine_defer', False) else None
-        del prev_outputs
         stats = {k: st[i] for i, k in enumerate(STAT_KEYS)}
         return (e, stats, grad) if return_grad else (e, stats)
 
@@ -335,17 +329,25 @@ class Engine:
         self._check(self.lib.dqmc_refine_info(self._ctx, out))
         return {'mode': int(out[0]), 'score_threshold': out[1], 'error_per_score': out[2], 'direct_f64_calls_left': int(out[3])}
 
+    def refine_counters(self) -> dict:
+        """Running counts of the context (dqmc_refine_counters): local-energy calls, calls evaluated in float64 whole,
+        calibration probes, walkers re-evaluated in float64."""
+        out = (ctypes.c_int64 * 4)()
+        self._check(self.lib.dqmc_refine_counters(self._ctx, out))
+        return {'calls': int(out[0]), 'direct_f64_calls': int(out[1]), 'probe_calls': int(out[2]), 'walkers_refined': int(out[3])}
+
+    def refine_scores(self, n: int) -> np.ndarray:
+        """Error-predictor scores of the first n walkers of the last float32 forward-Laplacian pass (dqmc_refine_scores)."""
+        out = np.empty(int(n), np.float64)
+        self._check(self.lib.dqmc_refine_scores(self._ctx, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(n)))
+        return out
+
     def last_chunks(self) -> dict:
         """Walker chunks the last local-energy call was split into (dqmc_last_chunks): the context's own pass and its
         float64 twin's."""
         out = (ctypes.c_int * 2)()
         self._check(self.lib.dqmc_last_chunks(self._ctx, out))
         return {'own': int(out[0]), 'twin': int(out[1])}
-
-    def refine_finish(self):
-        """Join a float64 pass deferred by the last local-energy call (option 'refine_defer'; dqmc_refine_finish)."""
-        self._check(self.lib.dqmc_refine_finish(self._ctx))
-        self._deferred_outputs = None
 
     def ecp_counts(self) -> dict:
         """(nucleus, electron) pairs of the last mixed-precision ECP quadrature by class (dqmc_ecp_counts)."""
@@ -355,9 +357,6 @@ class Engine:
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
-        if name == 'refine_defer':
-            self._refine_defer = bool(value)
-        self._deferred_outputs = None          # (every option change joins a pending pass first)
 
     def timing(self, enable=True):
         self._check(self.lib.dqmc_timing_enable(self._ctx, int(enable)))

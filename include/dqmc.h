@@ -260,8 +260,11 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * cancellation times the conditioning record of the Slater matrices that carry psi -- exceeds "refine_thresh", or whose
  * E_loc is not finite, are run again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign
  * replaced.  The threshold calibrates itself: on the first and then every "refine_probe"-th call a strided sample of
- * <= 64 further walkers is evaluated in float64 too, the measured float32 error per unit of score (90th percentile)
- * gives refine_thresh = target / c with target = 7e-6 relative; the count includes that sample on probe calls). */
+ * <= "refine_sample" (256) further walkers is evaluated in float64 too, the measured float32 error per unit of score (90th
+ * percentile) gives refine_thresh = target / c with target = "refine_target_e7" x 1e-7 relative.  A batch with more than
+ * "refine_direct_pct" (60 %) of its walkers above the threshold is evaluated in float64 whole, and so are the next 15 calls;
+ * the context returns to the mixed mode only when a float32 pass then finds fewer than "refine_direct_exit_pct" (45 %)
+ * above it -- hysteresis: one calibration draw near a single line used to flip the mode from run to run). */
 int dqmc_last_refined(dqmc_ctx* ctx);
 /* State of the refinement after the last local-energy call: out4 = {mode ("refine": 0 / 1 / 2; 0 in a float64
  * context), current score threshold, measured float32 error per unit of score (0 before the first probe), calls
@@ -272,19 +275,23 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4);
  * whose activations exceed "ws_budget_mb" is split into chunks inside the library (the reference has no such limit to
  * replace: its vmap over the electron batch, loss/energy.py:50-57, simply needs the memory). */
 int dqmc_last_chunks(dqmc_ctx* ctx, int* out2);
-/* Deferred refinement (option "refine_defer" 1, float32 contexts, no ECP): dqmc_local_energy returns with the float32
- * values of the flagged walkers still in place; their float64 pass is enqueued on a stream of the library's own at the
- * start of the NEXT dqmc_local_energy / dqmc_psi_grad call of the context -- behind everything the caller put on the
- * context's stream in between -- runs beside that call's float32 pass, and the context's stream joins it before that call
- * returns.  The output arrays of a call (e_loc, stats, grad, logpsi, sign) must therefore stay alive, and are final in
- * stream order, after the next local-energy call or after dqmc_refine_finish, which enqueues and joins a pending pass
- * at once.  Results are bit-identical to the synchronous path; probe calls and calls that refine most of the batch stay
- * synchronous.  (The reference's loop has no counterpart: XLA schedules its one program per step.) */
-int dqmc_refine_finish(dqmc_ctx* ctx);
+/* Running counts since the context was created: out4 = {dqmc_local_energy / dqmc_psi_grad calls, of them calls evaluated in
+ * float64 whole ("direct" mode or "refine" 2), calibration probe calls, walkers re-evaluated in float64 (sum of
+ * dqmc_last_refined)} -- what a caller needs to say which mode its steps actually ran in (bench.py: config.refine_engaged). */
+int dqmc_refine_counters(dqmc_ctx* ctx, int64_t* out4);
+/* The error-predictor scores (see dqmc_last_refined) of the first n walkers of the context's last float32 forward-Laplacian
+ * pass, copied to the host: together with the threshold of dqmc_refine_info they say which walkers kept their float32
+ * result.  DQMC_E_UNSUPPORTED if the last call ran no such pass (float64 context, "refine" 0 / 2, direct mode). */
+int dqmc_refine_scores(dqmc_ctx* ctx, double* out, int n);
 /* Non-local ECP term of a float32 context (replaces nonloc_potential, ecp/gaussian_type_ecp.py:161-255, for a whole
  * batch): with "refine" 1 the 12-point quadrature of every (walker, ECP nucleus, electron) triple runs in the precision its
  * weight w = max_l (2l+1)|V_l(|r_i - R_a|)| calls for -- float64 psi ratios above "ecp_heavy_e6" (default 10000 = 1e-2 Ha),
- * float32 below, none below "ecp_skip_e12" (default 100 = 1e-10 Ha: the contribution is below that times the mean ratio);
+ * float32 below, none below "ecp_skip_e12" (default 100 = 1e-10 Ha: the contribution is below that times the mean ratio).
+ * The bound is per walker: psi(r) of every walker is evaluated by both value paths first, and where the float32
+ * log|psi(r)| is off by more than "ecp_dlog_floor_e6" (default 100 = 1e-4: an ordinary float32 value of these networks) the
+ * walker's float64 bound tightens in proportion -- near a node psi(r), the denominator of all its ratios, is what float32
+ * cannot resolve; a sign mismatch sends all its kept pairs to float64 (0: weights alone decide).  Without a float64 twin
+ * (DQMC_E_UNSUPPORTED for this program) every kept pair runs in float32.
  * "ecp_mixed" 0 restores whole-walker float64 quadrature for flagged walkers only.  out3 = triples of the last call
  * {float32, float64, dropped}. */
 int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
@@ -300,8 +307,8 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * per value-mode batch of the non-local ECP term; "ws_budget_mb": activation workspace per evaluation
  * (larger batches are split into walker chunks); "lane_compact" (1): 8-lane storage of the edge stream;
  * "attention_mfma", "slogdet_mfma" (1: MFMA kernels where profitable, 2: wherever supported, 0: never);
- * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 32; "fused_chain" (0): second layers
- * of row-wise MLPs in the same wave as the first (measured slower); "fused_wg_per_cu" (4): LDS share a tile is planned for;
+ * "fused_lean" (1): straight-line unit body for layers with one input piece and K <= 32; "fused_wg_per_cu" (4): LDS share a
+ * tile is planned for;
  * "fused_prio" (1): the co-resident tiles of a CU take turns at the highest issue priority, level by level, instead of the
  * hardware's oldest-wave-first order (2: unit by unit, 0: off); "fused_bf" (float32 contexts; 1: the float32 layers of the
  * fused kernel whose pieces are whole octets wide run on the bf16 matrix pipe -- operands split into three bf16 pieces,
@@ -317,20 +324,20 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * replays (callers passing fresh buffers every time) returns to eager launches; 0: always eager;
  * "refine" (float32 contexts; 1: float64 re-evaluation of ill-conditioned walkers, 2: the whole local-energy pass in
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
- * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set), "refine_sample" (64): walkers of
- * the calibration sample (the threshold of a batch at the edge of the whole-batch float64 mode moves with the draw: DESIGN.md,
- * "calibration spread"),
+ * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set), "refine_sample"
+ * (256; 64 until round 4): walkers of the calibration sample, "refine_direct_pct" (60) / "refine_direct_exit_pct" (45): share
+ * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode,
  * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
- * Round 4: "linear_bf", "linear_bkx", "linear_f64_nr1" act on the calling context only (they were process-wide);
- * "linear_bf" 3 = 2 + value-only rows as 64 x 128 tiles on the bf16 pipe with host-split weight planes (measured slower);
+ * "linear_bf", "linear_bkx" act on the calling context only;
  * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per
  * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row
  * block; "attention_ncb" (-1: kernel instance per number of key tiles in float32, four-tile instance in float64);
- * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance, "mlp_dual" (0): two such MLPs
- * on the same input rows in one launch (measured slower); "linear_bkx_big" / "linear_bkx_val" (0): 32-wide K chunks for the
- * 128 x 128 tiles / value-only rows (measured slower / neutral); "ecp_mixed" (1), "ecp_heavy_e6" (10000), "ecp_skip_e12"
- * (100): mixed-precision non-local ECP quadrature (dqmc_ecp_counts); "refine_defer" (0): dqmc_refine_finish;
- * passes of fewer than 64 walkers are never captured into graphs.
+ * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance; "ecp_mixed" (1),
+ * "ecp_heavy_e6" (10000), "ecp_skip_e12" (100), "ecp_dlog_floor_e6" (100): mixed-precision non-local ECP quadrature
+ * (dqmc_ecp_counts); passes of fewer than 64 walkers are never captured into graphs.
+ * Removed in round 5 (each had been measured slower than the default or neutral on the MI355X and was never on; DESIGN.md
+ * section 4 keeps the numbers): "refine_defer" + dqmc_refine_finish, "refine_ahead", "mlp_dual", "fused_chain",
+ * "fused_stagger", "linear_bf" 3 and its host-split weight planes, "linear_bkx_big", "linear_bkx_val", "linear_f64_nr1".
  * Unknown names return DQMC_E_ARG. */
 int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 

@@ -187,45 +187,6 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     np.testing.assert_array_equal(e_l.numpy(), e_plain.numpy())
 
 
-def test_enqueue_ahead_refinement_matches_the_synchronous_path():
-    """The float64 pass enqueued at a capacity before the host knows the flagged count (engine.hip: option refine_ahead)
-    must give exactly what the synchronous path gives: padding slots are not scattered back, an overflow of the capacity
-    is finished by a second pass over the remainder.  (A reduced PauliNet keeps the emulation short.)"""
-    import dataclasses
-    from deepqmc_amd.params import init_params
-    from deepqmc_amd.spec import paulinet
-    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
-    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)
-    params = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
-    B = 24
-    r = torch.as_tensor(synthetic_walkers(h, B, seed=21).astype(np.float32))
-
-    def engine(ahead):
-        e = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-        e.set_option('refine_probe', 0)
-        e.set_option('refine_ahead', ahead)
-        return e
-    plain = engine(0)
-    plain.set_option('refine', 0)
-    e0, st0 = plain.local_energy(r)
-    score = np.sort(((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e0.abs().clamp(min=1.0)).numpy()
-                    * np.maximum(1.0, plain.debug_read('kappa', B)))
-    thr_few, thr_many = int(score[-3]), max(1, int(score[-12]))        # 2 and 11 walkers above (a minority of 24): capacity 8 holds / overflows
-    sync, ahead = engine(0), engine(1)      # (refine_ahead is opt-in)
-    n_few, n_many = int((score > thr_few).sum()), int((score > thr_many).sum())
-    assert 0 < n_few <= 8 < n_many <= B // 2
-    for thr, n_expect in ((thr_few, n_few), (thr_few, n_few), (thr_many, n_many)):      # sync call (sets the capacity), ahead call within capacity, overflow
-        for e in (sync, ahead):
-            e.set_option('refine_thresh', thr)
-        (es, ss, gs), (ea, sa, ga) = sync.local_energy(r, return_grad=True), ahead.local_energy(r, return_grad=True)
-        assert sync.last_refined() == ahead.last_refined() == n_expect
-        np.testing.assert_array_equal(es.numpy(), ea.numpy())
-        np.testing.assert_array_equal(gs.numpy(), ga.numpy())
-        for k in ss:
-            np.testing.assert_array_equal(ss[k].numpy(), sa[k].numpy())
-    assert 0 < (es.numpy() != e0.numpy()).sum() <= sync.last_refined()      # and refined walkers did change
-
-
 @pytest.mark.parametrize('molname,ansatz', [('LiH', 'paulinet'), ('C', 'ferminet')])
 def test_evaluate_spin_matches_the_reference_loop(molname, ansatz):
     """`evaluate_spin` (reference physics.py:159-226): all n_up n_down swapped configurations of a walker batch as ONE
@@ -258,61 +219,6 @@ def test_evaluate_spin_matches_the_reference_loop(molname, ansatz):
     per_walker = op(params, PhysicalConfiguration(torch.as_tensor(h.mol.coords), r, None), torch.tensor([h.n_up, h.n_up + h.n_down - 1, h.n_up]))
     np.testing.assert_allclose(per_walker[0].item(), op(params, r[:1], h.n_up)[0].item(), rtol=1e-12)
     np.testing.assert_allclose(per_walker[1].item(), op(params, r[1:2], h.n_up + h.n_down - 1)[0].item(), rtol=1e-12)
-
-
-def test_deferred_refinement_is_bit_identical_and_final_after_the_next_call():
-    """Option "refine_defer": the float64 pass over the flagged walkers of call k is enqueued at the start of call k + 1 and
-    joined before that call returns (engine.hip).  Three calls on different walkers: every call's outputs equal the
-    synchronous path bit for bit once the following call (or dqmc_refine_finish) has returned; until then the flagged
-    walkers hold their float32 values; a change of options in between joins the pending pass first."""
-    import dataclasses
-    from deepqmc_amd.params import init_params
-    from deepqmc_amd.spec import paulinet
-    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
-    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)
-    params = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
-    B = 24
-    rs = [torch.as_tensor(synthetic_walkers(h, B, seed=21 + k).astype(np.float32)) for k in range(3)]
-
-    def engine(defer):
-        e = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-        e.set_option('refine_probe', 0)
-        e.set_option('refine_defer', defer)
-        return e
-    plain = engine(0)
-    plain.set_option('refine', 0)
-    e0, st0 = plain.local_energy(rs[0])
-    score = np.sort(((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e0.abs().clamp(min=1.0)).numpy()
-                    * np.maximum(1.0, plain.debug_read('kappa', B)))
-    thr = max(1, int(score[-6]))
-    sync, dfr = engine(0), engine(1)
-    for e in (sync, dfr):
-        e.set_option('refine_thresh', thr)
-    ref = [sync.local_energy(r, return_grad=True) for r in rs]
-    n_ref = sync.last_refined()
-    out = []
-    for k, r in enumerate(rs):
-        out.append(dfr.local_energy(r, return_grad=True))
-        if k == 0:
-            changed = int((out[0][0].numpy() != ref[0][0].numpy()).sum())
-            assert 0 < changed <= 8                        # call 0 has returned, its flagged walkers are still float32
-            assert np.array_equal(out[0][0].numpy(), plain.local_energy(rs[0])[0].numpy())
-        if k >= 1:                                         # call k has joined the pass of call k - 1
-            for a, b in zip(out[k - 1][:1] + out[k - 1][2:], ref[k - 1][:1] + ref[k - 1][2:]):
-                np.testing.assert_array_equal(a.numpy(), b.numpy())
-            for key in ref[k - 1][1]:
-                np.testing.assert_array_equal(out[k - 1][1][key].numpy(), ref[k - 1][1][key].numpy())
-    assert dfr.last_refined() == n_ref > 0
-    assert (out[2][0].numpy() != ref[2][0].numpy()).any()
-    dfr.refine_finish()
-    np.testing.assert_array_equal(out[2][0].numpy(), ref[2][0].numpy())
-    np.testing.assert_array_equal(out[2][2].numpy(), ref[2][2].numpy())
-    # an option change joins a pending pass before it takes effect
-    e3 = dfr.local_energy(rs[0], return_grad=True)
-    dfr.set_option('refine_defer', 0)
-    np.testing.assert_array_equal(e3[0].numpy(), ref[0][0].numpy())
-    e4 = dfr.local_energy(rs[1])
-    np.testing.assert_array_equal(e4[0].numpy(), ref[1][0].numpy())
 
 
 def test_engine_is_released_by_reference_count():

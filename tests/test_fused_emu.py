@@ -64,8 +64,8 @@ def test_set_params_repacks_fused_weights():
 
 
 def test_plan_variants_agree():
-    """The lean unit body for small layers (default), the general body (fused_lean 0) and the chained-MLP plan
-    (fused_chain 1) are different instruction sequences for the same arithmetic: identical psi in float64."""
+    """The lean unit body for small layers (default) and the general body (fused_lean 0) are different instruction
+    sequences for the same arithmetic: identical psi in float64."""
     spec = paulinet()
     mol = Molecule.from_name('LiH')
     h = MolecularHamiltonian(mol=mol)
@@ -73,13 +73,12 @@ def test_plan_variants_agree():
     eng = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     rt = torch.as_tensor(make_walkers(mol, h.n_elec, 6))
     s0, l0 = eng.wf_eval(rt)
-    for opt, val in (('fused_lean', 0), ('fused_chain', 1), ('fused_prio', 0), ('fused_prio', 2), ('fused', 2)):
+    for opt, val in (('fused_lean', 0), ('fused_prio', 0), ('fused_prio', 2), ('fused', 2)):
         eng.set_option(opt, val)
         s1, l1 = eng.wf_eval(rt)
         np.testing.assert_array_equal(s1.numpy(), s0.numpy())
         np.testing.assert_allclose(l1.numpy(), l0.numpy(), rtol=1e-13, atol=1e-13)
     eng.set_option('fused_lean', 1)
-    eng.set_option('fused_chain', 0)
     eng.set_option('fused_prio', 1)
     eng.set_option('fused', 1)
     # "fused" = 1 picks the LDS-resident kernel only where it is the faster value path: not for larger systems at large batch

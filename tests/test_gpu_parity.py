@@ -326,35 +326,3 @@ def test_attention_mfma_vs_scalar_f32(spec_fn, molname):
                                          'logpsi_max_abs_diff': float(np.abs(res[2][1] - res[0][1]).max())})
 
 
-def test_deferred_refinement_bit_identical_on_device():
-    """Option "refine_defer" on the MI355X: the float64 pass of call k runs on a side stream beside the float32 pass of call
-    k + 1, with Metropolis sub-steps (in-place walker updates) in between.  Five VMC-like steps on 4096 LiH walkers from two
-    contexts with the same weights and the same sampler noise: every step's energies, statistics and gradient bit-identical
-    to the synchronous path once the following call has returned."""
-    spec, mol, h, tree, _, _ = setup(paulinet, 'LiH', torch.float32)
-    B = 4096
-    engs = []
-    for defer in (0, 1):
-        e = Engine(spec, h, tree, dtype=torch.float32, device=DEV, norm_eps=geom.F32_EPS)
-        e.set_option('refine_defer', defer)
-        engs.append(e)
-    r0 = torch.as_tensor(synthetic_walkers(h, B, seed=9), dtype=torch.float32, device=DEV)
-    states = []
-    for e in engs:
-        sg, lg = e.wf_eval(r0)
-        states.append({'r': r0.clone(), 'log': lg.clone(), 'sign': sg.clone(), 'age': torch.zeros(B, dtype=torch.int32, device=DEV),
-                       'tau': torch.full((1,), 0.3, dtype=torch.float32, device=DEV)})
-    outs = [[], []]
-    for step in range(5):
-        for k, e in enumerate(engs):
-            e.mcmc_steps(states[k], 10, seed=100 + step)                   # in place: the walkers move under the pending pass
-            outs[k].append(e.local_energy(states[k]['r'], return_grad=True))
-        assert torch.equal(states[0]['r'], states[1]['r'])
-        if step >= 1:
-            (es, ss, gs), (ed, sd, gd) = outs[0][step - 1], outs[1][step - 1]
-            assert torch.equal(es, ed) and torch.equal(gs, gd)
-            for key in ss:
-                assert torch.equal(ss[key], sd[key]), key
-    assert engs[0].last_refined() == engs[1].last_refined() > 0
-    engs[1].refine_finish()
-    assert torch.equal(outs[0][-1][0], outs[1][-1][0]) and torch.equal(outs[0][-1][2], outs[1][-1][2])

@@ -163,10 +163,6 @@ def test_attention_mfma_f64_two_row_blocks(ansatz):
     sign, logpsi = eng.wf_eval(torch.as_tensor(r))
     np.testing.assert_array_equal(sign.numpy(), val['sign'])
     np.testing.assert_allclose(logpsi.numpy(), val['log'], rtol=1e-11, atol=1e-11)
-    eng.set_option('linear_bkx_val', 1)          # value rows with 32-wide K chunks (K = 64 here): the same products in the same order
-    sign2, logpsi2 = eng.wf_eval(torch.as_tensor(r))
-    np.testing.assert_array_equal(sign2.numpy(), sign.numpy())
-    np.testing.assert_array_equal(logpsi2.numpy(), logpsi.numpy())
 
 
 def test_attention_mfma_split_three_row_blocks():
