@@ -365,7 +365,7 @@ def main():
         state, pc, _ = ms_sampler.sample(step * world + rank, state, params_s)
         r = pc.r[None]
         E, _ = loss.compute_local_energy(step, hamil, wf, params_s, r)
-        ratio = loss.compute_psi_ratio(wf, params_s, r)
+        ratio, _ = loss.compute_psi_ratio(wf, params_s, r)
         pen, info = loss.compute_mean_overlap(ratio, ones)
         stats = reduce_stats(eng, E[0, 0].contiguous())
         stats['overlap/penalty'] = float(pen)

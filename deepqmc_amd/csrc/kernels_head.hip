@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256, 2) k_slogdet_mfma(const real* __restrict_
           }
         load_frags(fb, it + 2);                             // this register set is free again: two lanes ahead
       }
-    } else if (wave == 3 && it >= 2) {
+    } else if (wave == 3 && it >= 2 && it <= T) {          // (T odd: the last pair of steps reaches it = T + 1, which has no lane to reduce)
       const int t = it - 1;                                 // 1 <= t < T
       const double* Mi = Mbuf[t & 1];
       const bool need2 = t < T - 1;

@@ -94,6 +94,9 @@ class Engine:
     # ------------------------------------------------------------------
     def _check(self, rc: int):
         if rc != 0:
+            if getattr(self, '_ctx', None) is None:
+                raise DqmcError('engine closed: its HIP context was destroyed (Engine.close / NeuralNetworkWaveFunction.release); '
+                                'obtain a new one with NeuralNetworkWaveFunction.engine(params)')
             raise DqmcError(f'dqmc error {rc}: {self.lib.dqmc_last_error().decode()}')
 
     def close(self):

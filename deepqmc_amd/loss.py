@@ -63,7 +63,8 @@ def compute_local_energy(rng, hamil, ansatz, params: Sequence, phys_conf_r: torc
 
 def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
     """loss/overlap.py:77-99 + :40-75: R[m, i, j, b] = psi_i(r_b ~ psi_j^2) / psi_j(r_b ~ psi_j^2),
-    computed from log-shifted values (shift = mean log|psi| of each state i over all samples)."""
+    computed from log-shifted values (shift = mean log|psi| of each state i over all samples).  Returns the reference's
+    tuple `(psi_ratio, stats)`; `stats` is the (empty) dict of compute_wave_function_values, overlap.py:19-50."""
     r, Rs = _unpack(phys_conf_r)
     M, S, B = r.shape[0], r.shape[1], r.shape[2]
     out = []
@@ -81,7 +82,7 @@ def compute_psi_ratio(ansatz, params: Sequence, phys_conf_r: torch.Tensor):
         log_ratio = shifted - diag[None]
         sdiag = torch.diagonal(sign, dim1=0, dim2=1).permute(1, 0)
         out.append(sign * sdiag[None] * torch.exp(log_ratio))
-    return torch.stack(out)
+    return torch.stack(out), {}
 
 
 def symmetrize_overlap_with_clipped_geometric_mean(x: torch.Tensor) -> torch.Tensor:

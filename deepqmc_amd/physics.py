@@ -62,7 +62,7 @@ def make_stochastic_spin_raising_operator(hamil, ansatz):
 
     def evaluate(params, phys_conf, down_idx):
         dev = ansatz.engine(params, getattr(phys_conf, 'R', None)).device
-        r = phys_conf.r if isinstance(phys_conf, PhysicalConfiguration) else phys_conf
+        r = torch.as_tensor(phys_conf.r if isinstance(phys_conf, PhysicalConfiguration) else phys_conf)      # (NumPy input too)
         down_idx = torch.as_tensor(down_idx, device=dev)
         if down_idx.dim() == 0:
             up = torch.arange(n_up, device=dev)
@@ -70,7 +70,14 @@ def make_stochastic_spin_raising_operator(hamil, ansatz):
         out = torch.empty(r.shape[0], dtype=torch.float64, device=dev)               # per-walker indices: group equal ones
         for d in torch.unique(down_idx).tolist():
             sel = (down_idx == d).nonzero().flatten()
-            sub = PhysicalConfiguration(phys_conf.R, r[sel], None) if isinstance(phys_conf, PhysicalConfiguration) else r[sel]
+            rs = r[sel.to(r.device)]
+            if isinstance(phys_conf, PhysicalConfiguration):
+                Rb = phys_conf.R
+                if Rb is not None and torch.as_tensor(Rb).dim() == 3:        # a geometry per walker: the selected walkers' own
+                    Rb = torch.as_tensor(Rb)[sel.to(torch.as_tensor(Rb).device)]
+                sub = PhysicalConfiguration(Rb, rs, None)
+            else:
+                sub = rs
             out[sel] = evaluate(params, sub, d)
         return out
 

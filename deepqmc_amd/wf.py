@@ -69,14 +69,11 @@ class NeuralNetworkWaveFunction:
             eng.set_params(params)
         else:
             if len(self._engines) >= self.max_engines:
-                # closed when nothing but this frame still refers to it (workspace, float64 twin and captured graphs go
-                # back to the device now, not when the garbage collector gets to a cycle); a caller that still holds the
-                # Engine keeps a working context, released with its last reference
-                import sys
-                _, _, old = self._engines.pop(0)
-                if sys.getrefcount(old) <= 2:
-                    old.close()
-                del old
+                # the evicted context leaves the cache; its device memory (workspace, float64 twin, captured graphs) goes back
+                # when its LAST reference goes -- now, if the cache held the only one (Engine keeps no reference cycle:
+                # tests/test_facade_emu.py::test_engine_is_released_by_reference_count), otherwise when the caller that
+                # still holds it drops it.  Nothing is closed under a caller's feet.
+                self._engines.pop(0)
                 self._evictions += 1
                 if self._evictions == 4 * self.max_engines:
                     import warnings
@@ -90,7 +87,8 @@ class NeuralNetworkWaveFunction:
         return eng
 
     def release(self):
-        """Close every cached HIP context (device workspaces, twins, captured graphs) now."""
+        """Close every cached HIP context (device workspaces, twins, captured graphs) NOW, whoever still refers to them:
+        an `Engine` obtained from `engine()` before this call raises a clear "engine closed" error afterwards."""
         while self._engines:
             self._engines.pop()[2].close()
 
@@ -102,11 +100,28 @@ class NeuralNetworkWaveFunction:
 
     def apply(self, params, phys_conf, return_mos: bool = False) -> Psi:
         """types.py:135-150 (batched)."""
-        if return_mos:
-            raise NotImplementedError('return_mos is a pretraining hook, outside the hot path')
         r = phys_conf.r if isinstance(phys_conf, PhysicalConfiguration) else phys_conf
         R = phys_conf.R if isinstance(phys_conf, PhysicalConfiguration) else None
-        sign, log = self.engine(params, R).wf_eval(r, R)
+        eng = self.engine(params, R)
+        if return_mos:
+            # wf/nn_wave_function.py:127,144-145: the (backflow-transformed) molecular orbitals the determinants are taken of,
+            # `(orb_up, orb_down)` -- the pretraining hook.  They are the Slater-matrix buffer of the value path: read back
+            # through the debug interface (a host copy: this is not a hot path) as [B, K, n_up | n_down, n_orb].
+            if not self.spec.full_determinant:
+                raise NotImplementedError('return_mos (wf/nn_wave_function.py:144): only full-determinant programs expose '
+                                          'their orbital matrices; spin-factorised ones store block-diagonal matrices')
+            import numpy as np
+            eng.set_option('fused', 0)              # every activation buffer stays readable (include/dqmc.h: "fused")
+            try:
+                eng.wf_eval(r, R)
+                B = torch.as_tensor(r).shape[0]
+                N, K = self.hamil.n_elec, self.spec.n_determinants
+                A = eng.debug_read('orbitals', B)[:, :, 0, :N * N].reshape(B, K, N, N)     # rows = electrons, columns = orbitals
+            finally:
+                eng.set_option('fused', 1)
+            A = torch.as_tensor(np.ascontiguousarray(A), dtype=self.dtype, device=self.device)
+            return A[:, :, :self.hamil.n_up], A[:, :, self.hamil.n_up:]
+        sign, log = eng.wf_eval(r, R)
         return Psi(sign, log)
 
     __call__ = apply

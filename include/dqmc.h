@@ -326,7 +326,8 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * float64 while sampling stays float32, 0: off), "refine_thresh" (200 until the first probe): score above which mode 1
  * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set), "refine_sample"
  * (256; 64 until round 4): walkers of the calibration sample, "refine_direct_pct" (60) / "refine_direct_exit_pct" (45): share
- * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode,
+ * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode, "refine_direct_calls" (15): calls it
+ * stays there before a float32 pass looks again,
  * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
  * "linear_bf", "linear_bkx" act on the calling context only;
  * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per

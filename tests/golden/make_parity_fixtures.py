@@ -49,6 +49,9 @@ CONFIGS = {
     'benzene_psiformer_256': ('benzene', 'psiformer', 256, 200, 8, 2, False),
     'c4h4_transpsiformer_512': ('cyclobutadiene_square', 'transpsiformer', 512, 200, 16, 4, False),
     'benzene_ecp_psiformer_32': ('benzene', 'psiformer', 32, 200, 2, 2, True),
+    # round 5: a SECOND synthetic table at the BASELINE-shaped batch -- what the ECP cut-offs of the library (tuned on the
+    # 32 walkers above) have never seen: exponents x 4 and / 4, a d channel
+    'benzene_ecpB_psiformer_256': ('benzene', 'psiformer', 256, 200, 2, 2, 'B'),
 }
 LEGACY = ('lih_paulinet_4096', 'n2_ferminet_512', 'benzene_psiformer_8', 'c4h4_transpsiformer_64', 'lih_paulinet_raw_1024',
           'lih_psiformer_256')      # round-2 fixtures: one block, the original random streams
@@ -58,6 +61,17 @@ def ecp_table(z: int):
     """The synthetic table of bench.py --ecp (pyscf ECP format: [n_core, [[l, [r^-2.., r^-1, r^0, r^1 terms]] ...]])."""
     return [2 if z > 2 else 0, [[-1, [[], [[5.4, float(z - 2)]], [[4.6, -4.6]], [[2.7, 5.4]]]],
                                 [0, [[], [], [[1.33, 6.75]]]], [1, [[], [], [[1.25, 0.45]]]]]]
+
+
+def ecp_table_b(z: int):
+    """Set B (round 5; the library's ECP thresholds were chosen on set A): the local exponents x 4 / : 4 / x 4, a broad s
+    channel (exponent : 4: its non-local weight reaches across the whole ring, so almost no (nucleus, electron) pair falls
+    below the drop threshold), a tight p channel (x 4) and an l = 2 channel that set A does not have."""
+    return [2 if z > 2 else 0, [[-1, [[], [[21.6, float(z - 2)]], [[1.15, -4.6]], [[10.8, 5.4]]]],
+                                [0, [[], [], [[0.3325, 6.75]]]], [1, [[], [], [[5.0, 0.45]]]], [2, [[], [], [[0.8, 0.9]]]]]]
+
+
+ECP_TABLES = {True: ecp_table, 'A': ecp_table, 'B': ecp_table_b}
 
 
 def setup(molname, ansatz, ecp=False):
@@ -72,7 +86,7 @@ def setup(molname, ansatz, ecp=False):
     if ecp:
         from deepqmc_amd.ecp import ELEMENTS
         h = MolecularHamiltonian(mol=mol, ecp_type='synthetic',
-                                 ecp_tables={ELEMENTS[int(z)]: ecp_table(int(z)) for z in set(mol.charges) if z > 2})
+                                 ecp_tables={ELEMENTS[int(z)]: ECP_TABLES[ecp](int(z)) for z in set(mol.charges) if z > 2})
     else:
         h = MolecularHamiltonian(mol=mol)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=PARAM_SEED, perturb_envelopes=PERTURB)
@@ -170,7 +184,7 @@ def assemble(name, results):
     elif fix['grad'].size > 2_000_000:
         fix['grad'] = fix['grad'][::8]
     meta = {'molecule': molname, 'ansatz': ansatz, 'walkers': B, 'equilibration_sub_steps': n_eq,
-            'param_seed': PARAM_SEED, 'perturb_envelopes': PERTURB, 'norm_eps': geom.F32_EPS, 'ecp': bool(ecp),
+            'param_seed': PARAM_SEED, 'perturb_envelopes': PERTURB, 'norm_eps': geom.F32_EPS, 'ecp': bool(ecp), 'ecp_table': ('B' if ecp == 'B' else 'A') if ecp else None,
             'blocks': len(results), 'acceptance_last': float(np.mean([x['acc_last'] for x in results])) if n_eq else None,
             'cpu_seconds': round(sum(x['seconds'] for x in results), 1),
             'cpu_seconds_equilibration': round(sum(x['seconds_equilibration'] for x in results), 1)}

@@ -12,7 +12,9 @@ flock 9
 FLAGS="-x c++ -std=c++17 -O1 -fPIC -w -I$HERE -I$SRC -I$HERE/../../include"
 pids=""
 for f in engine kernel_linear kernel_fused2 kernel_attention kernel_attention_mfma kernels_graph kernels_head kernels_mcmc kernels_ecp; do
-  if [ ! -f "$OUT/$f.o" ] || [ "$SRC/$f.hip" -nt "$OUT/$f.o" ] || [ "$SRC/common.h" -nt "$OUT/$f.o" ] || \
+  stale_inl=0
+  if [ "$f" = engine ]; then for i in "$SRC"/engine_*.inl; do [ "$i" -nt "$OUT/$f.o" ] && stale_inl=1; done; fi
+  if [ ! -f "$OUT/$f.o" ] || [ $stale_inl = 1 ] || [ "$SRC/$f.hip" -nt "$OUT/$f.o" ] || [ "$SRC/common.h" -nt "$OUT/$f.o" ] || \
      [ "$SRC/kernels.h" -nt "$OUT/$f.o" ] || [ "$HERE/hip/hip_runtime.h" -nt "$OUT/$f.o" ] || \
      [ "$HERE/../../include/dqmc.h" -nt "$OUT/$f.o" ]; then
     g++ $FLAGS -c "$SRC/$f.hip" -o "$OUT/$f.o" &

@@ -187,6 +187,68 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     np.testing.assert_array_equal(e_l.numpy(), e_plain.numpy())
 
 
+def test_direct_mode_hysteresis_counters_and_scores():
+    """The whole-batch float64 ("direct") mode of the refinement (engine.hip: mostly_flagged): a context enters it when more
+    than "refine_direct_pct" (60 %) of a batch lies above the score threshold and leaves it only when a later float32 pass
+    finds fewer than "refine_direct_exit_pct" (45 %) above it -- a flagged share between the two lines keeps whatever mode
+    the context is in.  Also: dqmc_refine_scores returns the scores the decision was taken on, dqmc_refine_counters what ran.
+    (A reduced PauliNet keeps the emulation short; thresholds are set by hand, the probe is off.)"""
+    import dataclasses
+    from deepqmc_amd.params import init_params
+    from deepqmc_amd.spec import paulinet
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)
+    params = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    B = 20
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=21).astype(np.float32))
+    eng = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    eng.set_option('refine_probe', 0)
+    eng.set_option('refine_direct_calls', 1)
+    eng.set_option('refine_thresh', 10 ** 9)
+    e_plain, st0 = eng.local_energy(r)
+    score = eng.refine_scores(B)
+    expect = ((st0['hamil/lap'].abs() + st0['hamil/quantum_force']) / e_plain.abs().clamp(min=1.0)).numpy() * np.maximum(1.0, eng.debug_read('kappa', B))
+    np.testing.assert_allclose(score, expect, rtol=1e-5)
+    def above(t):
+        return int((score > t).sum())
+
+    def thr_for(n_above):        # an integer threshold (dqmc_set_option takes integers) with exactly n_above scores above it
+        for t in range(1, int(score.max()) + 1):
+            if above(t) == n_above:
+                return t
+        raise AssertionError(f'no integer threshold leaves {n_above} scores above it: {np.sort(score)}')
+    t_mid, t_hi, t_lo = thr_for(10), thr_for(15), thr_for(8)      # 50 % / 75 % / 40 % of 20 walkers (lines: enter 60 %, exit 45 %)
+    c0 = eng.refine_counters()
+    # 50 % above, coming from the mixed mode: stays mixed
+    eng.set_option('refine_thresh', t_mid)
+    eng.local_energy(r)
+    assert eng.last_refined() == 10 and eng.refine_info()['direct_f64_calls_left'] == 0
+    # 75 %: enters the direct mode (this call evaluates the whole batch in float64, and so does the next one)
+    eng.set_option('refine_thresh', t_hi)
+    e_dir, _ = eng.local_energy(r)
+    assert eng.last_refined() == B and eng.refine_info()['direct_f64_calls_left'] == 1
+    eng.set_option('refine_thresh', t_mid)
+    eng.local_energy(r)                                  # the direct call
+    assert eng.last_refined() == B and eng.refine_info()['direct_f64_calls_left'] == 0
+    with pytest.raises(Exception):
+        eng.refine_scores(B)                             # no float32 pass ran: no scores
+    # 50 % again, but coming FROM the direct mode: above the exit line, so the context stays there
+    e_again, _ = eng.local_energy(r)
+    assert eng.last_refined() == B and eng.refine_info()['direct_f64_calls_left'] == 1
+    np.testing.assert_array_equal(e_again.numpy(), e_dir.numpy())
+    eng.local_energy(r)                                  # (direct)
+    # 40 %: below the exit line -> back to the mixed mode
+    eng.set_option('refine_thresh', t_lo)
+    e_mix, _ = eng.local_energy(r)
+    assert eng.last_refined() == 8 and eng.refine_info()['direct_f64_calls_left'] == 0
+    keep = score <= t_lo
+    np.testing.assert_array_equal(e_mix.numpy()[keep], e_plain.numpy()[keep])
+    np.testing.assert_array_equal(e_mix.numpy()[~keep], e_dir.numpy()[~keep])
+    c1 = eng.refine_counters()
+    assert c1['calls'] - c0['calls'] == 6 and c1['direct_f64_calls'] - c0['direct_f64_calls'] == 4 and c1['probe_calls'] == 0
+    assert c1['walkers_refined'] - c0['walkers_refined'] == 10 + 4 * B + 8
+
+
 @pytest.mark.parametrize('molname,ansatz', [('LiH', 'paulinet'), ('C', 'ferminet')])
 def test_evaluate_spin_matches_the_reference_loop(molname, ansatz):
     """`evaluate_spin` (reference physics.py:159-226): all n_up n_down swapped configurations of a walker batch as ONE
@@ -239,3 +301,61 @@ def test_engine_is_released_by_reference_count():
         assert ref() is None
     finally:
         gc.enable()
+
+
+def test_return_mos_released_engines_and_numpy_spin_input():
+    """Boundary details of the reference surface:
+      * `ansatz.apply(..., return_mos=True)` (wf/nn_wave_function.py:127,144-145) returns the orbital matrices the determinants
+        are taken of, `(orb_up, orb_down)`: their stacked slogdet reproduces log|psi| of a one-determinant, cusp-less
+        ansatz, and for K determinants the CI sum of the value path;
+      * an engine whose context was released raises a clear "engine closed" error instead of the library's "null argument";
+      * an evicted engine that nobody holds is freed by reference count (no getrefcount heuristics), one that a caller
+        holds keeps working;
+      * the per-walker branch of the stochastic spin-raising operator accepts NumPy walkers and a geometry per walker."""
+    import weakref
+    from deepqmc_amd.physics import make_stochastic_spin_raising_operator
+    h, wf = make()
+    params = wf.init(3, perturb_envelopes=0.1)
+    B = 3
+    r = torch.as_tensor(synthetic_walkers(h, B, seed=4))
+    psi = wf.apply(params, r)
+    up, dn = wf.apply(params, r, return_mos=True)
+    K, N = wf.spec.n_determinants, h.n_elec
+    assert up.shape == (B, K, h.n_up, N) and dn.shape == (B, K, h.n_down, N)
+    sgn, logdet = torch.linalg.slogdet(torch.cat([up, dn], dim=2))                 # [B, K]
+    eng = wf.engine(params)
+    np.testing.assert_allclose(logdet.numpy(), eng.debug_read('logdet', B)[:, :, 0], rtol=1e-10, atol=1e-10)
+    np.testing.assert_array_equal(sgn.numpy().astype(np.int32), eng.debug_read('sign_k', B))
+    assert torch.equal(wf.apply(params, r).log, psi.log)                           # the value path is back on its default kernels
+    # closed engines say so
+    held = wf.engine(params)
+    wf.release()
+    with pytest.raises(DqmcError, match='engine closed'):
+        held.wf_eval(r)
+    # eviction: freed by reference count when nobody holds the engine, alive while somebody does
+    wf.max_engines = 1
+    t1, t2, t3 = (wf.init(s, perturb_envelopes=0.1) for s in (1, 2, 3))
+    wf._geometry_key = lambda R: None if R is None else np.asarray(R, np.float64).tobytes()      # (one context per (tree, geometry))
+    g = [h.mol.coords, h.mol.coords * 1.1, h.mol.coords * 1.2]
+    gc.collect(); gc.disable()
+    try:
+        w1 = weakref.ref(wf.engine(t1, g[0]))
+        keep = wf.engine(t2, g[1])                         # evicts the first: nobody holds it -> gone now
+        assert w1() is None
+        wf.engine(t3, g[2])                                # evicts `keep` from the cache; the caller still holds it
+        assert keep._ctx is not None
+        keep.wf_eval(r, torch.as_tensor(g[1]))
+    finally:
+        gc.enable()
+    # spin-raising operator: NumPy walkers, a geometry per walker, per-walker electron indices
+    h2, wf2 = make()
+    p2 = wf2.init(2, perturb_envelopes=0.1)
+    op = make_stochastic_spin_raising_operator(h2, wf2)
+    r_np = synthetic_walkers(h2, B, seed=6)
+    idx = torch.tensor([h2.n_up, h2.n_up + h2.n_down - 1, h2.n_up])
+    R_b = np.broadcast_to(h2.mol.coords, (B, h2.n_nuc, 3)).copy()
+    a = op(p2, r_np, idx)
+    b = op(p2, PhysicalConfiguration(torch.as_tensor(R_b), torch.as_tensor(r_np), None), idx)
+    c = torch.stack([op(p2, torch.as_tensor(r_np[k:k + 1]), int(idx[k]))[0] for k in range(B)])
+    np.testing.assert_allclose(a.numpy(), c.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(b.numpy(), c.numpy(), rtol=1e-12)

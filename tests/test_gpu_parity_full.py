@@ -73,9 +73,10 @@ def load(name):
     if meta.get('ecp'):
         from deepqmc_amd.ecp import ELEMENTS
         sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
-        from make_parity_fixtures import ecp_table
+        from make_parity_fixtures import ECP_TABLES
+        table = ECP_TABLES[meta.get('ecp_table') or 'A']
         h = MolecularHamiltonian(mol=mol, ecp_type='synthetic',
-                                 ecp_tables={ELEMENTS[int(z)]: ecp_table(int(z)) for z in set(mol.charges) if z > 2})
+                                 ecp_tables={ELEMENTS[int(z)]: table(int(z)) for z in set(mol.charges) if z > 2})
     else:
         h = MolecularHamiltonian(mol=mol)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=meta['param_seed'], perturb_envelopes=meta['perturb_envelopes'])
@@ -279,7 +280,8 @@ def test_three_states_c4h4_local_energy_psi_ratio_overlap(dtype):
     # --- psi ratios: three states x 170 walkers each ---
     Bp = 170 if dtype == 'f32' else 48
     r_p = torch.as_tensor(r_all[:S * Bp].reshape(1, S, Bp, h.n_elec, 3), dtype=tdt, device=DEV)
-    ratio = loss.compute_psi_ratio(wf, params, pc(r_p))
+    ratio, ov_stats = loss.compute_psi_ratio(wf, params, pc(r_p))
+    assert ov_stats == {}                                                           # (overlap.py:50: the reference returns an empty Stats)
     assert ratio.shape == (1, S, S, Bp)
     ref, sym, pen_ref = _three_state_reference(fx, S, Bp)
     got = ratio[0].cpu().numpy()
@@ -309,3 +311,143 @@ def test_three_states_c4h4_local_energy_psi_ratio_overlap(dtype):
     assert np.median(rr) < 5e-4 and np.quantile(rr, 0.99) < 3e-2, (np.median(rr), np.quantile(rr, 0.99))
     assert ov_rel < 2e-3, ov_rel
     np.testing.assert_allclose(float(pen), pen_ref, rtol=3e-3)
+
+
+# ---- round 5: parity in the regime, and along the trajectory, that bench.py actually runs -------------------------------
+
+def _kept_f32_profile(eng, e, ref, B):
+    """Error distribution of the walkers that KEPT their float32 result in the last call (score <= threshold)."""
+    score = eng.refine_scores(B)
+    thr = eng.refine_info()['score_threshold']
+    kept = score <= thr
+    rel = np.abs(e - ref) / np.maximum(1.0, np.abs(ref))
+    out = {'n_kept_f32': int(kept.sum()), 'n_refined': int((~kept).sum()), 'score_threshold': thr}
+    if kept.any():
+        out.update({'kept_p50': float(np.median(rel[kept])), 'kept_p99': float(np.quantile(rel[kept], 0.99)), 'kept_max': float(rel[kept].max())})
+    if (~kept).any():
+        out['refined_max'] = float(rel[~kept].max())
+    return rel, kept, out
+
+
+@pytest.mark.parametrize('chunked', [False, True])
+def test_benzene_mixed_regime_256(chunked):
+    """BASELINE configs[3] on the machine: bench.py runs benzene / Psiformer with a THIRD to a HALF of the walkers refined in
+    float64 and the rest left in float32 (the library's mixed mode) -- the regime the 256-walker fixture never exercised
+    while a majority above the threshold sent the whole batch to float64.  Library defaults (calibration sample 256 =
+    this whole batch, mode switch at 60 % with hysteresis): the batch must stay in the MIXED mode, on the calibrating first
+    call and on the calibrated second one; every walker within 1e-5 of the oracle; the error distribution of the walkers
+    that kept their float32 value goes to the report.  `chunked`: the same under a workspace budget that splits the float32
+    pass AND the twin's pass into >= 4 chunks each (what the 2048-walker BASELINE batch does), bit-equal to unchunked."""
+    d, meta, h, eng = load('benzene_psiformer_256')
+    r = torch.as_tensor(d['r'], device=DEV)
+    B = r.shape[0]
+    if chunked:
+        e_un, st_un = eng.local_energy(r)            # unchunked reference of the calibrating call ...
+        e_un2, _ = eng.local_energy(r)               # ... and of the steady state
+        d, meta, h, eng = load('benzene_psiformer_256')
+        for name in ('ws_budget_mb', 'twin.ws_budget_mb'):
+            eng.set_option(name, 10 * 1024)
+    out = {}
+    for key in ('first_call', 'second_call'):
+        e, _ = eng.local_energy(r)
+        info, chunks = eng.refine_info(), eng.last_chunks()
+        rel, kept, prof = _kept_f32_profile(eng, e.double().cpu().numpy(), d['e_loc'], B)
+        prof.update({'frac_within_1e-5': float((rel < 1e-5).mean()), 'max': float(rel.max()), 'last_refined': eng.last_refined(),
+                     'direct_f64_calls_left': info['direct_f64_calls_left'], 'chunks': chunks})
+        out[key] = prof
+        if chunked:
+            assert torch.equal(e, e_un if key == 'first_call' else e_un2), key
+            assert chunks['own'] >= 4 and chunks['twin'] >= 4, chunks
+    out['counters'] = eng.refine_counters()
+    report('benzene_mixed_regime_256' + ('_chunked' if chunked else ''), out)
+    for key in ('first_call', 'second_call'):
+        p = out[key]
+        assert p['direct_f64_calls_left'] == 0, (key, p)                       # the mixed mode, not whole-batch float64
+        assert 0.15 * B <= p['n_refined'] <= 0.60 * B, (key, p)                # (what bench.py reports for this system: 28-40 %)
+        assert p['frac_within_1e-5'] == 1.0 and p['max'] < 1e-5, (key, p)      # the north-star tolerance, every walker
+    assert out['counters']['direct_f64_calls'] == 0
+
+
+@pytest.mark.parametrize('molname,ansatz,n_sub', [('LiH', 'paulinet', 30), ('N2', 'ferminet', 10)])
+def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
+    """Parity ALONG THE TRAJECTORY bench.py runs (BASELINE configs[1] / [2]: 4096 walkers, bench's parameters, 400 burn-in
+    sub-steps), not on one frozen ensemble: 20 VMC steps; at every step the local energies the library returns at its
+    DEFAULTS (self-calibrated refinement, captured passes) against the float64 pass of a second context ("refine" 2: oracle-
+    checked to 2e-7 by the fixtures) on the same walkers.  >= 80 k evaluations per system; asserted: EVERY one within 1e-5
+    (reference semantics: loss/energy.py:50-57 -- the reference evaluates every walker in one precision).  The tail goes to
+    the report, and so does what two tighter targets ("refine_target_e7" 50 / 35) would buy and cost on the same walkers."""
+    from deepqmc_amd import MolecularHamiltonian as MH, Molecule as Mol
+    from deepqmc_amd.sampling import DecorrSampler
+    from deepqmc_amd.wf import NeuralNetworkWaveFunction
+    B, steps = 4096, 20
+    h = MH(mol=Mol.from_name(molname))
+    wf = NeuralNetworkWaveFunction(h, ansatz, dtype=torch.float32, device=DEV)
+    params = wf.init(0, perturb_envelopes=0.05)
+    eng = wf.engine(params)
+    ref = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
+    ref.set_option('refine', 2)
+    alt = {}
+    for t7 in (50, 35):
+        alt[t7] = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
+        alt[t7].set_option('refine_target_e7', t7)
+    smp = DecorrSampler(h, wf, length=n_sub, in_place=True)
+    st = smp.init(1000, params, B)
+    burn = DecorrSampler(h, wf, length=50)
+    for k in range(8):
+        st = burn.sample(900_000 + k, st, params)[0]
+    rels, n_ref, alt_rel, alt_ref = [], [], {t: [] for t in alt}, {t: [] for t in alt}
+    for s in range(steps):
+        st, pc, _ = smp.sample(s, st, params)
+        e, _ = eng.local_energy(st['r'])
+        n_ref.append(eng.last_refined())
+        e64 = ref.local_energy(st['r'])[0].double().cpu().numpy()
+        rels.append(np.abs(e.double().cpu().numpy() - e64) / np.maximum(1.0, np.abs(e64)))
+        for t7, a in alt.items():
+            ea = a.local_energy(st['r'])[0].double().cpu().numpy()
+            alt_rel[t7].append(np.abs(ea - e64) / np.maximum(1.0, np.abs(e64)))
+            alt_ref[t7].append(a.last_refined())
+    rel = np.concatenate(rels)
+    tail = lambda x: {'frac_within_1e-5': float((x < 1e-5).mean()), 'n_above_1e-5': int((x >= 1e-5).sum()), 'n_above_5e-6': int((x >= 5e-6).sum()),
+                      'p99': float(np.quantile(x, 0.99)), 'p99.9': float(np.quantile(x, 0.999)), 'max': float(x.max())}
+    payload = {'evaluations': int(rel.size), 'steps': steps, 'default': {**tail(rel), 'refined_per_step_mean': float(np.mean(n_ref[1:])),
+                                                                        'refined_fraction': float(np.mean(n_ref[1:])) / B},
+               'refine_info': eng.refine_info(), 'counters': eng.refine_counters(),
+               'max_per_step': [float(x.max()) for x in rels]}
+    for t7 in alt:
+        x = np.concatenate(alt_rel[t7])
+        payload[f'target_{t7}e-7'] = {**tail(x), 'refined_fraction': float(np.mean(alt_ref[t7][1:])) / B}
+    report(f'trajectory_{molname}_{ansatz}_{B}', payload)
+    assert rel.size >= 80_000
+    assert payload['default']['frac_within_1e-5'] == 1.0, payload['default']
+
+
+def test_ecp_thresholds_hold_on_a_second_table_256():
+    """The cut-offs of the mixed-precision ECP quadrature ("ecp_skip_e12", "ecp_heavy_e6": chosen in round 4 on the 32 walkers
+    of set A, profiles/r04_ecp_mixed_precision_sweep.json) on what they were NOT tuned on: a second synthetic table (local
+    exponents x 4 / : 4, a broad s channel whose weight reaches across the ring, a tight p channel, an l = 2 channel A does
+    not have) at 256 |psi|^2-equilibrated benzene walkers, oracle values from tests/golden/make_parity_fixtures.py
+    (oracle/ecp.py <- ecp/gaussian_type_ecp.py:161-255; the reference has ONE precision and no cut-off, :239-244).
+    Library defaults.  Asserted: every walker's E_loc within 1e-5 relative, first and second call; V_nl within 1e-5 |E|;
+    the share of pairs per class and the V_nl error go to the report."""
+    d, meta, h, eng = load('benzene_ecpB_psiformer_256')
+    assert meta['ecp_table'] == 'B'
+    r = torch.as_tensor(d['r'], device=DEV)
+    phi = torch.as_tensor(d['ecp_phi'], dtype=torch.float32, device=DEV)
+    out = {}
+    for key in ('first_call', 'second_call'):
+        e, stats = eng.local_energy(r, rng=0, ecp_phi=phi)
+        rel, prof = profile(e.double().cpu().numpy(), d['e_loc'])
+        v_nl = stats['hamil/V_nl'].double().cpu().numpy()
+        prof.update({'n_refined': eng.last_refined(), 'pairs': eng.ecp_counts(), 'refine_info': eng.refine_info(),
+                     'V_nl_abs_err_max': float(np.abs(v_nl - d['stats'][3]).max()), 'V_nl_abs_err_p50': float(np.median(np.abs(v_nl - d['stats'][3]))),
+                     'V_nl_abs_mean': float(np.abs(d['stats'][3]).mean()), 'E_abs_mean': float(np.abs(d['e_loc']).mean())})
+        out[key] = prof
+    eng.set_option('ecp_dlog_floor_e6', 0)             # the round-4 rule (weights alone) on the same walkers: recorded
+    e0, _ = eng.local_energy(r, rng=0, ecp_phi=phi)
+    _, out['weights_only_rule'] = profile(e0.double().cpu().numpy(), d['e_loc'])
+    out['weights_only_rule']['pairs'] = eng.ecp_counts()
+    report('ecp_set_b_benzene_256', out)
+    for key in ('first_call', 'second_call'):
+        p = out[key]
+        assert p['frac_within_1e-5'] == 1.0 and p['max'] < 1e-5, (key, p)
+        assert p['V_nl_abs_err_max'] < 1e-5 * np.abs(d['e_loc']).max(), (key, p)

@@ -125,7 +125,7 @@ def test_batched_local_energy_and_psi_ratio_three_states():
         for j in range(S):
             sg, lg = physics.batch_wave_function(owf.to_torch(params[s]), wf.spec, r[0, j].cpu(), Rt, h.n_up, geom.F32_EPS)
             logs[s, j], signs[s, j] = lg.numpy(), sg.numpy()
-    ratio = loss.compute_psi_ratio(wf, params, r)
+    ratio, _ = loss.compute_psi_ratio(wf, params, r)
     assert ratio.shape == (1, S, S, B)
     shifted = logs - logs.mean(axis=(1, 2))[:, None, None]
     for i in range(S):

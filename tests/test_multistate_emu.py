@@ -25,7 +25,8 @@ def test_two_states_energy_and_psi_ratio():
         e_ref, _, _ = physics.batch_local_energy(owf.to_torch(params[s]), wf.spec, r[0, s], T(h.mol.coords), T(h.mol.charges),
                                                  h.n_up, geom.F32_EPS)
         np.testing.assert_allclose(E[0, s].numpy(), e_ref.numpy(), rtol=1e-8, atol=1e-8)
-    R = loss.compute_psi_ratio(wf, params, r)
+    R, ratio_stats = loss.compute_psi_ratio(wf, params, r)
+    assert ratio_stats == {}
     assert R.shape == (1, 2, 2, B)
     np.testing.assert_allclose(R[0, 0, 0].numpy(), 1.0, rtol=1e-12)            # psi_j / psi_j on its own samples
     np.testing.assert_allclose(R[0, 1, 1].numpy(), 1.0, rtol=1e-12)
@@ -174,7 +175,7 @@ def test_multi_geometry_sampler_and_energies():
                          norm_eps=geom.F32_EPS)
             e_ref, _ = eng.local_energy(pc.r[k, s])
             np.testing.assert_allclose(E[k, s].numpy(), e_ref.numpy(), rtol=1e-12, atol=1e-12)
-    ratio = loss.compute_psi_ratio(wf, params, pc)
+    ratio, _ = loss.compute_psi_ratio(wf, params, pc)
     assert ratio.shape == (2, S, S, B)
     np.testing.assert_allclose(ratio[:, 0, 0].numpy(), 1.0, rtol=1e-12)
     idx = MoleculeIdxSampler(0, 3, 2)
