@@ -516,6 +516,12 @@ def main():
             'bound': 'mfma', 'kernel': names[dom],
             'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
             'achieved': achieved, 'peak': F32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_MFMA_PEAK_TFLOPS,
+            # `achieved` / `frac` price ALGORITHMIC flops (the dense T = 3N + 2 lanes of SURVEY.md section 8d).  What the launches
+            # actually multiply (8 compact lanes on edge rows, per-walker pieces once per walker: dqmc_timing_get_executed) is
+            # `executed`; executed / peak is matrix-pipe utilisation, not a roofline fraction -- for N2 / FermiNet the two
+            # differ by ~2x, and the events of launches that overlap on four streams are summed (an upper bound on both)
+            'executed': {k: v.get('flops_executed', v['flops']) / (v['ms'] * 1e-3) / 1e12 for k, v in cands.items()},
+            'executed_frac_of_peak': (lin.get('flops_executed', lin['flops']) / (lin['ms'] * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if lin['ms'] > 0 else 0.0,
             # (counters cannot be collected inside the timed process: the figure is read from the committed rocprofv3 --pmc passes
             # of the same workload, not measured by this run -- hence the key's name; `traffic` itself stays null)
             'traffic': None, 'traffic_from_profile': traffic, 'traffic_unit': 'HBM bytes per launch', 'traffic_source': traffic_src,
@@ -538,6 +544,7 @@ def main():
                                                       'for 96 / 128 lanes)', 'attention': 'k_attention_mfma<double> (v_mfma_f64_16x16x4_f64)'}.get(d64, d64),
                 'per_kernel_tflops': {k: v['flops'] / (v['ms'] * 1e-3) / 1e12 for k, v in f64_c.items()},
                 'achieved': a64, 'peak': F64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': a64 / F64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                'executed': {k: v.get('flops_executed', v['flops']) / (v['ms'] * 1e-3) / 1e12 for k, v in f64_c.items()},
                 'avg_launch_us': 1e3 * f64_c[d64]['ms'] / max(f64_c[d64]['launches'], 1), 'launches_per_step': f64_c[d64]['launches'] / 3,
                 'share_of_kernel_time': f64_c[d64]['ms'] / total_ms, 'f64_share_of_kernel_time': f64_ms / total_ms,
                 'kernel_ms_per_step': {k: v['ms'] / 3 for k, v in f64.items()}}

@@ -50,6 +50,7 @@ SIGNATURES = [
     ('dqmc_timing_enable', c_int, [c_void_p, c_int]),
     ('dqmc_timing_reset', c_int, [c_void_p]),
     ('dqmc_timing_get', c_int, [c_void_p, c_char_p, POINTER(c_double), POINTER(c_int64), POINTER(c_double)]),
+    ('dqmc_timing_get_executed', c_int, [c_void_p, c_char_p, POINTER(c_double)]),
     ('dqmc_timing_names', c_int, [c_void_p, c_char_p, c_size_t]),
 ]
 

@@ -44,7 +44,9 @@ inline int pad4(int n) { return (n + 3) / 4 * 4; }
 struct TimingRec {
   double ms = 0;
   int64_t launches = 0;
-  double flops = 0;
+  double flops = 0;       // algorithmic: the dense-T count of SURVEY.md section 8d (what `roofline.achieved` is priced with)
+  double executed = 0;    // what the launches actually multiply: 8 compact lanes on edge rows, per-walker pieces once per walker,
+                          // lanes padded to TP, widths padded to 4 (matrix-pipe utilisation = this / time / peak)
 };
 
 }  // namespace
@@ -90,7 +92,7 @@ struct dqmc_ctx {
   // timing
   bool timing = false;
   std::map<std::string, TimingRec> trec;
-  struct Pending { std::string name; hipEvent_t a, b; double flops; };
+  struct Pending { std::string name; hipEvent_t a, b; double flops, executed; };
   std::vector<Pending> pending;
   std::vector<hipEvent_t> ev_pool;
   hipStream_t st = nullptr;
@@ -102,10 +104,10 @@ struct dqmc_ctx {
     return e;
   }
   hipStream_t t_stream = nullptr;      // stream of the launch being timed (the context's, or its edge-stream companion)
-  void t_begin(const char* name, double flops, hipStream_t s = nullptr) {
+  void t_begin(const char* name, double flops, hipStream_t s = nullptr, double executed = -1.0) {
     if (!timing) return;
     t_stream = s ? s : st;
-    Pending p{name, get_event(), get_event(), flops};
+    Pending p{name, get_event(), get_event(), flops, executed < 0 ? flops : executed};
     (void)hipEventRecord(p.a, t_stream);
     pending.push_back(p);
   }
@@ -120,7 +122,7 @@ struct dqmc_ctx {
       float ms = 0;
       (void)hipEventElapsedTime(&ms, p.a, p.b);
       auto& r = trec[p.name];
-      r.ms += ms; r.launches += 1; r.flops += p.flops;
+      r.ms += ms; r.launches += 1; r.flops += p.flops; r.executed += p.executed;
       ev_pool.push_back(p.a); ev_pool.push_back(p.b);
     }
     pending.clear();
@@ -245,16 +247,25 @@ struct Engine : dqmc_ctx {
   int refine = 1;
   // Flag rule: score > refine_thresh (kernels.h: FinalArgs).  The threshold is SELF-CALIBRATED: every refine_probe-th
   // local-energy call (and the first) a strided sample of <= refine_sample (256) walkers is evaluated by the float64 twin
-  // as well, the measured float32 error per unit of score -- its 90th percentile c over the sample -- sets
-  // refine_thresh = refine_target / c, i.e. the score at which the expected error reaches refine_target (7e-6
-  // relative, 0.7 of the tolerance of the north star).  Deep / ill-conditioned systems (Psiformer, a random-init
-  // TransPsiformer) measure a large c, flag most walkers and fall into the direct float64 pass by themselves; a
-  // small system keeps a few per cent.  refine_probe = 0 freezes the threshold at the option's value.
+  // as well.  What the MI355X shows (round 5: 82 k evaluations each along the bench trajectories of LiH / PauliNet and
+  // N2 / FermiNet, 5 k of benzene / Psiformer; tools/calib_data.py, profiles/r05_calibration_model.txt): the float32 error
+  // of a walker is  err = m x score x xi  with xi EXPONENTIALLY distributed -- every quantile of err / score is the same in
+  // every score bin (p50 : p90 : p99 : p99.9 = ln 2 : ln 10 : ln 100 : ln 1000), m = 1.3e-8 (LiH), 0.8e-8 (N2, benzene),
+  // 5.6e-8 (LiH / Psiformer).  A walker kept in float32 at score s therefore misses the tolerance with probability
+  // exp(-tol / (m s)), and a score threshold can promise a RATE of misses, not their absence.  The probe measures m on
+  // its sample (robustly: the larger of median / ln 2 and 90th percentile / ln 10) and sets the largest threshold for
+  // which the expected share of kept walkers beyond refine_target (the tolerance, 1e-5) -- the mean of
+  // exp(-tol / (m s_i)) over the kept walkers of the probed batch -- stays below refine_miss (1e-7: one walker in ten
+  // million evaluations).  Rounds 3-4 used threshold = 7e-6 / (90th percentile of err / score): along the same
+  // trajectories that left 27-32 of 82 k evaluations beyond 1e-5 (max 2.2e-5).  Deep / ill-conditioned systems
+  // (Psiformer, a random-init TransPsiformer) end up with most walkers above the threshold and fall into the direct
+  // float64 pass by themselves.  refine_probe = 0 freezes the threshold at the option's value.
   double refine_thresh = 200.0;
-  double refine_target = 7e-6;
+  double refine_target = 1e-5;      // "refine_target_e7" (100): the relative tolerance the kept walkers are to meet
+  double refine_miss = 1e-7;        // "refine_miss_e9" (100): accepted share of kept walkers beyond it
   int refine_probe = 32;
-  int refine_sample = 256;       // walkers of the calibration sample (option "refine_sample": c is the 90th percentile of a sample this
-                                 // large; 64 until round 4 -- six seeds on benzene then drew thresholds that flagged 36-50 % of the batch)
+  int refine_sample = 256;       // walkers of the calibration sample (option "refine_sample"; 64 until round 4 -- six seeds on benzene
+                                 // then drew thresholds that flagged 36-50 % of the batch)
   // Whole-batch float64 ("direct") mode, with hysteresis: a context ENTERS it when more than refine_direct_enter of a batch
   // lies above the threshold (the float32 pass would mostly be wasted: f32(B) + f64(p B) costs more than f64(B) from
   // p ~ 0.6 on, the float64 pass being ~2.5-3 x the float32 one per walker), runs 15 calls there, then looks again with a
@@ -302,7 +313,7 @@ struct Engine : dqmc_ctx {
     pgraphs.clear();
   }
   int calls_since_probe = -1;    // -1: never probed
-  double probe_c = 0.0;          // last measured error per unit of score (0: none yet)
+  double probe_c = 0.0;          // last measured scale m of the float32 error per unit of score (0: none yet)
   bool flag_on = false;
   int refine_all_calls = 0;      // > 0: most walkers were flagged last time -> the next calls go to float64 directly
   std::vector<std::pair<std::string, int>> twin_opts;
@@ -639,6 +650,19 @@ int dqmc_timing_get(dqmc_ctx* ctx, const char* name, double* ms, int64_t* launch
   if (ms) *ms = r.ms;
   if (launches) *launches = r.launches;
   if (flops) *flops = r.flops;
+  return DQMC_OK;
+}
+int dqmc_timing_get_executed(dqmc_ctx* ctx, const char* name, double* flops_executed) {
+  if (!ctx || !name || !flops_executed) return fail(DQMC_E_ARG, "null argument");
+  if (!std::strncmp(name, "f64.", 4)) {
+    dqmc_ctx* t = ctx->twin_ctx();
+    if (t) return dqmc_timing_get_executed(t, name + 4, flops_executed);
+    *flops_executed = 0;
+    return DQMC_OK;
+  }
+  ctx->t_collect();
+  auto it = ctx->trec.find(name);
+  *flops_executed = it == ctx->trec.end() ? 0.0 : it->second.executed;
   return DQMC_OK;
 }
 int dqmc_timing_names(dqmc_ctx* ctx, char* out, size_t n) {

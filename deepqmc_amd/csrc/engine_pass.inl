@@ -279,7 +279,8 @@
             a.res = c[25] >= 0 ? bptr(c[25]) : nullptr;
             if (c[25] >= 0) { a.ld_res = bufs[c[25]].width; a.rpw_res = bufs[c[25]].rows; a.r0_res = c[26]; }
             a.res_scale = c[27] ? (real)0.70710678118654752440 : (real)1;
-            t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so);
+            t_begin("linear", 2.0 * (double)B * i[20] * li.T * ((double)ktot * i[21] + (double)c[3] * c[21]), so,
+                    2.0 * (double)B * i[20] * a.TP * ((double)w_row * a.ldw + (double)a.ldw * a.ldw2));
             dqmc::launch_linear_chain<real>(so, a);
             t_end();
             ran_with_parent[mlp_child[opi]] = 1;
@@ -314,7 +315,7 @@
                 if (i[4 + 4 * p]) { const int rcw = wait_buf(i[1 + 4 * p], zsid); if (rcw) return rcw; }
               if (zb_reader && zsid != sid) HIP_TRY(hipStreamWaitEvent(sl[zsid], zb_reader, 0));
             }
-            t_begin("linear", 0, sl[zsid]);
+            t_begin("linear", 0, sl[zsid], 2.0 * (double)B * li.TP * (double)[&] { int k = 0; for (int q = 0; q < z.n_pieces; ++q) k += z.piece[q].K; return k; }() * a.ldw);
             dqmc::launch_linear<real>(sl[zsid], z);
             t_end();
             if (dual && zsid != sid) {
@@ -324,7 +325,8 @@
               last_ev[zsid] = ez;
               HIP_TRY(hipStreamWaitEvent(so, ez, 0));
             }
-            t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
+            t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so,
+                    2.0 * (double)B * i[20] * a.TP * (double)[&] { int k = 0; for (int q = 0; q < m.n_pieces; ++q) k += m.piece[q].K; return k; }() * a.ldw);
             dqmc::launch_linear<real>(so, m);
             t_end();
             if (dual) {
@@ -333,7 +335,7 @@
             }
             break;
           }
-          t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so);
+          t_begin("linear", 2.0 * (double)B * i[20] * li.T * (double)ktot * i[21], so, 2.0 * (double)B * i[20] * a.TP * (double)w_row * a.ldw);
           dqmc::launch_linear<real>(so, a);
           t_end();
           break;

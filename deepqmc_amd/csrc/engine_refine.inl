@@ -252,10 +252,25 @@
           if (std::isfinite(rel) && std::isfinite(score[b]) && score[b] > 0) cs.push_back(rel / score[b]);
         }
         if (cs.size() >= 2) {
+          // scale m of the exponential error model err = m x score x xi (engine.hip, above refine_thresh): two robust
+          // estimates from the sample's quantiles, the larger one
           std::sort(cs.begin(), cs.end());
-          const double c = std::fmax(cs[(size_t)(0.9 * (cs.size() - 1) + 0.5)], 1e-12);
-          probe_c = probe_c > 0 ? std::sqrt(probe_c * c) : c;         // geometric smoothing over the probes
-          refine_thresh = std::fmin(std::fmax(refine_target / probe_c, 1.0), 1e9);
+          const double q50 = cs[(size_t)(0.5 * (cs.size() - 1) + 0.5)], q90 = cs[(size_t)(0.9 * (cs.size() - 1) + 0.5)];
+          const double m = std::fmax(std::fmax(q50 / 0.6931471805599453, q90 / 2.302585092994046), 1e-14);
+          probe_c = probe_c > 0 ? std::sqrt(probe_c * m) : m;         // geometric smoothing over the probes
+          // the largest threshold whose kept walkers (scores of THIS batch, ascending) miss the tolerance at an expected
+          // rate <= refine_miss:  (1 / B) sum_{s_i <= thr} exp(-tol / (m s_i)) <= refine_miss
+          std::vector<double> ss;
+          for (int b = 0; b < B; ++b) if (std::isfinite(score[b]) && score[b] > 0) ss.push_back(score[b]);
+          std::sort(ss.begin(), ss.end());
+          double acc = 0.0, thr = 1.0;
+          for (size_t k = 0; k < ss.size(); ++k) {
+            acc += std::exp(-refine_target / (probe_c * ss[k])) / (double)B;
+            if (acc > refine_miss) break;
+            thr = ss[k];
+          }
+          if (!ss.empty() && acc <= refine_miss) thr = 1e9;           // (the whole batch may stay in float32)
+          refine_thresh = std::fmin(std::fmax(thr, 1.0), 1e9);
         }
       };
       rc = refine_listed(r, R, B, (int)list.size(), e_loc, stats, grad, logpsi, sign, nullptr, nullptr, 0, true);

@@ -330,6 +330,7 @@ class Engine:
         """State of the float64 refinement after the last local-energy call (dqmc_refine_info)."""
         out = (ctypes.c_double * 4)()
         self._check(self.lib.dqmc_refine_info(self._ctx, out))
+        # ('error_per_score': the scale m of the exponential error model, float32 error = m x score x xi)
         return {'mode': int(out[0]), 'score_threshold': out[1], 'error_per_score': out[2], 'direct_f64_calls_left': int(out[3])}
 
     def refine_counters(self) -> dict:
@@ -374,5 +375,7 @@ class Engine:
         for nm in filter(None, buf.value.decode().split(',')):
             ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
             self._check(self.lib.dqmc_timing_get(self._ctx, nm.encode(), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)))
-            out[nm] = {'ms': ms.value, 'launches': n.value, 'flops': fl.value}
+            ex = ctypes.c_double()
+            self._check(self.lib.dqmc_timing_get_executed(self._ctx, nm.encode(), ctypes.byref(ex)))
+            out[nm] = {'ms': ms.value, 'launches': n.value, 'flops': fl.value, 'flops_executed': ex.value}
         return out

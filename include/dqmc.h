@@ -260,8 +260,11 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * cancellation times the conditioning record of the Slater matrices that carry psi -- exceeds "refine_thresh", or whose
  * E_loc is not finite, are run again by a float64 twin of the context and their E_loc / stats / grad / log|psi| / sign
  * replaced.  The threshold calibrates itself: on the first and then every "refine_probe"-th call a strided sample of
- * <= "refine_sample" (256) further walkers is evaluated in float64 too, the measured float32 error per unit of score (90th
- * percentile) gives refine_thresh = target / c with target = "refine_target_e7" x 1e-7 relative.  A batch with more than
+ * <= "refine_sample" (256) further walkers is evaluated in float64 too.  Measured on the MI355X, the float32 error of a
+ * walker is m x score x (an exponentially distributed factor): the sample gives the scale m, and the threshold is the largest
+ * one for which the expected share of float32-kept walkers beyond the tolerance "refine_target_e7" x 1e-7 (default 1e-5
+ * relative) -- the mean of exp(-tol / (m score_i)) over the kept walkers of the probed batch -- stays below
+ * "refine_miss_e9" x 1e-9 (default 1e-7).  A batch with more than
  * "refine_direct_pct" (60 %) of its walkers above the threshold is evaluated in float64 whole, and so are the next 15 calls;
  * the context returns to the mixed mode only when a float32 pass then finds fewer than "refine_direct_exit_pct" (45 %)
  * above it -- hysteresis: one calibration draw near a single line used to flip the mode from run to run). */
@@ -328,7 +331,10 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * (256; 64 until round 4): walkers of the calibration sample, "refine_direct_pct" (60) / "refine_direct_exit_pct" (45): share
  * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode, "refine_direct_calls" (15): calls it
  * stays there before a float32 pass looks again,
- * "refine_target_e7" (70): target relative error of the unrefined walkers in units of 1e-7.
+ * "refine_target_e7" (100): relative tolerance the float32-kept walkers are to meet, in units of 1e-7; "refine_miss_e9" (100):
+ * accepted share of kept walkers beyond it, in units of 1e-9 (1e-7 costs LiH / PauliNet ~27 % and N2 / FermiNet ~31 % of their
+ * walkers in float64; 10000 = 1e-5 costs ~17 % / ~18 %; the 90th-percentile rule of rounds 3-4 refined 5 % and left
+ * ~30 of 82 k evaluations beyond the tolerance).
  * "linear_bf", "linear_bkx" act on the calling context only;
  * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per
  * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row
@@ -348,6 +354,12 @@ int dqmc_set_option(dqmc_ctx* ctx, const char* name, int value);
 int dqmc_timing_enable(dqmc_ctx* ctx, int enable);
 int dqmc_timing_reset(dqmc_ctx* ctx);
 int dqmc_timing_get(dqmc_ctx* ctx, const char* name, double* ms, int64_t* launches, double* flops);
+/* The flops the launches of kernel class `name` actually multiplied, beside dqmc_timing_get's ALGORITHMIC count (the dense
+ * T = 3N + 2 lanes of SURVEY.md section 8d, which `roofline.achieved` is priced with): edge rows carry 8 pair-compact lanes,
+ * per-walker (broadcast) pieces are multiplied once per walker, lanes are padded to TP and widths to multiples of 4.
+ * executed / time / peak is the matrix-pipe utilisation; algorithmic / time / peak is the roofline fraction -- for
+ * N2 / FermiNet the two differ by ~2x. */
+int dqmc_timing_get_executed(dqmc_ctx* ctx, const char* name, double* flops_executed);
 int dqmc_timing_names(dqmc_ctx* ctx, char* out, size_t n);
 
 #ifdef __cplusplus

@@ -17,10 +17,10 @@ with the oracle to float32 OUTPUT rounding (< 2e-7) for 100 % of the walkers.
 
 How the default gets there (engine.hip: lap_refined): the float32 error of E_loc is predicted per
 walker by score = (|lap| + |grad|^2) / max(1, |E_loc|) x conditioning record of the Slater matrices; on the first call
-(and every 32nd) <= 64 extra walkers are evaluated in float64, the measured error per unit of score sets the score
-threshold for a 5e-6 target, walkers above it are re-evaluated by the float64 twin.  LiH / PauliNet refines ~3 % of
-its walkers, N2 / FermiNet ~10 %, the Psiformers and the random-init TransPsiformer most or all of them -- those
-fall into the direct float64 pass.
+(and every 32nd) <= 256 extra walkers are evaluated in float64; measured, err = m x score x (exponential factor), the sample
+gives m, and the threshold is the largest one whose kept walkers miss 1e-5 at an expected rate <= 1e-7; walkers above it are
+re-evaluated by the float64 twin.  LiH / PauliNet refines ~10 % of the fixture's walkers (~27 % along the bench trajectory),
+N2 / FermiNet ~30 %, the Psiformers and the random-init TransPsiformer nearly all -- those run in the direct float64 mode.
 Everything lands in gpurun_out/parity_report.json -> profiles/r04_parity_report.json.
 """
 import json
@@ -44,21 +44,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, 'gpurun_out')
 
 # name: (min fraction within 1e-5, p50 bound, p99 bound, max bound, log|psi| p99 bound)
-# The four BASELINE-size sets (+ the ECP set) assert the north-star tolerance itself: EVERY walker within 1e-5 (round-4;
-# observed maxima 9.0e-6 / 8.1e-6 / <= 6e-8, profiles/r03_parity_report.json).  The looser bounds below them belong to the
-# AUXILIARY sets only (small batches of the same systems, raw Gaussian walkers): 0.1-0.4 % of their walkers sit at 1.2-1.4e-5.
+# Every set asserts the north-star tolerance itself -- EVERY walker within 1e-5 -- with ONE documented exception.  Round 5: the
+# score threshold now promises a miss rate of 1e-7 under the measured exponential error model (engine.hip, above refine_thresh),
+# which refines 2-3 x more walkers than the 90th-percentile rule of rounds 3-4 did (profiles/r05_calibration_model.txt).
 BOUNDS = {
     'lih_paulinet_4096': (1.0, 1e-6, 1e-5, 1e-5, 1e-5),
     'n2_ferminet_4096': (1.0, 2e-6, 1e-5, 1e-5, 1e-4),
     'benzene_psiformer_256': (1.0, 3e-6, 1e-5, 1e-5, 1e-3),
     'c4h4_transpsiformer_512': (1.0, 1e-6, 1e-5, 1e-5, 1e-3),
     'benzene_ecp_psiformer_32': (1.0, 2e-6, 1e-5, 1e-5, 1e-3),    # + V_nl: 2 160 psi ratios per walker (float64 for refined walkers)
-    # auxiliary sets
-    'lih_psiformer_256': (0.99, 2e-6, 1e-5, 2e-5, 2e-5),
-    'n2_ferminet_512': (0.99, 2e-6, 1e-5, 2e-5, 1e-4),
-    'benzene_psiformer_8': (0.99, 3e-6, 1e-5, 1e-5, 5e-4),
-    'c4h4_transpsiformer_64': (0.99, 1e-6, 1e-5, 1e-5, 1e-3),     # the probe sends this system to the direct float64 pass
-    'lih_paulinet_raw_1024': (0.99, 1e-6, 1e-5, 5e-5, 5e-4),      # raw Gaussian walkers: log|psi| near nodes is not refined
+    # auxiliary sets (small batches of the same systems, raw Gaussian walkers)
+    'lih_psiformer_256': (1.0, 2e-6, 1e-5, 1e-5, 2e-5),
+    # ONE walker of this set (index 468: score 86, float32 error 1.40e-5 -- 17 x the scale m x score, i.e. a 2e-8 event under the
+    # exponential model that fits the other 170 k evaluations we hold; nothing singular about it: cond(A) 3e4, nearest
+    # nucleus 0.24 bohr) is a model outlier that only a threshold below ITS score catches.  Kept as the documented
+    # exception instead of tuning the default to a single walker: >= 99.8 % of the set and max < 2e-5 are asserted.
+    'n2_ferminet_512': (0.998, 2e-6, 1e-5, 2e-5, 1e-4),
+    'benzene_psiformer_8': (1.0, 3e-6, 1e-5, 1e-5, 5e-4),
+    'c4h4_transpsiformer_64': (1.0, 1e-6, 1e-5, 1e-5, 1e-3),      # the probe sends this system to the direct float64 pass
+    'lih_paulinet_raw_1024': (1.0, 1e-6, 1e-5, 1e-5, 5e-4),       # raw Gaussian walkers (not what the VMC loop evaluates): ~50 % refined
 }
 
 
@@ -315,57 +319,70 @@ def test_three_states_c4h4_local_energy_psi_ratio_overlap(dtype):
 
 # ---- round 5: parity in the regime, and along the trajectory, that bench.py actually runs -------------------------------
 
-def _kept_f32_profile(eng, e, ref, B):
-    """Error distribution of the walkers that KEPT their float32 result in the last call (score <= threshold)."""
-    score = eng.refine_scores(B)
-    thr = eng.refine_info()['score_threshold']
-    kept = score <= thr
-    rel = np.abs(e - ref) / np.maximum(1.0, np.abs(ref))
-    out = {'n_kept_f32': int(kept.sum()), 'n_refined': int((~kept).sum()), 'score_threshold': thr}
-    if kept.any():
-        out.update({'kept_p50': float(np.median(rel[kept])), 'kept_p99': float(np.quantile(rel[kept], 0.99)), 'kept_max': float(rel[kept].max())})
-    if (~kept).any():
-        out['refined_max'] = float(rel[~kept].max())
-    return rel, kept, out
-
-
 @pytest.mark.parametrize('chunked', [False, True])
-def test_benzene_mixed_regime_256(chunked):
-    """BASELINE configs[3] on the machine: bench.py runs benzene / Psiformer with a THIRD to a HALF of the walkers refined in
-    float64 and the rest left in float32 (the library's mixed mode) -- the regime the 256-walker fixture never exercised
-    while a majority above the threshold sent the whole batch to float64.  Library defaults (calibration sample 256 =
-    this whole batch, mode switch at 60 % with hysteresis): the batch must stay in the MIXED mode, on the calibrating first
-    call and on the calibrated second one; every walker within 1e-5 of the oracle; the error distribution of the walkers
-    that kept their float32 value goes to the report.  `chunked`: the same under a workspace budget that splits the float32
-    pass AND the twin's pass into >= 4 chunks each (what the 2048-walker BASELINE batch does), bit-equal to unchunked."""
+def test_benzene_regimes_256(chunked):
+    """BASELINE configs[3] on the machine.  Round 4's bench.py ran benzene / Psiformer with 28-40 % of the walkers refined in
+    float64 and the rest left in float32 -- a regime the 256-walker fixture never exercised, because a majority above the
+    threshold sent that batch to float64 whole.  Two parts:
+      (1) LIBRARY DEFAULTS (round 5: the threshold promises a miss RATE under the measured exponential error model, engine.hip
+          above refine_thresh): nearly every benzene walker lies above it, the context enters the whole-batch float64 mode on
+          the calibrating call and stays there; EVERY walker within 1e-5 of the oracle, first and second call.
+      (2) THE MIXED REGIME, PINNED (probe off, threshold at the 60th percentile of the batch's scores, mode switch disabled):
+          ~40 % refined, 60 % kept in float32 -- what round 4 ran.  Asserted: the mechanics (refined walkers carry the float64
+          result, kept ones the plain float32 one, bit for bit; counts).  RECORDED, because it is the finding: the kept
+          walkers do NOT all meet 1e-5 (5 k evaluations along the bench trajectory at 49 % refined: 21 beyond it, max 2.1e-5,
+          profiles/r05_calibration_model.txt) -- which is why (1) is the default.
+    `chunked`: part (2) again under a workspace budget that splits the float32 pass AND the twin's pass into >= 4 chunks each
+    (what the 2048-walker BASELINE batch does): bit-equal to the unchunked evaluation."""
     d, meta, h, eng = load('benzene_psiformer_256')
     r = torch.as_tensor(d['r'], device=DEV)
     B = r.shape[0]
-    if chunked:
-        e_un, st_un = eng.local_energy(r)            # unchunked reference of the calibrating call ...
-        e_un2, _ = eng.local_energy(r)               # ... and of the steady state
-        d, meta, h, eng = load('benzene_psiformer_256')
-        for name in ('ws_budget_mb', 'twin.ws_budget_mb'):
-            eng.set_option(name, 10 * 1024)
     out = {}
     for key in ('first_call', 'second_call'):
         e, _ = eng.local_energy(r)
-        info, chunks = eng.refine_info(), eng.last_chunks()
-        rel, kept, prof = _kept_f32_profile(eng, e.double().cpu().numpy(), d['e_loc'], B)
-        prof.update({'frac_within_1e-5': float((rel < 1e-5).mean()), 'max': float(rel.max()), 'last_refined': eng.last_refined(),
-                     'direct_f64_calls_left': info['direct_f64_calls_left'], 'chunks': chunks})
+        rel, prof = profile(e.double().cpu().numpy(), d['e_loc'])
+        prof.update({'last_refined': eng.last_refined(), **eng.refine_info(), 'chunks': eng.last_chunks()})
         out[key] = prof
-        if chunked:
-            assert torch.equal(e, e_un if key == 'first_call' else e_un2), key
-            assert chunks['own'] >= 4 and chunks['twin'] >= 4, chunks
     out['counters'] = eng.refine_counters()
-    report('benzene_mixed_regime_256' + ('_chunked' if chunked else ''), out)
+    del eng
+    # ---- (2) the mixed regime, pinned ----
+    d, meta, h, mix = load('benzene_psiformer_256')
+    for name, val in (('refine_probe', 0), ('refine_direct_pct', 100), ('refine_thresh', 10 ** 9)):
+        mix.set_option(name, val)
+    e_plain, _ = mix.local_energy(r)
+    score = mix.refine_scores(B)
+    thr = int(np.quantile(score, 0.6))
+    mix.set_option('refine_thresh', thr)
+    e_mix, st_mix, g_mix = mix.local_energy(r, return_grad=True)
+    kept = score <= thr
+    assert mix.last_refined() == int((~kept).sum()) and 0.3 * B <= (~kept).sum() <= 0.5 * B
+    assert mix.refine_info()['direct_f64_calls_left'] == 0      # (the 32 GB default budget already splits this pass in two)
+    if chunked:
+        for name in ('ws_budget_mb', 'twin.ws_budget_mb'):
+            mix.set_option(name, 10 * 1024)
+        e_c, st_c, g_c = mix.local_energy(r, return_grad=True)
+        info = mix.last_chunks()
+        assert info['own'] >= 4 and info['twin'] >= 4, info
+        assert torch.equal(e_c, e_mix) and torch.equal(g_c, g_mix)
+        for k in st_mix:
+            assert torch.equal(st_c[k], st_mix[k]), k
+        out['mixed_chunks'] = info
+    mix.set_option('refine', 2)
+    e_f64, _ = mix.local_energy(r)
+    em, ep, ef = (x.cpu().numpy() for x in (e_mix, e_plain, e_f64))
+    np.testing.assert_array_equal(em[kept], ep[kept])                      # kept walkers: the plain float32 result, untouched
+    np.testing.assert_array_equal(em[~kept], ef[~kept])                    # refined walkers: the float64 pass's result
+    rel = np.abs(em.astype(np.float64) - d['e_loc']) / np.maximum(1.0, np.abs(d['e_loc']))
+    out['mixed_regime_pinned'] = {'score_threshold': thr, 'n_refined': int((~kept).sum()), 'n_kept_f32': int(kept.sum()),
+                                  'kept_p50': float(np.median(rel[kept])), 'kept_p99': float(np.quantile(rel[kept], 0.99)),
+                                  'kept_max': float(rel[kept].max()), 'kept_beyond_1e-5': int((rel[kept] >= 1e-5).sum()),
+                                  'refined_max': float(rel[~kept].max())}
+    report('benzene_regimes_256' + ('_chunked' if chunked else ''), out)
+    assert out['mixed_regime_pinned']['refined_max'] < 2e-7 and out['mixed_regime_pinned']['kept_max'] < 1e-4
     for key in ('first_call', 'second_call'):
         p = out[key]
-        assert p['direct_f64_calls_left'] == 0, (key, p)                       # the mixed mode, not whole-batch float64
-        assert 0.15 * B <= p['n_refined'] <= 0.60 * B, (key, p)                # (what bench.py reports for this system: 28-40 %)
-        assert p['frac_within_1e-5'] == 1.0 and p['max'] < 1e-5, (key, p)      # the north-star tolerance, every walker
-    assert out['counters']['direct_f64_calls'] == 0
+        assert p['frac_within_1e-5'] == 1.0 and p['max'] < 1e-5, (key, p)      # the north-star tolerance, every walker, at defaults
+    assert out['second_call']['direct_f64_calls_left'] > 0, out['second_call']  # (the mode the default runs this system in)
 
 
 @pytest.mark.parametrize('molname,ansatz,n_sub', [('LiH', 'paulinet', 30), ('N2', 'ferminet', 10)])
@@ -375,7 +392,8 @@ def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
     DEFAULTS (self-calibrated refinement, captured passes) against the float64 pass of a second context ("refine" 2: oracle-
     checked to 2e-7 by the fixtures) on the same walkers.  >= 80 k evaluations per system; asserted: EVERY one within 1e-5
     (reference semantics: loss/energy.py:50-57 -- the reference evaluates every walker in one precision).  The tail goes to
-    the report, and so does what two tighter targets ("refine_target_e7" 50 / 35) would buy and cost on the same walkers."""
+    the report, and so does what two LOOSER miss rates ("refine_miss_e9" 1e-6 / 1e-5 instead of the default 1e-7) would save
+    and cost on the same walkers."""
     from deepqmc_amd import MolecularHamiltonian as MH, Molecule as Mol
     from deepqmc_amd.sampling import DecorrSampler
     from deepqmc_amd.wf import NeuralNetworkWaveFunction
@@ -387,9 +405,9 @@ def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
     ref = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
     ref.set_option('refine', 2)
     alt = {}
-    for t7 in (50, 35):
+    for t7 in (1000, 10000):
         alt[t7] = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
-        alt[t7].set_option('refine_target_e7', t7)
+        alt[t7].set_option('refine_miss_e9', t7)
     smp = DecorrSampler(h, wf, length=n_sub, in_place=True)
     st = smp.init(1000, params, B)
     burn = DecorrSampler(h, wf, length=50)
@@ -415,7 +433,7 @@ def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
                'max_per_step': [float(x.max()) for x in rels]}
     for t7 in alt:
         x = np.concatenate(alt_rel[t7])
-        payload[f'target_{t7}e-7'] = {**tail(x), 'refined_fraction': float(np.mean(alt_ref[t7][1:])) / B}
+        payload[f'miss_rate_{t7}e-9'] = {**tail(x), 'refined_fraction': float(np.mean(alt_ref[t7][1:])) / B}
     report(f'trajectory_{molname}_{ansatz}_{B}', payload)
     assert rel.size >= 80_000
     assert payload['default']['frac_within_1e-5'] == 1.0, payload['default']
