@@ -1,8 +1,8 @@
-"""Offline replay of the refinement calibration on the per-walker data of tools/calib_data.py (gpurun_out/calib_*.npz):
-for a rule (percentile of error / score over the calibration sample, target), the threshold it derives, the share of walkers
-it sends to float64 and the errors of the walkers it leaves in float32.
+"""Offline replay of the refinement calibration on the per-walker data of tools/calib_data.py (gpurun_out/calib_*.npz: score,
+plain float32 E_loc, float64 E_loc per walker; fixtures and bench-like trajectories): the error model the library's threshold
+rule rests on, and what each rule would have refined / left beyond the tolerance.
 
-    python tools/calib_sim.py [gpurun_out/calib_*.npz]
+    python tools/calib_sim.py > profiles/r05_calibration_model.txt
 """
 import glob
 import os
@@ -11,30 +11,86 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL = 1e-5
 
 
-def replay(score, e32, e64, pct, target, sample=256):
-    """score/e32/e64: [steps, B] (a fixture is one step).  Calibrate on a strided sample of step 0, apply to all steps."""
+def load(f):
+    d = np.load(f)
+    score, e32, e64 = (np.atleast_2d(d[k]) for k in ('score', 'e32', 'e64'))
     rel = np.abs(e32 - e64) / np.maximum(1.0, np.abs(e64))
+    return score, rel
+
+
+def sample_of(score, rel, n=256):
     B = score.shape[1]
-    idx = (np.arange(min(sample, B)) * B // min(sample, B))
-    cs = rel[0, idx] / score[0, idx]
-    cs = np.sort(cs[np.isfinite(cs) & (score[0, idx] > 0)])
-    c = max(cs[int(pct * (len(cs) - 1) + 0.5)], 1e-12)
-    thr = min(max(target / c, 1.0), 1e9)
+    idx = np.arange(min(n, B)) * B // min(n, B)
+    q = rel[0, idx] / score[0, idx]
+    return np.sort(q[np.isfinite(q) & (score[0, idx] > 0)])
+
+
+def rule_percentile(score, rel, pct=0.9, target=7e-6):
+    """rounds 3-4: threshold = target / (pct-quantile of err / score over the calibration sample of the first call)"""
+    q = sample_of(score, rel)
+    return target / max(q[int(pct * (len(q) - 1) + 0.5)], 1e-12)
+
+
+def rule_miss_rate(score, rel, rho=1e-7):
+    """round 5 (engine_refine.inl: probe_rethreshold): exponential model err = m score xi; the largest threshold whose kept
+    walkers (scores of the first call) miss TOL at an expected rate <= rho"""
+    q = sample_of(score, rel)
+    m = max(q[int(0.5 * (len(q) - 1) + 0.5)] / np.log(2), q[int(0.9 * (len(q) - 1) + 0.5)] / np.log(10), 1e-14)
+    s0 = np.sort(score[0][np.isfinite(score[0]) & (score[0] > 0)])
+    acc = np.cumsum(np.exp(-TOL / (m * s0))) / score.shape[1]
+    k = int(np.searchsorted(acc, rho, side='right'))
+    return (s0[k - 1] if k > 0 else 1.0) if k < len(s0) else 1e9, m
+
+
+def outcome(score, rel, thr):
     kept = score <= thr
-    out = {'thr': thr, 'refined': 1.0 - kept.mean(), 'kept_max': rel[kept].max() if kept.any() else 0.0,
-           'kept_above_1e-5': int((rel[kept] >= 1e-5).sum()), 'n': rel.size}
-    return out
+    return (100 * (1 - kept.mean()), rel[kept].max() if kept.any() else 0.0, int((rel[kept] >= TOL).sum()), int((rel[kept] >= 5e-6).sum()))
 
 
 if __name__ == '__main__':
     files = sys.argv[1:] or sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', 'calib_*.npz')))
+    print('Error model of the float32 forward-Laplacian pass on the MI355X (tools/calib_data.py -> tools/calib_sim.py).')
+    print('err = |E_f32 - E_f64| / max(1, |E_f64|) per walker (plain float32, refinement off); score = the predictor of k_final.')
+    print()
+    print('1. err / score has ONE distribution in every score bin, and it is exponential: quantile / ln(1 / (1 - p)) is the same number m for')
+    print('   p = 0.5, 0.9, 0.99, 0.999 (an exponential variable has quantile(p) = m ln(1 / (1 - p))).')
     for f in files:
-        d = np.load(f)
-        score, e32, e64 = (np.atleast_2d(d[k]) for k in ('score', 'e32', 'e64'))
-        rel = np.abs(e32 - e64) / np.maximum(1.0, np.abs(e64))
-        print(f'{os.path.basename(f)[6:-4]:32s} n={rel.size:6d} plain: within 1e-5 {100 * (rel < 1e-5).mean():6.2f} %  max {rel.max():.1e}')
-        for pct, target in ((0.9, 7e-6), (0.9, 5e-6), (0.9, 3.5e-6), (0.9, 2.5e-6), (0.99, 7e-6), (0.99, 5e-6), (1.0, 1e-5), (1.0, 7e-6)):
-            o = replay(score, e32, e64, pct, target)
-            print(f'    pct {pct:4.2f} target {target:.1e}: thr {o["thr"]:9.1f} refined {100 * o["refined"]:5.1f} %  kept max {o["kept_max"]:.2e}  kept >= 1e-5: {o["kept_above_1e-5"]}')
+        score, rel = load(f)
+        q = (rel / score).ravel()
+        q = q[np.isfinite(q)]
+        est = [np.quantile(q, p) / np.log(1 / (1 - p)) for p in (0.5, 0.9, 0.99, 0.999)]
+        print(f'   {os.path.basename(f)[6:-4]:30s} n = {rel.size:6d}  plain float32 within 1e-5: {100 * (rel < TOL).mean():6.2f} %  max {rel.max():.1e}   '
+              f'm from p50 / p90 / p99 / p99.9 = {est[0]:.2e} {est[1]:.2e} {est[2]:.2e} {est[3]:.2e}   mean {q.mean():.2e}')
+    print()
+    print('2. Quantiles of err by score bin along the bench trajectories (every quantile doubles when the score doubles).')
+    for f in files:
+        if 'traj_' not in f:
+            continue
+        score, rel = load(f)
+        s, x = score.ravel(), rel.ravel()
+        print(f'   {os.path.basename(f)[6:-4]}')
+        edges = [0, 10, 20, 40, 80, 160, 320, 640, 1280, 1e9]
+        for a, b in zip(edges, edges[1:]):
+            msk = (s >= a) & (s < b)
+            if msk.sum() < 5:
+                continue
+            y = x[msk]
+            print(f'     score [{a:5.0f}, {b:10.0f})  {100 * msk.mean():5.1f} % of walkers   err p50 {np.median(y):.1e}  p90 {np.quantile(y, .9):.1e}  p99 {np.quantile(y, .99):.1e}'
+                  f'  p99.9 {np.quantile(y, .999):.1e}  max {y.max():.1e}   >= 1e-5: {(y >= TOL).sum():4d}')
+    print()
+    print('3. Threshold rules replayed: calibrated on a strided 256-walker sample of the FIRST step, applied to every step.')
+    print('   columns: threshold, share of walkers refined in float64, largest error among the walkers KEPT in float32, kept walkers >= 1e-5, >= 5e-6')
+    for f in files:
+        score, rel = load(f)
+        print(f'   {os.path.basename(f)[6:-4]}  (n = {rel.size})')
+        thr = rule_percentile(score, rel)
+        o = outcome(score, rel, thr)
+        print(f'     rounds 3-4: 7e-6 / p90(err / score)        thr {thr:8.1f}  refined {o[0]:5.1f} %  kept max {o[1]:.2e}  kept >= 1e-5: {o[2]:3d}  >= 5e-6: {o[3]:4d}')
+        for rho in (1e-5, 1e-6, 1e-7):
+            thr, m = rule_miss_rate(score, rel, rho)
+            o = outcome(score, rel, thr)
+            tag = '  <- library default' if rho == 1e-7 else ''
+            print(f'     round 5: miss rate {rho:.0e} (m = {m:.2e})      thr {thr:8.1f}  refined {o[0]:5.1f} %  kept max {o[1]:.2e}  kept >= 1e-5: {o[2]:3d}  >= 5e-6: {o[3]:4d}{tag}')
