@@ -288,7 +288,7 @@ struct Engine : dqmc_ctx {
   bool graph_broken = false;
   hipStream_t st_g = nullptr;
   hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
-  struct PassGraph { const void* p[7]; int B; bool flag; const void* ws; const void* flagp; uint64_t epoch, used; void* exec; };
+  struct PassGraph { const void* p[7]; int B; bool flag; const void* ws; const void* flagp; const void* ws_tail[2]; uint64_t epoch, used; void* exec; };
   std::vector<PassGraph> pgraphs;
   uint64_t graph_epoch = 0, graph_clock = 0, graph_captures = 0, graph_hits = 0;
   std::vector<int> graph_warm;          // batch sizes that have run eagerly
@@ -330,6 +330,33 @@ struct Engine : dqmc_ctx {
   std::vector<int32_t> ph_mask_h;
   dqmc_ctx* twin = nullptr;
   dqmc_ctx* twin_ctx() override { return twin; }
+  // float64 TAIL of a float32 forward-Laplacian pass (option "tail_f64", default 1; engine_refine.inl: run_tail).  The last
+  // linear layer -- the backflow head whose output multiplies the envelopes into the Slater matrices -- is where a float32
+  // rounding hurts most: everything after it is the ill-conditioned part of the path (inverse of A, CI cancellation), which
+  // amplifies a relative error of the matrix entries by the walker's score, while the roundings of earlier layers average
+  // out.  tests/f32_model.py (the float32 rounding model, which reproduces the MI355X's error percentiles) with that ONE
+  // buffer kept in double: E_loc errors x 0.54 (LiH / PauliNet), x 0.39 (N2 / FermiNet) -- the scale m of the error model
+  // drops by that factor, the score threshold rises by its inverse, and the share of walkers that need the float64 twin
+  // falls.  Measured on the MI355X (tools/gpu_r05_d.sh): m x 0.81 on LiH (26.7 -> 20.8 % refined; the step is unchanged,
+  // the tail's cost eats the saving), m x 0.63 on N2 (34.1 -> 16.2 % refined, 63.7 -> 58.4 ms per step with the first
+  // version, which widened the 2.8 GB input of the head layer).  So the TAIL OPS -- the LINEAR ops that write the buffer
+  // ORBITALS reads, then ORBITALS, SLOGDET and FINAL (envelopes x backflow, determinants, CI sum, E_loc) -- run on the
+  // float64 twin for EVERY walker of an unchunked Laplacian pass: the twin's linear kernel reads the head's float32
+  // activations where they lie (LinArgs::src_f32), the few other inputs (the Jastrow row) are widened into the twin's
+  // workspace, the twin's k_final flags / scores for this context, the results are narrowed back.
+  int tail_f64 = 1;
+  int k_tail = -1;                   // first op of the tail; -1: this program has none (analyse_tail)
+  std::vector<char> in_tail;         // per op: runs on the twin when a pass hands over its tail
+  std::vector<int> tail_in;          // buffers the head writes and the tail reads ...
+  std::vector<char> tail_direct;     // ... per buffer: every tail reader is a LINEAR op that can read it as float32 (not widened)
+  std::vector<char> tail_written;    // buffers written by tail ops (dqmc_debug_read finds them in the twin's workspace)
+  std::vector<char> tail_alloc;      // buffers the twin needs memory for while it runs a tail (written + widened)
+  bool tail_only = false;            // this context (a twin) executes tail ops only ...
+  std::vector<const float*> src32_of;   // ... and reads these buffers from the float32 context's workspace
+  bool tail_now = false;             // the chunk being executed hands its tail to the twin
+  bool last_tail = false;            // ... and so did the last Laplacian-mode evaluation
+  char* d_tail = nullptr;            // widened positions / geometry and the tail's float64 results
+  size_t tail_bytes = 0;
   int32_t* d_flag = nullptr;     // [0] = count, [1..] = walker indices
   double* d_score = nullptr;     // [B] error predictor of the last flagged pass
   size_t flag_cap = 0;
@@ -355,6 +382,7 @@ struct Engine : dqmc_ctx {
     if (d_molz) (void)hipFree(d_molz);
     if (d_flag) (void)hipFree(d_flag);
     if (d_score) (void)hipFree(d_score);
+    if (d_tail) (void)hipFree(d_tail);
     if (d_ref) (void)hipFree(d_ref);
     if (d_descs) (void)hipFree(d_descs);
     if (d_wave_begin) (void)hipFree(d_wave_begin);
@@ -408,6 +436,7 @@ struct Engine : dqmc_ctx {
     analyse_lanes();
     analyse_chains();
     analyse_streams();
+    analyse_tail();
     rc = set_weights(w, nw);
     if (rc) return rc;
     return build_fused_plan();

@@ -220,6 +220,14 @@
   int debug_read(int buf, double* out, size_t n) override {
     if (last_B == 0) return fail(DQMC_E_ARG, "no evaluation has run yet");
     HIP_TRY(hipStreamSynchronize(st));
+    if constexpr (sizeof(real) == 4) {
+      // the last Laplacian-mode evaluation handed its tail to the float64 twin: what the tail wrote lives in the twin's workspace
+      if (last_tail && last_TP > 1 && twin && (buf == -1 || buf == -2 || buf == -4 || (buf >= 0 && buf < (int)bufs.size() && tail_written[buf]))) {
+        auto* tw = static_cast<Engine<double>*>(twin);
+        if (tw->last_B == last_B && tw->last_TP == last_TP) return tw->debug_read(buf, out, n);
+        return fail(DQMC_E_ARG, "the float64 twin has been re-planned since the tail of this evaluation ran (a refinement pass): read with \"refine\" 0");
+      }
+    }
     if (buf == -1) {
       const size_t cnt = (size_t)last_B * sys.n_det * last_TP;
       if (n != cnt) return fail(DQMC_E_ARG, "size mismatch");

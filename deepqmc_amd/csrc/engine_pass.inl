@@ -6,12 +6,13 @@
     return TP == 1 || TP == 16 || TP == 32 || TP == 48 || TP == 64 || TP == 96 || TP == 128;
   }
 
-  int plan(int B, int TP) {
+  // `only` (a twin planning for a float64 tail): memory for these buffers alone; the others keep offset 0 and are not touched
+  int plan(int B, int TP, const std::vector<char>* only = nullptr) {
     buf_off.resize(bufs.size());
     size_t off = 0;
     auto bump = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     for (size_t k = 0; k < bufs.size(); ++k)
-      buf_off[k] = bump(sizeof(real) * (size_t)B * bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width);
+      buf_off[k] = (only && !(*only)[k]) ? 0 : bump(sizeof(real) * (size_t)B * bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width);
     {
       int max_ldw = 4;
       for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && pad4(o.i[21]) > max_ldw) max_ldw = pad4(o.i[21]);
@@ -34,9 +35,10 @@
   real* bptr(int b) { return reinterpret_cast<real*>(d_ws + buf_off[b]); }
 
   // Workspace bytes per walker for an evaluation with TP lanes (what plan() allocates, without alignment slack).
-  size_t ws_bytes_per_walker(int TP) const {
+  size_t ws_bytes_per_walker(int TP, const std::vector<char>* only = nullptr) const {
     size_t b = 0;
-    for (size_t k = 0; k < bufs.size(); ++k) b += sizeof(real) * (size_t)bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width;
+    for (size_t k = 0; k < bufs.size(); ++k)
+      if (!only || (*only)[k]) b += sizeof(real) * (size_t)bufs[k].rows * lanes_of((int)k, TP) * bufs[k].width;
     size_t zrow = 4;
     for (const auto& o : ops) if (o.kind == DQMC_OP_LINEAR && (size_t)pad4(o.i[21]) > zrow) zrow = (size_t)pad4(o.i[21]);
     return b + sizeof(real) * zrow * TP + sizeof(double) * (size_t)sys.n_det * TP + sizeof(int32_t) * (size_t)sys.n_det +
@@ -55,10 +57,15 @@
     long chunk = per ? (long)(ws_budget / per) : B;
     if (chunk < 1) chunk = 1;
     if (laplacian) last_chunks[0] = chunk >= B ? 1 : (int)((B + chunk - 1) / chunk);
+    tail_now = false;
+    if (laplacian) last_tail = false;
     if (chunk >= B) {
-      if (laplacian && graph_fits(B))
-        return run_graphed(r, R, B, logpsi, sign, e_loc, stats, grad);
-      return run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
+      if (laplacian) { tail_now = tail_ready(B, TP); last_tail = tail_now; }
+      int rc;
+      if (laplacian && graph_fits(B)) rc = run_graphed(r, R, B, logpsi, sign, e_loc, stats, grad);
+      else rc = run_chunk(r, R, B, laplacian, logpsi, sign, e_loc, stats, B, grad, 0);
+      tail_now = false;
+      return rc;
     }
     for (int b0 = 0; b0 < B; b0 += (int)chunk) {
       const int nb = (B - b0) < chunk ? (B - b0) : (int)chunk;
@@ -78,7 +85,8 @@
     const void* key[7] = {r, R, logpsi, sign, e_loc, stats, grad};
     PassGraph* hit = nullptr;
     for (auto& g : pgraphs)
-      if (g.B == B && g.flag == flag_on && g.ws == d_ws && g.flagp == d_flag && g.epoch == graph_epoch && !memcmp(g.p, key, sizeof(key))) hit = &g;
+      if (g.B == B && g.flag == flag_on && g.ws == d_ws && g.flagp == d_flag && g.epoch == graph_epoch && !memcmp(g.p, key, sizeof(key)) &&
+          g.ws_tail[0] == tail_ws(0) && g.ws_tail[1] == tail_ws(1)) hit = &g;
     if (!hit) {
       // a caller that hands over different buffers on every call would pay a capture (milliseconds) per pass: once captures
       // clearly outnumber replays, the context goes back to eager launches for good
@@ -122,6 +130,7 @@
       PassGraph g{};
       memcpy(g.p, key, sizeof(key));
       g.B = B; g.flag = flag_on; g.ws = d_ws; g.flagp = d_flag; g.epoch = graph_epoch; g.exec = exec;
+      g.ws_tail[0] = tail_ws(0); g.ws_tail[1] = tail_ws(1);      // (a captured tail holds the twin's workspace and the tail scratch)
       pgraphs.push_back(g);
       hit = &pgraphs.back();
     }
@@ -134,6 +143,9 @@
     HIP_TRY(hipStreamWaitEvent(st, ev_g1, 0));
     // the host-side layout (buf_off, off_*, last_B, last_TP) follows the replayed pass, so that dqmc_debug_read after it
     // addresses what the graph wrote; the slab is already large enough (the graph was captured on it), nothing is reallocated
+    if constexpr (sizeof(real) == 4) {
+      if (tail_now && twin) { const int rct = static_cast<Engine<double>*>(twin)->plan(B, (3 * N + 2 + 15) / 16 * 16, &tail_alloc); if (rct) return rct; }
+    }
     return plan(B, (3 * N + 2 + 15) / 16 * 16);
   }
 
@@ -144,7 +156,7 @@
     li.T = laplacian ? 3 * N + 2 : 1;
     li.TP = laplacian ? (li.T + 15) / 16 * 16 : 1;
     if (!lanes_supported(li.TP)) return fail(DQMC_E_UNSUPPORTED, "no kernel instance for " + std::to_string(li.TP) + " lanes");
-    int rc = plan(B, li.TP);
+    int rc = plan(B, li.TP, tail_only ? &tail_alloc : nullptr);
     if (rc) return rc;
     // pseudo-Hamiltonian: the local-energy pass (not the plain gradient of psi_grad / the Langevin sampler) seeds its
     // derivative lanes with the per-electron Cholesky factors of A(r_i) (ecp/pseudo_hamiltonian.py:115-146)
@@ -215,6 +227,7 @@
     // as ordinary LINEAR ops)
     std::vector<char> ran_with_parent(ops.size(), 0);
     size_t first_op = 0;
+    const bool skip_tail = tail_now && laplacian;      // this context runs the head: the tail ops go to the float64 twin afterwards
     if (!laplacian && fused_n_ops > 0 && fused2_WT > 0 && (fused_enabled >= 2 || (fused_enabled == 1 && fused_pays(B)))) {
       rc = run_fused2(r, R, B, li);
       if (rc) return rc;
@@ -223,7 +236,8 @@
     for (size_t opi = first_op; opi < ops.size(); ++opi) {
       const dqmc_op& op = ops[opi];
       const int32_t* i = op.i;
-      if (ran_with_parent[opi]) continue;               // second layer of a chained MLP: ran with its parent
+      if (ran_with_parent[opi]) continue;
+      if (skip_tail ? in_tail[opi] != 0 : (tail_only && !in_tail[opi])) continue;               // second layer of a chained MLP: ran with its parent
       const int sid = sid_of(opi);
       const hipStream_t so = sl[sid];
       { const int rcb = before(op, sid); if (rcb) return rcb; }
@@ -256,6 +270,14 @@
             w_row += pad4(i[3 + 4 * p]);
             n_bc += i[4 + 4 * p] ? 1 : 0;
             ktot += i[3 + 4 * p];
+          }
+          if (tail_only) {          // (the twin executing a tail: pieces the float32 context wrote are read where they lie)
+            bool all32 = !src32_of.empty();
+            for (int p = 0; p < i[0] && all32; ++p) all32 = src32_of[i[1 + 4 * p]] != nullptr;
+            if (all32) {
+              a.src_f32 = 1;
+              for (int p = 0; p < i[0]; ++p) a.piece[p].src = reinterpret_cast<const real*>(src32_of[i[1 + 4 * p]]);
+            }
           }
           a.W = d_w + i[22];
           a.ldw = pad4(i[21]);
@@ -445,6 +467,7 @@
     if (dual)        // join: nothing of this evaluation may still run on another stream when the caller goes on
       for (int x = 1; x < 4; ++x) if (last_ev[x]) HIP_TRY(hipStreamWaitEvent(st, last_ev[x], 0));
     HIP_TRY(hipGetLastError());
+    if (tail_now && laplacian) return run_tail(r, R, B, logpsi, sign, e_loc, stats, stats_ld, grad, b_offset);
     return DQMC_OK;
   }
   bool timing_serial() const { return false; }

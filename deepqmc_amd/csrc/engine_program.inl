@@ -111,6 +111,62 @@
     }
   }
 
+  // The float64 tail (engine.hip, above tail_f64): the LINEAR ops that write the buffer ORBITALS reads (the backflow head),
+  // ORBITALS, SLOGDET, FINAL.  None if the program has no ORBITALS op, if a writer of that buffer is not a plain LINEAR op
+  // without residual (a chained MLP's hidden tile never reaches memory), or if a head op reads what a tail op writes.
+  void analyse_tail() {
+    const int no = (int)ops.size(), nb = (int)bufs.size();
+    k_tail = -1; tail_in.clear(); in_tail.assign(no, 0);
+    tail_written.assign(nb, 0); tail_direct.assign(nb, 0); tail_alloc.assign(nb, 0);
+    int bf = -1;
+    for (int k = 0; k < no; ++k) if (ops[k].kind == DQMC_OP_ORBITALS) bf = ops[k].i[0];
+    if (bf < 0) return;
+    std::vector<int> rd, wr;
+    int first = -1;
+    for (int k = 0; k < no; ++k) {
+      op_io(ops[k], rd, wr);
+      bool w_bf = false;
+      for (int b : wr) w_bf = w_bf || b == bf;
+      if (w_bf) {
+        if (ops[k].kind != DQMC_OP_LINEAR || ops[k].i[25] >= 0) return;
+        if (mlp_skip.size() == (size_t)no && (mlp_skip[k] || mlp_child[k] >= 0)) return;
+        in_tail[k] = 1;
+        if (first < 0) first = k;
+      } else if (ops[k].kind == DQMC_OP_ORBITALS || ops[k].kind == DQMC_OP_SLOGDET || ops[k].kind == DQMC_OP_FINAL) {
+        in_tail[k] = 1;
+      }
+    }
+    if (first <= 0) { in_tail.assign(no, 0); return; }
+    std::vector<char> head_w(nb, 0), tail_r(nb, 0), nonlin_r(nb, 0);
+    for (int k = 0; k < no; ++k) {
+      op_io(ops[k], rd, wr);
+      if (in_tail[k]) {
+        for (int b : wr) tail_written[b] = 1;
+        for (int b : rd) { tail_r[b] = 1; if (ops[k].kind != DQMC_OP_LINEAR) nonlin_r[b] = 1; }
+      } else {
+        for (int b : wr) head_w[b] = 1;
+      }
+    }
+    for (int k = 0; k < no; ++k) {               // the head must not depend on the tail; tail ops must not write head buffers
+      if (in_tail[k]) continue;
+      op_io(ops[k], rd, wr);
+      for (int b : rd) if (tail_written[b]) { in_tail.assign(no, 0); return; }
+    }
+    for (int b = 0; b < nb; ++b) {
+      if (tail_written[b] && head_w[b]) { in_tail.assign(no, 0); tail_written.assign(nb, 0); return; }
+      if (tail_r[b] && head_w[b]) { tail_in.push_back(b); tail_direct[b] = !nonlin_r[b]; }
+    }
+    // a tail LINEAR op reads its pieces either all as float32 (direct) or all from the twin's workspace
+    for (int k = 0; k < no; ++k) {
+      if (!in_tail[k] || ops[k].kind != DQMC_OP_LINEAR) continue;
+      bool all_direct = true;
+      for (int p = 0; p < ops[k].i[0]; ++p) all_direct = all_direct && tail_direct[ops[k].i[1 + 4 * p]];
+      if (!all_direct) for (int p = 0; p < ops[k].i[0]; ++p) tail_direct[ops[k].i[1 + 4 * p]] = 0;
+    }
+    for (int b = 0; b < nb; ++b) tail_alloc[b] = tail_written[b] || (tail_r[b] && head_w[b] && !tail_direct[b]);
+    k_tail = first;
+  }
+
   // Stream slots of the Laplacian pass.  Edge-stream ops (pair-compact destination) keep slot 1.  Every other op goes, in
   // program order, to a slot whose last op it depends on anyway (directly or through other ops) -- placing it there costs
   // no concurrency -- preferring the main slot, then the slot of its most recent producer, then a free one; only if
@@ -290,7 +346,8 @@
     if (s == "lane_compact") { lane_compact = value != 0; analyse_lanes(); last_B = 0; return DQMC_OK; }
     if (s == "linear_f64_split") { linear_f64_split = value; return DQMC_OK; }
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
-    if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); return DQMC_OK; }
+    if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); analyse_tail(); return DQMC_OK; }
+    if (s == "tail_f64") { tail_f64 = value; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }

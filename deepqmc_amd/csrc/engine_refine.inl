@@ -77,6 +77,81 @@
     if (!d_count && !use_score) last_refined += n_scatter;
     return DQMC_OK;
   }
+  // ---- float64 tail of a float32 forward-Laplacian pass (engine.hip, above tail_f64) ----
+  // May this (unchunked) pass of B walkers hand ops [k_tail, end) to the twin?  Creates the twin if need be.
+  bool tail_ready(int B, int TP) {
+    if constexpr (sizeof(real) == 4) {
+      if (!tail_f64 || k_tail <= 0 || fused_dbg) return false;
+      if (ensure_twin() != DQMC_OK) { g_err.clear(); return false; }      // (no float64 kernel set for this program: plain float32)
+      auto* tw = static_cast<Engine<double>*>(twin);
+      return (double)tw->ws_bytes_per_walker(TP, &tail_alloc) * (double)B <= (double)tw->ws_budget;
+    }
+    return false;
+  }
+  // what a captured pass with a tail holds besides this context's own workspace
+  const void* tail_ws(int which) const {
+    if constexpr (sizeof(real) == 4) {
+      if (!tail_now || !twin) return nullptr;
+      return which == 0 ? (const void*)static_cast<const Engine<double>*>(twin)->d_ws : (const void*)d_tail;
+    }
+    return nullptr;
+  }
+  // The head (ops [0, k_tail)) of this chunk has been enqueued on `st`: widen its live buffers into the twin's workspace,
+  // let the twin execute the tail there, narrow the results into the caller's arrays.
+  int run_tail(const real* r, const real* R, int B, real* logpsi, int32_t* sign, real* e_loc, real* stats, long stats_ld, real* grad,
+               int b_offset) {
+    if constexpr (sizeof(real) == 4) {
+      auto* tw = static_cast<Engine<double>*>(twin);
+      const int T = 3 * N + 2, TP = (T + 15) / 16 * 16, n3 = 3 * N, nR3 = 3 * sys.n_nuc;
+      auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+      const size_t o_r = 0, o_R = o_r + al(sizeof(double) * (size_t)B * n3), o_e = o_R + al(sizeof(double) * nR3),
+                   o_s = o_e + al(sizeof(double) * B), o_g = o_s + al(sizeof(double) * 6 * (size_t)B),
+                   o_l = o_g + al(sizeof(double) * (size_t)B * n3), o_sg = o_l + al(sizeof(double) * B),
+                   tot = o_sg + al(sizeof(int32_t) * B);
+      if (tot > tail_bytes) {
+        if (d_tail) { HIP_TRY(hipStreamSynchronize(st)); HIP_TRY(hipFree(d_tail)); d_tail = nullptr; tail_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&d_tail, tot));
+        tail_bytes = tot;
+      }
+      double* r64 = (double*)(d_tail + o_r); double* R64 = (double*)(d_tail + o_R); double* e64 = (double*)(d_tail + o_e);
+      double* s64 = (double*)(d_tail + o_s); double* g64 = (double*)(d_tail + o_g); double* l64 = (double*)(d_tail + o_l);
+      int32_t* sg64 = (int32_t*)(d_tail + o_sg);
+      const hipStream_t keep_st = tw->st;
+      tw->st = st;                                     // (a captured pass runs on the capture stream)
+      int rc = tw->plan(B, TP, &tail_alloc);
+      if (rc) { tw->st = keep_st; return rc; }
+      t_begin("tail", 0);
+      dqmc::launch_widen(st, (const float*)r, r64, (long)B * n3);
+      dqmc::launch_widen(st, (const float*)R, R64, (long)nR3);
+      tw->src32_of.assign(bufs.size(), nullptr);
+      for (int b : tail_in) {
+        if (tail_direct[b]) tw->src32_of[b] = (const float*)bptr(b);       // read in place by the twin's linear kernel
+        else dqmc::launch_widen(st, (const float*)bptr(b), tw->bptr(b), (long)B * bufs[b].rows * lanes_of(b, TP) * bufs[b].width);
+      }
+      t_end();
+      // the twin's k_final flags and scores for THIS context (same walker numbering: b_offset + walker of the chunk)
+      const bool k_flag = tw->flag_on; int32_t* const k_dflag = tw->d_flag; double* const k_dscore = tw->d_score;
+      const double k_thr = tw->refine_thresh; double* const k_dthr = tw->d_thresh;
+      tw->flag_on = flag_on; tw->d_flag = d_flag; tw->d_score = d_score; tw->refine_thresh = refine_thresh; tw->d_thresh = d_thresh;
+      tw->ph_skip = (e_loc == nullptr);
+      tw->tail_only = true;
+      tw->in_tail = in_tail; tw->tail_alloc = tail_alloc;      // (the twin's own analysis of the same program gives the same sets)
+      rc = tw->run_chunk(r64, R64, B, true, l64, sg64, e_loc ? e64 : nullptr, s64, (long)B, grad ? g64 : nullptr, b_offset);
+      tw->tail_only = false;
+      tw->src32_of.clear();
+      tw->ph_skip = false;
+      tw->flag_on = k_flag; tw->d_flag = k_dflag; tw->d_score = k_dscore; tw->refine_thresh = k_thr; tw->d_thresh = k_dthr;
+      tw->st = keep_st;
+      if (rc) return rc;
+      t_begin("tail", 0);
+      dqmc::launch_tail_narrow(st, B, n3, e64, s64, g64, l64, sg64, (float*)e_loc, e_loc ? (float*)stats : nullptr, stats_ld, (float*)grad,
+                               (float*)logpsi, sign);
+      t_end();
+      HIP_TRY(hipGetLastError());
+    }
+    return DQMC_OK;
+  }
+
   // error-predictor scores of the last float32 pass that flagged (host copy; walkers of that call, in order)
   int last_score_B = 0;
   int refine_scores(double* out, int n) override {

@@ -478,6 +478,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
   constexpr int HS = CHAIN ? BN + 2 : 1;                // hidden tile stride: 2 * odd -> conflict-free fragment reads
   constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
+  constexpr bool CAN32 = sizeof(real) == 8 && !SPLIT && !CHAIN;      // LinArgs::src_f32 (float32 A pieces under a float64 product)
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
   static_assert(!SPLIT || (!CHAIN && WN == 1 && 6 * NR * 16 <= BM * AS), "split groups: plain layers, one column tile per workgroup");
@@ -538,7 +539,8 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
       if (a_g[j] >= 0) {
         const int b = a_g[j] / a.nrows, rr = a_g[j] - b * a.nrows;
         const long srow = ((long)b * pc.rpw + pc.r0 + (pc.bcast ? 0 : rr)) * a.TP + a_t[j];
-        a_src[j] = pc.src + srow * pc.ld;
+        if (CAN32 && a.src_f32) a_src[j] = reinterpret_cast<const real*>(reinterpret_cast<const float*>(pc.src) + srow * pc.ld);
+        else a_src[j] = pc.src + srow * pc.ld;
       } else {
         a_src[j] = nullptr;
       }
@@ -551,7 +553,14 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 #pragma unroll
         for (int x = 0; x < BKX; ++x) {
           const int k0 = kc * BK + 16 * x + 4 * a_kq;
-          if (a_src[j] != nullptr && k0 < pc.K) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
+          if (CAN32 && a.src_f32) {
+            if (a_src[j] != nullptr && k0 < pc.K) {
+              const Vec4<float> t = *reinterpret_cast<const Vec4<float>*>(reinterpret_cast<const float*>(a_src[j]) + k0);
+              ra[j][x] = Vec4<real>{{(real)t.v[0], (real)t.v[1], (real)t.v[2], (real)t.v[3]}};
+            } else {
+              ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
+            }
+          } else if (a_src[j] != nullptr && k0 < pc.K) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
           else ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
         }
 #pragma unroll
@@ -1001,7 +1010,7 @@ template <typename real, int MR, int GPW> static void launch_nr(hipStream_t st, 
 // LDS in the epilogue.  Option "linear_f64_split" (default 1) / LinArgs::cfg_f64_split.
 template <typename real, int MRH> static bool launch_split(hipStream_t st, const LinArgs<real>& a) {
   if constexpr (sizeof(real) == 8) {
-    if (!a.cfg_f64_split) return false;
+    if (!a.cfg_f64_split || a.src_f32) return false;
     if (a.ldw > 32) launch_cfg<real, MRH, 4, -2, 1>(st, a);
     else if (a.ldw > 16) launch_cfg<real, MRH, 2, -2, 1>(st, a);
     else launch_cfg<real, MRH, 1, -2, 1>(st, a);

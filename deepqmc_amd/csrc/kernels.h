@@ -61,6 +61,10 @@ template <typename real> struct LinArgs {
   int ldw2;           // pad4(Nout of the second layer)
   const real* bias2;
   int act2;
+  // float64 launches only: the A pieces are FLOAT32 buffers (`src` points at float data, same ld / rows / lanes) that the
+  // kernel widens while it stages them -- the float64 tail of a float32 pass reads the head's activations where they lie
+  // (plain and 8- / 16- / 32- / 48- / 64-lane tiles; not the split-group and chained instances)
+  int src_f32;
   // kernel-selection switches of the calling context (dqmc_set_option "linear_bf" / "linear_bkx" / "linear_f64_split";
   // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
   // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
@@ -327,6 +331,9 @@ template <typename real>
 void launch_exchange_propose(hipStream_t st, const real* r, const int32_t* up_idx, const int32_t* down_idx, int n_up, int B, int N,
                              real* r_prop);
 void launch_read_accept(hipStream_t st, int32_t* n_accept, int B, double* acc_out);
+void launch_widen(hipStream_t st, const float* src, double* dst, long n);
+void launch_tail_narrow(hipStream_t st, int n, int n3, const double* e64, const double* st64, const double* g64, const double* lp64,
+                        const int32_t* sg64, float* e_loc, float* stats, long stats_ld, float* grad, float* logpsi, int32_t* sign);
 void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, const int32_t* count, int n, int n3,
                           int nR3, double* r64, double* R64);
 void launch_refine_scatter(hipStream_t st, const int32_t* idx, const int32_t* count, int n, int n_scatter, const double* score,

@@ -388,6 +388,43 @@ __global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restric
   if (logpsi) logpsi[b] = (float)lp64[j];
   if (sign) sign[b] = sg64[j];
 }
+// ---- float64 tail of a float32 forward-Laplacian pass (engine_refine.inl: run_tail) ----
+// widen: a float32 activation buffer (or the walker positions) into the float64 twin's workspace, four elements per thread
+__global__ void __launch_bounds__(256) k_widen(const float* __restrict__ src, double* __restrict__ dst, long n) {
+  const long e = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
+  if (e + 3 < n) {
+    const Vec4<float> v = *reinterpret_cast<const Vec4<float>*>(src + e);          // (buffers are 256-byte aligned, widths multiples of 4)
+    *reinterpret_cast<Vec2<double>*>(dst + e) = Vec2<double>{{(double)v.v[0], (double)v.v[1]}};
+    *reinterpret_cast<Vec2<double>*>(dst + e + 2) = Vec2<double>{{(double)v.v[2], (double)v.v[3]}};
+  } else {
+    for (long k = e; k < n; ++k) dst[k] = (double)src[k];
+  }
+}
+void launch_widen(hipStream_t st, const float* src, double* dst, long n) {
+  if (n < 1) return;
+  hipLaunchKernelGGL(k_widen, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+// narrow: the float64 results of the tail -> the caller's float32 arrays (walker j of the chunk; stats columns with the
+// caller's leading dimension)
+__global__ void __launch_bounds__(256) k_tail_narrow(int n, int n3, const double* __restrict__ e64, const double* __restrict__ st64,
+                                                     const double* __restrict__ g64, const double* __restrict__ lp64,
+                                                     const int32_t* __restrict__ sg64, float* __restrict__ e_loc,
+                                                     float* __restrict__ stats, long stats_ld, float* __restrict__ grad,
+                                                     float* __restrict__ logpsi, int32_t* __restrict__ sign) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (grad && e < (long)n * n3) grad[e] = (float)g64[e];
+  if (e >= n) return;
+  if (e_loc) e_loc[e] = (float)e64[e];
+  if (stats) for (int k = 0; k < 6; ++k) stats[k * stats_ld + e] = (float)st64[(long)k * n + e];
+  if (logpsi) logpsi[e] = (float)lp64[e];
+  if (sign) sign[e] = sg64[e];
+}
+void launch_tail_narrow(hipStream_t st, int n, int n3, const double* e64, const double* st64, const double* g64, const double* lp64,
+                        const int32_t* sg64, float* e_loc, float* stats, long stats_ld, float* grad, float* logpsi, int32_t* sign) {
+  const long tot = grad ? (long)n * n3 : n;
+  hipLaunchKernelGGL(k_tail_narrow, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, n, n3, e64, st64, g64, lp64, sg64, e_loc, stats,
+                     stats_ld, grad, logpsi, sign);
+}
 void launch_refine_gather(hipStream_t st, const float* r, const float* R, const int32_t* idx, const int32_t* count, int n, int n3,
                           int nR3, double* r64, double* R64) {
   long tot = (long)n * n3;

@@ -359,3 +359,76 @@ def test_return_mos_released_engines_and_numpy_spin_input():
     c = torch.stack([op(p2, torch.as_tensor(r_np[k:k + 1]), int(idx[k]))[0] for k in range(B)])
     np.testing.assert_allclose(a.numpy(), c.numpy(), rtol=1e-12)
     np.testing.assert_allclose(b.numpy(), c.numpy(), rtol=1e-12)
+
+
+def test_float64_tail_of_a_float32_pass():
+    """The float64 TAIL of a float32 forward-Laplacian pass (engine.hip, above tail_f64; engine_refine.inl: run_tail): the ops
+    from the backflow head on -- the LINEAR ops that write what ORBITALS reads, ORBITALS, SLOGDET, FINAL -- run on the float64 twin
+    for every walker of an unchunked pass, reading the float32 head's activations where they lie.  Checked here, through the
+    emulator: WHICH kernels run where (timing records of the context and of its twin), that the results are float32-class
+    results of the same quantity (against the float64 engine), that dqmc_debug_read finds the tail's buffers in the twin, that
+    a chunked pass and a context with the option off keep the plain float32 tail, and that flags / scores come out the same way."""
+    import dataclasses
+    from deepqmc_amd.params import init_params
+    from deepqmc_amd.spec import paulinet
+    h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
+    spec = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)
+    params = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    B = 16
+    r32 = synthetic_walkers(h, B, seed=9).astype(np.float32)
+    r = torch.as_tensor(r32)
+    e64 = Engine(spec, h, params, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    ref, st64, g64 = e64.local_energy(torch.as_tensor(r32.astype(np.float64)), return_grad=True)
+    orb64 = e64.debug_read('orbitals', B)
+
+    def engine(tail):
+        e = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+        e.set_option('refine', 0)
+        e.set_option('tail_f64', tail)
+        return e
+    on, off = engine(1), engine(0)
+    out = {}
+    for name, e in (('on', on), ('off', off)):
+        e.timing(True); e.timing_reset()
+        out[name] = e.local_energy(r, return_grad=True)
+        rep = e.timing_report()
+        e.timing(False)
+        n32 = {k: rep.get(k, {'launches': 0})['launches'] for k in ('orbitals', 'slogdet', 'final', 'tail')}
+        n64 = {k: rep.get('f64.' + k, {'launches': 0})['launches'] for k in ('linear', 'orbitals', 'slogdet', 'final')}
+        if name == 'on':
+            assert n32 == {'orbitals': 0, 'slogdet': 0, 'final': 0, 'tail': 2}, n32          # widen + narrow; the head stops before the backflow head
+            assert n64['orbitals'] == 1 and n64['slogdet'] == 1 and n64['final'] == 1 and n64['linear'] >= 1, n64
+        else:
+            assert n32 == {'orbitals': 1, 'slogdet': 1, 'final': 1, 'tail': 0} and not any(n64.values()), (n32, n64)
+    rel = {k: np.abs(v[0].double().numpy() - ref.numpy()) / np.maximum(1.0, np.abs(ref.numpy())) for k, v in out.items()}
+    assert np.median(rel['on']) < 5e-6 and np.median(rel['off']) < 5e-6, (rel['on'], rel['off'])      # both float32-class evaluations
+    for key in ('hamil/E_kin', 'hamil/V_el', 'hamil/V_loc'):
+        np.testing.assert_allclose(out['on'][1][key].double().numpy(), st64[key].numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(out['on'][2].double().numpy(), g64.numpy(), rtol=5e-3, atol=5e-2)
+    # the potential terms do not pass through the network: the float64 k_final gives them to float32 OUTPUT rounding
+    np.testing.assert_allclose(out['on'][1]['hamil/V_el'].double().numpy(), st64['hamil/V_el'].numpy(), rtol=2e-7)
+    # the tail's buffers live in the twin: the Slater matrices read back are float64 values built on a float32 head
+    orb_on = on.debug_read('orbitals', B)
+    assert np.abs(orb_on[:, :, 0] - orb64[:, :, 0]).max() < 1e-4 * np.abs(orb64[:, :, 0]).max()
+    assert (orb_on[:, :, 0].astype(np.float32).astype(np.float64) != orb_on[:, :, 0]).any()      # (float64 values, not float32-representable ones)
+    # a chunked pass keeps the float32 tail (the hand-over is for unchunked passes), same results as the option off
+    small = engine(1)
+    per_walker = 4 * sum(rows * 16 * width for rows, width in small.program.bufs)
+    small.set_option('ws_budget_mb', max(1, int(3.5 * per_walker / 2 ** 20)))
+    e_c, _ = small.local_energy(r)
+    if small.last_chunks()['own'] > 1:
+        np.testing.assert_array_equal(e_c.numpy(), out['off'][0].numpy())
+    # flags and scores through the twin's k_final: same count, same walkers as with a float32 tail up to round-off in the score
+    fl_on, fl_off = engine(1), engine(0)
+    for e in (fl_on, fl_off):
+        e.set_option('refine', 1); e.set_option('refine_probe', 0); e.set_option('refine_thresh', 10 ** 9)
+        e.local_energy(r)
+    s_on, s_off = fl_on.refine_scores(B), fl_off.refine_scores(B)
+    np.testing.assert_allclose(s_on, s_off, rtol=5e-2)
+    thr = int(np.sort(s_on)[B - 4]) + 1
+    fl_on.set_option('refine_thresh', thr)
+    e_ref, _ = fl_on.local_energy(r)
+    assert fl_on.last_refined() == int((s_on > thr).sum())
+    above = s_on > thr
+    np.testing.assert_allclose(e_ref.numpy()[above], ref.numpy()[above], rtol=3e-7)                   # refined walkers: the full float64 pass (the twin sees the float32-rounded geometry)
+    np.testing.assert_array_equal(e_ref.numpy()[~above], out['on'][0].numpy()[~above])                 # kept walkers: float32 head + float64 tail

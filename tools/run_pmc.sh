@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ counters of one VMC step per kernel (three passes of <= 8 SQ counters) -> gpurun_out/pmc_sq.json
+# SQ counters of one VMC step per kernel (three passes of <= 8 SQ counters) -> gpurun_out/${PMC_OUT:-pmc_sq}.json
+# (PMC_FULLNAME=1: one entry per kernel instantiation instead of per kernel family)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 ROOT=$(pwd)
 mkdir -p gpurun_out
@@ -14,11 +15,12 @@ for P in "$P1" "$P2" "$P3"; do
   k=$((k+1))
 done
 cd "$ROOT"
-python tools/pmc_sq.py gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 > gpurun_out/pmc_sq.json
+python tools/pmc_sq.py gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 > gpurun_out/${PMC_OUT:-pmc_sq}.json
 rm -f gpurun_out/pmc[123]/*kernel_trace.csv
 python - <<'PY'
 import json
-d = json.load(open('gpurun_out/pmc_sq.json'))
-for k in ('k_fused2_value', 'k_linear'):
-    if k in d: print(k, json.dumps(d[k]))
+import os
+d = json.load(open('gpurun_out/%s.json' % os.environ.get('PMC_OUT', 'pmc_sq')))
+for k in d:
+    if k.startswith(('k_fused2_value', 'k_linear', 'k_attention')): print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a.startswith(('frac_', 'valu_per', 'mfma_busy', 'launches'))}))
 PY
