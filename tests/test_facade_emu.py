@@ -115,9 +115,12 @@ def test_f64_refinement_of_ill_conditioned_walkers():
     """float32 context: walkers k_final flags (score = (|lap| + |grad|^2) / max(1, |E_loc|) x conditioning record above
     the threshold) are re-evaluated by the float64 twin; their results equal a float64 engine's (rounded to float32),
     the others stay float32.  Probe off = fixed threshold; the self-calibrating probe is exercised below."""
+    import dataclasses
+    from deepqmc_amd.spec import paulinet
     h = MolecularHamiltonian(mol=Molecule.from_name('LiH'))
-    wf32 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
-    wf64 = NeuralNetworkWaveFunction(h, 'paulinet', dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    small_net = dataclasses.replace(paulinet(), embedding_dim=32, n_interactions=1, n_determinants=4)      # (keeps the emulation short)
+    wf32 = NeuralNetworkWaveFunction(h, small_net, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    wf64 = NeuralNetworkWaveFunction(h, small_net, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     params = wf32.init(5, perturb_envelopes=0.1)
     e32, e64 = wf32.engine(params), wf64.engine(params)
     B = 6

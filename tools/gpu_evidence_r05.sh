@@ -24,4 +24,5 @@ PMC_FULLNAME=1 PMC_OUT=pmc_sq_n2 tools/run_pmc.sh --molecule N2 --ansatz fermine
 PMC_FULLNAME=1 PMC_OUT=pmc_sq_benzene tools/run_pmc.sh --molecule benzene --ansatz psiformer --walkers 256 --n-sub 10 > gpurun_out/pmc_benzene.log 2>&1
 PMC_FULLNAME=1 PMC_OUT=pmc_sq_c4h4 tools/run_pmc.sh --molecule cyclobutadiene_square --ansatz transpsiformer --walkers 512 > gpurun_out/pmc_c4h4.log 2>&1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/mfma_peak.hip -o /tmp/mfma_peak && /tmp/mfma_peak > gpurun_out/mfma_peak.txt 2>&1; rocm-smi --showclocks >> gpurun_out/mfma_peak.txt 2>&1
+find gpurun_out -type f -size +8M -delete; du -sh gpurun_out            # (gpurun merges at most 64 MiB back -- and nothing at all above that)
 tail -3 gpurun_out/smoke.log; tail -4 gpurun_out/pytest_gpu.log; grep '^{' gpurun_out/bench.log | tail -1 | cut -c1-700; tail -3 gpurun_out/traffic_eloc.log; cat gpurun_out/other_configs.txt | cut -c1-260; cat gpurun_out/mfma_peak.txt | cut -c1-220

@@ -64,9 +64,11 @@ template <int KIND, int NACC> static void run(const char* name, double flop_per_
   long long h[2] = {0, 1};
   hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost);
   const double mhz = (double)h[0] / ((double)h[1] / 100.0);                      // shader cycles per microsecond of the 100 MHz counter
-  const double cyc_per_mfma = (double)h[0] / ((double)iters * NACC * wg_per_cu);    // one SIMD issues the MFMAs of its wg_per_cu waves
-  printf("%-28s %d acc, %d waves/SIMD: %8.1f TFLOP/s  (%.2f ms)  effective shader clock %6.0f MHz, %5.1f cycles per MFMA and SIMD -> at 2400 MHz: %7.1f TFLOP/s\n",
-         name, NACC, wg_per_cu, flops / ms / 1e9, ms, mhz, cyc_per_mfma, flops / ms / 1e9 * 2400.0 / mhz);
+  // issue interval of one SIMD implied by the rate at the measured clock (1024 SIMDs).  Not the stamped wave's own cycle count: with
+  // several waves per SIMD the arbiter serves the oldest wave first, workgroup 0 finishes long before the launch does
+  const double cyc_per_mfma = flop_per_mfma * 1024.0 * mhz * 1e6 / (flops / (ms * 1e-3));
+  printf("%-28s %d acc, %d waves/SIMD: %8.1f TFLOP/s  (%.2f ms)  shader clock while it ran %6.0f MHz -> one MFMA per %5.1f cycles and SIMD\n",
+         name, NACC, wg_per_cu, flops / ms / 1e9, ms, mhz, cyc_per_mfma);
   hipFree(out); hipFree(stamps);
 }
 int main() {

@@ -16,7 +16,7 @@ for P in "$P1" "$P2" "$P3"; do
 done
 cd "$ROOT"
 python tools/pmc_sq.py gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3 > gpurun_out/${PMC_OUT:-pmc_sq}.json
-rm -f gpurun_out/pmc[123]/*kernel_trace.csv
+rm -rf gpurun_out/pmc1 gpurun_out/pmc2 gpurun_out/pmc3      # (the raw counter tables are tens of MB: gpurun merges at most 64 MiB back)
 python - <<'PY'
 import json
 import os

@@ -10,4 +10,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 cd "$ROOT"
 python tools/pmc_traffic.py $(find gpurun_out/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find gpurun_out/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1) gpurun_out/pmc_hbm_traffic.json "${WORKLOAD:-LiH/paulinet/4096/f32}"
-rm -f gpurun_out/pmc_*/*kernel_trace.csv   # keep the merge small
+rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE   # keep the merge small
