@@ -452,6 +452,7 @@ def main():
         return dt
 
     log('warm-up done; timing')
+    counters0 = eng.refine_counters()
     blocks = [timed_block(args.warmup)]
     n_blocks = args.repeats if args.repeats > 0 else max(10, int(np.ceil(args.min_seconds / max(blocks[0], 1e-6))))
     n_blocks = min(n_blocks, 2000)
@@ -466,6 +467,10 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     refined_timed = list(refined[args.warmup:]) if S == 1 and not args.overlap else []
     refine_state = eng.refine_info()
+    counters1 = eng.refine_counters()
+    # which mode the timed local-energy calls ran in (dqmc_refine_counters): mixed float32 + float64 twin, or whole batch in float64
+    refine_modes = {k: counters1[k] - counters0[k] for k in counters1}
+    refine_modes['mixed_calls'] = refine_modes['calls'] - refine_modes['direct_f64_calls']
     value = S * B * world / (elapsed / args.steps)        # every state's walkers get a local energy per step
 
     # ---- the same loop with the float64 refinement switched off (secondary figure; plain float32 arithmetic) ----
@@ -581,7 +586,7 @@ def main():
                        'refine': {-1: 'library default (1: float64 re-evaluation of flagged walkers, self-calibrated threshold)', 0: 'off',
                                   1: 'flagged walkers', 2: 'whole E_loc pass in float64'}[args.refine],
                        # what the library actually did during the timed steps (dqmc_last_refined / dqmc_refine_info)
-                       'refine_engaged': {**refine_state,
+                       'refine_engaged': {**refine_state, 'timed_calls_by_mode': refine_modes,
                                           'walkers_refined_per_step_mean': float(np.mean(refined_timed)) if refined_timed else None,
                                           'walkers_refined_per_step_max': int(np.max(refined_timed)) if refined_timed else None,
                                           'fraction_refined': float(np.mean(refined_timed)) / B if refined_timed else None}},

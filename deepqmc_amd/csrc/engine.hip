@@ -236,8 +236,12 @@ struct Engine : dqmc_ctx {
   bool ecp_defer = false;       // set while lap_refined_core runs for a call whose quadrature follows in ecp_mixed
   double ecp_w_heavy = 1e-2, ecp_w_skip = 1e-10;
   // float32 error of log|psi(r)| up to which a walker counts as ordinary ("ecp_dlog_floor_e6", in 1e-6; 0: weights alone
-  // decide, the round-4 rule): beyond it the walker's float64 bound tightens in proportion (kernels.h: EcpMixArgs::l32)
-  double ecp_dlog_floor = 1e-4;
+  // decide, the round-4 rule): beyond it the walker's float64 bound tightens in proportion (kernels.h: EcpMixArgs::l32).
+  // 3e-5 = half the median float32 error of log|psi| of these networks (6e-5).  Sweep on the MI355X (tools/ecp_sweep_b.py,
+  // profiles/r05_ecp_threshold_sweep.txt), largest E_loc error of 256 set-B / 32 set-A walkers and time per call:
+  // weights alone 1.2e-5 (one walker beyond the tolerance) / 1.7e-6; floor 1e-4: 9.8e-6 / 1.7e-6 at + 0.6 %; floor 3e-5:
+  // 3.5e-6 / 5.9e-7 at + 3 % -- the same as tightening "ecp_heavy_e6" to 3e-3 at + 6 %.
+  double ecp_dlog_floor = 3e-5;
   char* d_ecpm = nullptr;
   size_t ecpm_bytes = 0;
   size_t ecp_max_cfg = 1 << 16; // quadrature walkers per value-mode batch

@@ -291,7 +291,7 @@ int dqmc_refine_scores(dqmc_ctx* ctx, double* out, int n);
  * weight w = max_l (2l+1)|V_l(|r_i - R_a|)| calls for -- float64 psi ratios above "ecp_heavy_e6" (default 10000 = 1e-2 Ha),
  * float32 below, none below "ecp_skip_e12" (default 100 = 1e-10 Ha: the contribution is below that times the mean ratio).
  * The bound is per walker: psi(r) of every walker is evaluated by both value paths first, and where the float32
- * log|psi(r)| is off by more than "ecp_dlog_floor_e6" (default 100 = 1e-4: an ordinary float32 value of these networks) the
+ * log|psi(r)| is off by more than "ecp_dlog_floor_e6" (default 30 = 3e-5: half the median float32 error of these networks) the
  * walker's float64 bound tightens in proportion -- near a node psi(r), the denominator of all its ratios, is what float32
  * cannot resolve; a sign mismatch sends all its kept pairs to float64 (0: weights alone decide).  Without a float64 twin
  * (DQMC_E_UNSUPPORTED for this program) every kept pair runs in float32.
@@ -340,7 +340,7 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row
  * block; "attention_ncb" (-1: kernel instance per number of key tiles in float32, four-tile instance in float64);
  * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance; "ecp_mixed" (1),
- * "ecp_heavy_e6" (10000), "ecp_skip_e12" (100), "ecp_dlog_floor_e6" (100): mixed-precision non-local ECP quadrature
+ * "ecp_heavy_e6" (10000), "ecp_skip_e12" (100), "ecp_dlog_floor_e6" (30): mixed-precision non-local ECP quadrature
  * (dqmc_ecp_counts); passes of fewer than 64 walkers are never captured into graphs.
  * Removed in round 5 (each had been measured slower than the default or neutral on the MI355X and was never on; DESIGN.md
  * section 4 keeps the numbers): "refine_defer" + dqmc_refine_finish, "refine_ahead", "mlp_dual", "fused_chain",

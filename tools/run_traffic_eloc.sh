@@ -17,18 +17,23 @@ p='gpurun_out/pmc_hbm_traffic_eloc.json'
 d=json.load(open(p))
 K=d['kernels']
 skip=('k_fused2_value','k_rng','k_sampler_stats','k_tau_finalize')
-is64=lambda k: '<double' in k or k.startswith('k_refine')
-n32=sum(v['launches'] for k,v in K.items() if k.startswith('k_final<float'))
-n64=sum(v['launches'] for k,v in K.items() if k.startswith('k_final<double'))
+# passes are counted by their FIRST kernel (k_feat_en of the precision); since round 5 the float32 pass ends in float64 kernels
+# (the float64 tail: backflow head, orbitals, determinants, k_final on the twin for every walker), so the double instantiations
+# belong partly to the float32 pass and partly to the refinement twin's pass -- the split by precision below is by kernel
+# instantiation, the per-call total is what the call moves
+is64=lambda k: '<double' in k or k.startswith(('k_refine','k_widen','k_tail'))
+n32=sum(v['launches'] for k,v in K.items() if k.startswith('k_feat_en<float'))
+n64=sum(v['launches'] for k,v in K.items() if k.startswith('k_feat_en<double'))
 tot32=sum(v['hbm_bytes']*v['launches'] for k,v in K.items() if k.startswith('k_') and not k.startswith(skip) and not is64(k))
 tot64=sum(v['hbm_bytes']*v['launches'] for k,v in K.items() if k.startswith('k_') and not k.startswith(skip) and is64(k))
-d['float32_passes']=n32; d['float64_twin_passes']=n64
-d['hbm_bytes_per_float32_pass']=tot32/max(n32,1)
-d['hbm_bytes_per_twin_pass']=tot64/max(n64,1)
+d['eloc_calls']=n32; d['float64_twin_passes']=n64
+d['hbm_bytes_per_call_float32_kernels']=tot32/max(n32,1)
+d['hbm_bytes_per_call_float64_kernels']=tot64/max(n32,1)
 d['hbm_bytes_per_eloc_call']=(tot32+tot64)/max(n32,1)
-d['note_eloc']='sums over every kernel of the forward-Laplacian pass of 4096 walkers (float32 instantiations) and of its float64 refinement twin (double instantiations + gather / scatter), each divided by the number of k_final launches of that precision'
+for k in ('float32_passes','hbm_bytes_per_float32_pass','hbm_bytes_per_twin_pass'): d.pop(k, None)
+d['note_eloc']='sums over every kernel of a local-energy call on 4096 walkers, divided by the number of calls (= k_feat_en<float> launches): float32 instantiations (the head of the forward-Laplacian pass) and float64 instantiations (its float64 tail for every walker + the refinement twin over the flagged walkers + gather / scatter / widen / narrow)'
 json.dump(d,open(p,'w'),indent=1)
-print('HBM bytes per float32 E_loc pass: %.3f GB (%d passes); twin: %.3f GB (%d); per call %.3f GB' % (tot32/max(n32,1)/1e9, n32, tot64/max(n64,1)/1e9, n64, (tot32+tot64)/max(n32,1)/1e9))
+print('HBM bytes per E_loc call: %.3f GB = %.3f (float32 kernels) + %.3f (float64 kernels: tail + twin); %d calls, %d twin passes' % ((tot32+tot64)/max(n32,1)/1e9, tot32/max(n32,1)/1e9, tot64/max(n32,1)/1e9, n32, n64))
 for k,v in sorted(K.items(), key=lambda kv:-kv[1]['hbm_bytes']*kv[1]['launches'])[:14]: print('  %-50s n=%4d %8.1f MB/launch  %5.1f us' % (k[:50], v['launches'], v['hbm_bytes']/1e6, v['avg_us'] or 0))
 PY
 rm -rf gpurun_out/pmce_FETCH_SIZE gpurun_out/pmce_WRITE_SIZE
