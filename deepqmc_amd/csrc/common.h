@@ -84,7 +84,7 @@ __device__ __forceinline__ void bf_split8(const float (&a)[8], BfFrag& p0, BfFra
 
 template <typename real> struct Vec4;   // 4 consecutive reals, naturally aligned
 template <> struct __attribute__((aligned(16))) Vec4<float> { float v[4]; };
-template <> struct __attribute__((aligned(32))) Vec4<double> { double v[4]; };
+template <> struct __attribute__((aligned(16))) Vec4<double> { double v[4]; };      // (two 16-byte accesses; 32-byte alignment kept conditionally assigned prefetch registers in scratch)
 
 template <typename real> struct Vec2;   // 2 consecutive reals, naturally aligned
 template <> struct __attribute__((aligned(8))) Vec2<float> { float v[2]; };

@@ -483,10 +483,16 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
   static_assert(!SPLIT || (!CHAIN && WN == 1 && 6 * NR * 16 <= BM * AS), "split groups: plain layers, one column tile per workgroup");
   typedef typename Mfma<real>::acc_t acc_t;
-  __shared__ real As[BM * AS];
-  __shared__ real Bs[BK * BS];
-  __shared__ real Hs[CHAIN ? BM * HS : 1];
-  __shared__ real Bs2[CHAIN ? BK2 * BS2 : 1];
+  // One LDS block.  CHAIN: the hidden tile Hs ALIASES the staging tiles As / Bs -- it is written by the first layer's epilogue, when
+  // the K loop has read them for the last time (one more barrier), so the float64 chained instances need 44 KB instead of 77
+  // (three workgroups per CU, which is also what their 152 registers allow, instead of two).
+  constexpr int N_AB = BM * AS + BK * BS, N_H = CHAIN ? BM * HS : 0, N_MAIN = N_AB > N_H ? N_AB : N_H;
+  __shared__ __attribute__((aligned(32))) real smem_lin[N_MAIN + (CHAIN ? BK2 * BS2 : 0)];
+  real* const As = smem_lin;
+  real* const Bs = smem_lin + BM * AS;
+  real* const Hs = smem_lin;
+  real* const Bs2 = smem_lin + N_MAIN;
+  static_assert((BM * AS) % 4 == 0 && N_MAIN % 4 == 0, "16-byte (float) / 32-byte (double) aligned LDS tiles");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 3, wn = wave >> 2;
@@ -546,7 +552,9 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
       }
     }
     const int n_chunks = (pc.K + BK - 1) / BK;
-    Vec4<real> ra[APT][BKX], rb_[NBV];
+    Vec4<real> ra[APT][BKX];
+    real rb_[NBV][4];          // (scalars: as a conditionally assigned array of over-aligned float64 structs the prefetched weights lived in
+                               // scratch -- every chunk's load was waited for at once, stored to scratch and re-read before the LDS store)
     auto load_chunk = [&](int kc) {
 #pragma unroll
       for (int j = 0; j < APT; ++j)
@@ -568,11 +576,10 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         const int f = tid + NT * j;
         const int k = f / (BN / 4), n4 = f % (BN / 4);
         const int kk = kc * BK + k, col = col_blk0 + 4 * n4;
-        if (f < BK * BN / 4 && kk < pc.K && col < a.ldw) {
-          rb_[j] = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk) * a.ldw + col);
-        } else {
-          rb_[j] = Vec4<real>{{0, 0, 0, 0}};
-        }
+        Vec4<real> t{{0, 0, 0, 0}};
+        if (f < BK * BN / 4 && kk < pc.K && col < a.ldw) t = *reinterpret_cast<const Vec4<real>*>(a.W + (long)(w_row0 + kk) * a.ldw + col);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) rb_[j][x] = t.v[x];
       }
     };
     load_chunk(0);
@@ -591,7 +598,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
         const int f = tid + NT * j;
         if (f < BK * BN / 4) {
           const int k = f / (BN / 4), n4 = f % (BN / 4);
-          *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = rb_[j];
+          *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = Vec4<real>{{rb_[j][0], rb_[j][1], rb_[j][2], rb_[j][3]}};
         }
       }
       __syncthreads();
@@ -636,6 +643,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
       for (int x = 0; x < 4; ++x) w2r[kc][x] = t.v[x];
     }
     {
+      __syncthreads();                                      // every wave has read the last chunk of As / Bs: Hs may overwrite them
       LdsSink<real> hsink{Hs, HS};
       lin_epilogue<real, MR, NR, GPW>(h, a, bias1, a.act, a.ldw, (const real*)nullptr, 0, wm, n_groups, hsink, bx);
     }
