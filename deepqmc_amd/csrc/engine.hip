@@ -334,6 +334,9 @@ struct Engine : dqmc_ctx {
   std::vector<int32_t> ph_mask_h;
   dqmc_ctx* twin = nullptr;
   dqmc_ctx* twin_ctx() override { return twin; }
+  int no_twin = 0;        // option "no_twin" 1: this float32 context never creates its float64 twin -- ensure_twin answers like a program
+                          // without a float64 kernel set (DQMC_E_UNSUPPORTED): plain float32 everywhere (refinement off by itself,
+                          // float32 tail, float32 ECP quadrature)
   // float64 TAIL of a float32 forward-Laplacian pass (option "tail_f64", default 1; engine_refine.inl: run_tail).  The last
   // linear layer -- the backflow head whose output multiplies the envelopes into the Slater matrices -- is where a float32
   // rounding hurts most: everything after it is the ill-conditioned part of the path (inverse of A, CI cancellation), which

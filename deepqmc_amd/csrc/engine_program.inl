@@ -348,6 +348,7 @@
     if (s == "linear_bkx") { linear_bkx = value; return DQMC_OK; }      // (kernel selection of kernel_linear.hip, this context only)
     if (s == "mlp_fuse") { mlp_fuse = value; analyse_chains(); analyse_tail(); return DQMC_OK; }
     if (s == "tail_f64") { tail_f64 = value; return DQMC_OK; }
+    if (s == "no_twin") { if (value && twin) return fail(DQMC_E_ARG, "no_twin must be set before the first local-energy call creates the twin"); no_twin = value; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }

@@ -4,6 +4,7 @@
 
   int ensure_twin() {
     if (twin) return DQMC_OK;
+    if (no_twin) return fail(DQMC_E_UNSUPPORTED, "the float64 twin of this context is switched off (option no_twin)");
     auto* t = new Engine<double>();
     t->st = st; t->device = device;
     dqmc_system s2 = sys;
