@@ -277,6 +277,10 @@ struct Engine : dqmc_ctx {
   // 50 % line used to flip the mode -- and the cost of a benzene step between 166 and 207 ms -- from run to run.
   double refine_direct_enter = 0.60, refine_direct_exit = 0.45;
   int refine_direct_calls = 15;  // calls a context stays in the direct mode before it looks again (option "refine_direct_calls")
+  int refine_direct_backoff = 4; // every look that CONFIRMS the direct mode doubles the stay, at most this many times (15, 30, ... 240 calls:
+                                 // the float32 pass of such a look is thrown away -- 1/16 of ~0.4 of a benzene / C4H4 E_loc call at a fixed stay);
+                                 // option "refine_direct_backoff"
+  int direct_streak = 0;         // consecutive confirmations
   bool was_direct = false;       // the last mode decision was "direct"
 
   int twin_full_budget = 1;      // the twin's activation workspace may be as large as this context's (option "twin_full_budget")

@@ -369,6 +369,7 @@
     if (s == "refine_miss_e9") { if (value < 1) return fail(DQMC_E_ARG, "refine_miss_e9 must be >= 1"); refine_miss = 1e-9 * value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_target_e7") { if (value < 1) return fail(DQMC_E_ARG, "refine_target_e7 must be >= 1"); refine_target = 1e-7 * value; calls_since_probe = -1; return DQMC_OK; }
     if (s == "refine_direct_calls") { if (value < 0) return fail(DQMC_E_ARG, "refine_direct_calls must be >= 0"); refine_direct_calls = value; return DQMC_OK; }
+    if (s == "refine_direct_backoff") { if (value < 0 || value > 16) return fail(DQMC_E_ARG, "refine_direct_backoff must be in [0, 16]"); refine_direct_backoff = value; return DQMC_OK; }
     if (s == "refine_direct_pct") { if (value < 1 || value > 100) return fail(DQMC_E_ARG, "refine_direct_pct must be 1..100"); refine_direct_enter = 0.01 * value; if (refine_direct_exit > refine_direct_enter) refine_direct_exit = refine_direct_enter; return DQMC_OK; }
     if (s == "refine_direct_exit_pct") { if (value < 0 || value > 100) return fail(DQMC_E_ARG, "refine_direct_exit_pct must be 0..100"); refine_direct_exit = 0.01 * value; if (refine_direct_exit > refine_direct_enter) refine_direct_enter = refine_direct_exit; return DQMC_OK; }
     if (s == "refine_thresh") { if (value < 0) return fail(DQMC_E_ARG, "refine_thresh must be >= 0"); refine_thresh = (double)value; return DQMC_OK; }

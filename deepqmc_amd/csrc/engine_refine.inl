@@ -200,8 +200,15 @@
   bool mostly_flagged(long n_above, int B) {
     const double lim = was_direct ? refine_direct_exit : refine_direct_enter;
     const bool yes = B >= 16 && (double)n_above > lim * (double)B;
+    direct_streak = (yes && was_direct) ? direct_streak + 1 : 0;
     was_direct = yes;
     return yes;
+  }
+  // calls the context now stays in the direct mode: doubled by every look that confirmed it (refine_direct_backoff)
+  int direct_stay() const {
+    const int sh = direct_streak < refine_direct_backoff ? direct_streak : refine_direct_backoff;
+    const long n = (long)refine_direct_calls << (sh < 16 ? sh : 16);
+    return n > 1000000 ? 1000000 : (int)n;
   }
   int lap_refined_core_(const real* r, const real* R, int B, real* e_loc, real* stats, real* grad, real* logpsi, int32_t* sign) {
     last_refined = 0;
@@ -264,7 +271,7 @@
         if (rc) return rc;
         if (refine == 1 && mostly_flagged(n, B)) {
           // most of the batch is beyond float32: this call and the next 15 evaluate everything in float64
-          refine_all_calls = refine_direct_calls;
+          refine_all_calls = direct_stay();
           ++refine_counters[1];
           std::vector<int32_t> iota((size_t)B);
           for (int k = 0; k < B; ++k) iota[k] = k;
@@ -359,7 +366,7 @@
       if (refine == 1 && mostly_flagged(n_above, B)) {
         // most of the batch is beyond float32: the next calls go to float64 directly, and so does the rest of this one
         // (the few walkers below the threshold of such a system are not reliably predicted either)
-        refine_all_calls = refine_direct_calls;
+        refine_all_calls = direct_stay();
         ++refine_counters[1];
         for (int b = 0; b < B; ++b) if (!done[b] || score[b] <= refine_thresh) more.push_back(b);     // not yet written back
         last_refined = B - (int)more.size();

@@ -330,7 +330,8 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * refines a walker, "refine_probe" (32): calls between self-calibration probes (0: keep refine_thresh as set), "refine_sample"
  * (256; 64 until round 4): walkers of the calibration sample, "refine_direct_pct" (60) / "refine_direct_exit_pct" (45): share
  * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode, "refine_direct_calls" (15): calls it
- * stays there before a float32 pass looks again,
+ * stays there before a float32 pass looks again, "refine_direct_backoff" (4): every look that confirms the mode doubles the stay, at
+ * most this many times (15, 30, ... 240 calls),
  * "refine_target_e7" (100): relative tolerance the float32-kept walkers are to meet, in units of 1e-7; "refine_miss_e9" (100):
  * accepted share of kept walkers beyond it, in units of 1e-9 (1e-7 costs LiH / PauliNet ~27 % and N2 / FermiNet ~31 % of their
  * walkers in float64; 10000 = 1e-5 costs ~17 % / ~18 %; the 90th-percentile rule of rounds 3-4 refined 5 % and left

@@ -207,6 +207,7 @@ def test_direct_mode_hysteresis_counters_and_scores():
     eng = Engine(spec, h, params, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
     eng.set_option('refine_probe', 0)
     eng.set_option('refine_direct_calls', 1)
+    eng.set_option('refine_direct_backoff', 0)           # (the doubling of the stay is checked at the end)
     eng.set_option('refine_thresh', 10 ** 9)
     e_plain, st0 = eng.local_energy(r)
     score = eng.refine_scores(B)
@@ -250,6 +251,17 @@ def test_direct_mode_hysteresis_counters_and_scores():
     c1 = eng.refine_counters()
     assert c1['calls'] - c0['calls'] == 6 and c1['direct_f64_calls'] - c0['direct_f64_calls'] == 4 and c1['probe_calls'] == 0
     assert c1['walkers_refined'] - c0['walkers_refined'] == 10 + 4 * B + 8
+    # back-off: every float32 look that CONFIRMS the direct mode doubles the stay, "refine_direct_backoff" times at most
+    eng.set_option('refine_direct_backoff', 2)
+    eng.set_option('refine_thresh', t_hi)
+    stays = []
+    for _ in range(4):
+        eng.local_energy(r)                              # a look (float32 pass + decision)
+        left = eng.refine_info()['direct_f64_calls_left']
+        stays.append(left)
+        for _ in range(left):
+            eng.local_energy(r)                          # the direct calls of the stay
+    assert stays == [1, 2, 4, 4], stays
 
 
 @pytest.mark.parametrize('molname,ansatz', [('LiH', 'paulinet'), ('C', 'ferminet')])
