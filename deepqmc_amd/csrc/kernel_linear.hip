@@ -478,6 +478,13 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   constexpr int NBV = (BK * BN / 4 + NT - 1) / NT;      // B float4 per thread and chunk
   constexpr int HS = CHAIN ? BN + 2 : 1;                // hidden tile stride: 2 * odd -> conflict-free fragment reads
   constexpr int BN2 = 16 * NR2, BS2 = BStride<BN2>::v;
+#ifndef DQMC_FRESH_MR_MAX
+#define DQMC_FRESH_MR_MAX 3
+#endif
+  // a fresh accumulator per k chunk (below, at the MFMA loop): float32 Laplacian tiles of up to 3 row blocks per wave (<= 48 lanes: up to 15
+  // electrons; N2 / FermiNet 56.3 -> 55.0 ms per step with the 48-lane tiles included, 56.4 without).  Not the value-only rows (Metropolis sub-steps: log|psi| feeds an accept test), not the taller tiles: the second
+  // accumulator set costs them a wave of occupancy or spills (<4,4,0,2> 116 -> 128 registers + 144 spilled, <3,4,1,1> 152 -> 180)
+  constexpr bool FRESH = sizeof(real) == 4 && GPW != 0 && MR <= DQMC_FRESH_MR_MAX;
   constexpr bool CAN32 = sizeof(real) == 8 && !SPLIT && !CHAIN;      // LinArgs::src_f32 (float32 A pieces under a float64 product)
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   static_assert(!CHAIN || WN == 1, "chained layers use one column tile");
@@ -603,6 +610,19 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
       }
       __syncthreads();
       if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
+      // float32: every chunk of 16 / 32 k is summed into a FRESH accumulator and its result added to the running sum.  The MFMA rounds
+      // its accumulator once per k-step of 4, and in one long chain each of those K / 4 roundings is as large as the sum has grown;
+      // chunked, the roundings inside a chunk are relative to the chunk's partial sum and only K / 16 additions happen at full size.
+      // Measured on the MI355X (LiH / PauliNet, 4096 walkers, tools/gpu_r05_h.sh): median float32 error of E_loc 1.39e-7 -> 1.01e-7, error
+      // scale m of the refinement 1.24e-8 -> 8.7e-9, walkers re-evaluated in float64 20.7 % -> 12.6 % (tests/f32_model.py with an MFMA-chain
+      // accumulator had predicted x 0.6-0.7).  float64 passes keep the single chain.
+      acc_t part[FRESH ? MR : 1][FRESH ? NR : 1];
+      if (FRESH) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) part[FRESH ? i : 0][FRESH ? j : 0] = acc_t{0, 0, 0, 0};
+      }
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
         const int kcol = kk * 4 + (lane >> 4);
@@ -614,7 +634,18 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < NR; ++j) {
+            if (FRESH) part[FRESH ? i : 0][FRESH ? j : 0] = Mfma<real>::run(fa[i], fb[j], part[FRESH ? i : 0][FRESH ? j : 0]);
+            else acc[i][j] = Mfma<real>::run(fa[i], fb[j], acc[i][j]);
+          }
+      }
+      if (FRESH) {
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) acc[i][j][x] += part[FRESH ? i : 0][FRESH ? j : 0][x];
       }
     }
   }
@@ -707,6 +738,14 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
   constexpr int APT = MR / WN;                                  // A rows per thread and chunk (two 16-byte loads each)
   constexpr int NBI = ((BK / 2) * (BN / 4) + NT - 1) / NT;       // B items (2 k rows x 4 columns) per thread and chunk
   constexpr bool HOLD_A = MR <= NR;                              // which operand's pieces stay in registers across the other's loop
+#ifndef DQMC_BF_FRESH
+#define DQMC_BF_FRESH 1
+#endif
+  // Laplacian tiles: the nine product passes of a 32-wide k chunk go to a FRESH accumulator per block, added to the running sum once
+  // (k_linear: FRESH, same reason: nine roundings per chunk at the size of the whole sum become one).  N2 / FermiNet, 4096 walkers, same
+  // call (tools/gpu_r05_h.sh): median float32 error of E_loc 2.03e-7 -> 1.17e-7, error scale m 5.6e-9 -> 3.7e-9, walkers re-evaluated in
+  // float64 16.2 % -> 8.4 %, 56.4 -> 52.7 ms per step -- although <3,4,1,1,9> now spills 16 registers at its 168-register bound (2 before).
+  constexpr bool BF_FRESH = DQMC_BF_FRESH && NP == 9;
   static_assert(MR % WN == 0, "MR must be a multiple of WN");
   typedef Mfma<float>::acc_t acc_t;
   HIP_DYNAMIC_SHARED(char, smem_raw)
@@ -848,26 +887,39 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
         for (int j = 0; j < NR; ++j) {
           BfFrag b0, b1, b2;
           read_b(j, b0, b1, b2);
+          // the products of this chunk are summed into a fresh accumulator and added to the running sum once (k_linear: FRESH)
+          acc_t part[MR];
+#pragma unroll
+          for (int i = 0; i < MR; ++i) part[i] = BF_FRESH ? acc_t{0, 0, 0, 0} : acc[i][j];
           if (NP == 9) {
 #pragma unroll
-            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b2, acc[i][j]);
+            for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][2], b2, part[i]);
 #pragma unroll
-            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b1, acc[i][j]);
+            for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][2], b1, part[i]);
 #pragma unroll
-            for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b2, acc[i][j]);
+            for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][1], b2, part[i]);
           }
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][2], b0, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][2], b0, part[i]);
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b1, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][1], b1, part[i]);
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b2, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][0], b2, part[i]);
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][1], b0, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][1], b0, part[i]);
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b1, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][0], b1, part[i]);
 #pragma unroll
-          for (int i = 0; i < MR; ++i) acc[i][j] = mfma_bf16(fa[i][0], b0, acc[i][j]);
+          for (int i = 0; i < MR; ++i) part[i] = mfma_bf16(fa[i][0], b0, part[i]);
+#pragma unroll
+          for (int i = 0; i < MR; ++i) {
+            if (BF_FRESH) {
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[i][j][x] += part[i][x];
+            } else {
+              acc[i][j] = part[i];
+            }
+          }
           sched_fence();       // (keeps the scheduler from hoisting every column block's fragment reads: registers)
         }
       } else {
@@ -878,26 +930,38 @@ __global__ void __launch_bounds__(256 * WN, (MR == 3 && WN == 1) ? 3 : 1) k_line
         for (int i = 0; i < MR; ++i) {
           BfFrag a0, a1, a2;
           read_a(i, a0, a1, a2);
+          acc_t part[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) part[j] = BF_FRESH ? acc_t{0, 0, 0, 0} : acc[i][j];
           if (NP == 9) {
 #pragma unroll
-            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][2], acc[i][j]);
+            for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a2, fb[j][2], part[j]);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][1], acc[i][j]);
+            for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a2, fb[j][1], part[j]);
 #pragma unroll
-            for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][2], acc[i][j]);
+            for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a1, fb[j][2], part[j]);
           }
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a2, fb[j][0], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a2, fb[j][0], part[j]);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][1], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a1, fb[j][1], part[j]);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][2], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a0, fb[j][2], part[j]);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a1, fb[j][0], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a1, fb[j][0], part[j]);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][1], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a0, fb[j][1], part[j]);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma_bf16(a0, fb[j][0], acc[i][j]);
+          for (int j = 0; j < NR; ++j) part[j] = mfma_bf16(a0, fb[j][0], part[j]);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            if (BF_FRESH) {
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[i][j][x] += part[j][x];
+            } else {
+              acc[i][j] = part[j];
+            }
+          }
           sched_fence();
         }
       }

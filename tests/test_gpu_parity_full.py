@@ -471,6 +471,33 @@ def test_ecp_thresholds_hold_on_a_second_table_256():
         assert p['V_nl_abs_err_max'] < 1e-5 * np.abs(d['e_loc']).max(), (key, p)
 
 
+@pytest.mark.parametrize('name', ['benzene_psiformer_256', 'c4h4_transpsiformer_512'])
+def test_split_f64_attention_kernel_equals_the_one_wave_kernel_on_device(name):
+    """The eight-wave float64 attention kernel of the Laplacian pass (kernel_attention_mfma.hip: k_attention_mfma_split<double>, a PAIR of
+    waves per query row block; the default of every float64 pass, i.e. of the whole local energy of the attention ansatzes) against the
+    four-wave kernel it replaced (option "attention_split" 0) on the SAME walkers on the device: the float32 instance of the split kernel
+    once misbehaved on this hardware while agreeing in the emulation (engine_pass.inl, DQMC_OP_ATTENTION), so the float64 instance is
+    pinned here directly -- not only through the oracle fixtures, where a 1e-8 defect of the reference energies would pass."""
+    d, meta, h, eng = load(name)
+    r = torch.as_tensor(d['r'], device=DEV)[:128]
+    eng.set_option('refine', 2)                       # the whole pass on the float64 twin
+    out = {}
+    for split in (1, 0):
+        eng.set_option('twin.attention_split', split)
+        e, stats, grad = eng.local_energy(r, return_grad=True)
+        out[split] = (e.double().cpu().numpy(), grad.double().cpu().numpy(), stats['hamil/lap'].double().cpu().numpy())
+    ref = d['e_loc'][:128]
+    rel = np.abs(out[1][0] - out[0][0]) / np.maximum(1.0, np.abs(out[0][0]))
+    rel_o = np.abs(out[1][0] - ref) / np.maximum(1.0, np.abs(ref))
+    report(f'{name}_attention_split_vs_one_wave', {'max_rel_between_kernels': float(rel.max()), 'max_rel_to_oracle_split': float(rel_o.max()),
+                                                   'identical': bool(np.array_equal(out[1][0], out[0][0]))})
+    # (results are float32 values of a float64 pass: the two kernels sum in different orders, ~1e-13 apart before the narrowing)
+    assert rel.max() < 3e-7, rel.max()
+    assert np.abs(out[1][1] - out[0][1]).max() <= 3e-6 * max(1.0, np.abs(out[0][1]).max())
+    assert (np.abs(out[1][2] - out[0][2]) / np.maximum(1.0, np.abs(out[0][2]))).max() < 3e-7
+    assert rel_o.max() < 1e-6
+
+
 @pytest.mark.parametrize('name,ratio_max', [('lih_paulinet_4096', 0.95), ('n2_ferminet_4096', 0.80)])
 def test_float64_tail_lowers_the_float32_error_on_device(name, ratio_max):
     """The float64 tail of a float32 pass (engine.hip above tail_f64: the backflow head, envelopes x backflow, determinants and

@@ -323,7 +323,10 @@ def test_linear_layers_on_the_bf16_pipe_match_float64():
             np.testing.assert_allclose(l.numpy(), l64.numpy(), rtol=2e-5, atol=2e-5)
     finally:
         eng.set_option('linear_bf', 2)             # (process-wide switch: back to the default)
-    assert np.median(err[1]) < 5e-6 and np.median(err[1]) < 3 * np.median(err[0]) + 1e-7
+    # (geometric means: the median of twelve walkers moves by a factor of four between two float32 summation orders that are
+    # equally accurate on forty-eight)
+    gm = {bf: float(np.exp(np.mean(np.log(err[bf] + 1e-12)))) for bf in (0, 1)}
+    assert np.median(err[1]) < 5e-6 and gm[1] < 3 * gm[0] + 1e-7, (gm, np.median(err[0]), np.median(err[1]))
 
 
 def test_emu_column_tiles_share_an_xcd_mapping():
