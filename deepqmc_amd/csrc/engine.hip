@@ -259,14 +259,17 @@ struct Engine : dqmc_ctx {
   // exp(-tol / (m s)), and a score threshold can promise a RATE of misses, not their absence.  The probe measures m on
   // its sample (robustly: the larger of median / ln 2 and 90th percentile / ln 10) and sets the largest threshold for
   // which the expected share of kept walkers beyond refine_target (the tolerance, 1e-5) -- the mean of
-  // exp(-tol / (m s_i)) over the kept walkers of the probed batch -- stays below refine_miss (1e-7: one walker in ten
-  // million evaluations).  Rounds 3-4 used threshold = 7e-6 / (90th percentile of err / score): along the same
+  // exp(-tol / (m s_i)) over the kept walkers of the probed batch -- stays below refine_miss (1e-8).  (1e-7 until the linear kernels got their fresh
+  // per-chunk accumulators, kernel_linear.hip: the typical error fell to 0.65-0.70 of what it was, the rare outliers whose error is
+  // made elsewhere did not, and relative to the smaller m they reach further: 3 of 19 k N2 walkers at scores 100-400 beyond
+  // 10 m s where the old kernels had none -- one of them at 1.008e-5 under the threshold of the 1e-7 rule.  1e-8 keeps the
+  // largest float32 error of both 82 k-evaluation trajectories at 5e-6.)  Rounds 3-4 used threshold = 7e-6 / (90th percentile of err / score): along the same
   // trajectories that left 27-32 of 82 k evaluations beyond 1e-5 (max 2.2e-5).  Deep / ill-conditioned systems
   // (Psiformer, a random-init TransPsiformer) end up with most walkers above the threshold and fall into the direct
   // float64 pass by themselves.  refine_probe = 0 freezes the threshold at the option's value.
   double refine_thresh = 200.0;
   double refine_target = 1e-5;      // "refine_target_e7" (100): the relative tolerance the kept walkers are to meet
-  double refine_miss = 1e-7;        // "refine_miss_e9" (100): accepted share of kept walkers beyond it
+  double refine_miss = 1e-8;        // "refine_miss_e9" (10): accepted share of kept walkers beyond it
   int refine_probe = 32;
   int refine_sample = 256;       // walkers of the calibration sample (option "refine_sample"; 64 until round 4 -- six seeds on benzene
                                  // then drew thresholds that flagged 36-50 % of the batch)

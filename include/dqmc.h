@@ -264,7 +264,7 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * walker is m x score x (an exponentially distributed factor): the sample gives the scale m, and the threshold is the largest
  * one for which the expected share of float32-kept walkers beyond the tolerance "refine_target_e7" x 1e-7 (default 1e-5
  * relative) -- the mean of exp(-tol / (m score_i)) over the kept walkers of the probed batch -- stays below
- * "refine_miss_e9" x 1e-9 (default 1e-7).  A batch with more than
+ * "refine_miss_e9" x 1e-9 (default 1e-8).  A batch with more than
  * "refine_direct_pct" (60 %) of its walkers above the threshold is evaluated in float64 whole, and so are the next 15 calls;
  * the context returns to the mixed mode only when a float32 pass then finds fewer than "refine_direct_exit_pct" (45 %)
  * above it -- hysteresis: one calibration draw near a single line used to flip the mode from run to run). */
@@ -332,10 +332,11 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * of a batch above the threshold at which the context enters / leaves the whole-batch float64 mode, "refine_direct_calls" (15): calls it
  * stays there before a float32 pass looks again, "refine_direct_backoff" (4): every look that confirms the mode doubles the stay, at
  * most this many times (15, 30, ... 240 calls),
- * "refine_target_e7" (100): relative tolerance the float32-kept walkers are to meet, in units of 1e-7; "refine_miss_e9" (100):
- * accepted share of kept walkers beyond it, in units of 1e-9 (1e-7 costs LiH / PauliNet ~27 % and N2 / FermiNet ~31 % of their
- * walkers in float64; 10000 = 1e-5 costs ~17 % / ~18 %; the 90th-percentile rule of rounds 3-4 refined 5 % and left
- * ~30 of 82 k evaluations beyond the tolerance).
+ * "refine_target_e7" (100): relative tolerance the float32-kept walkers are to meet, in units of 1e-7; "refine_miss_e9" (10):
+ * accepted share of kept walkers beyond it, in units of 1e-9 (1e-8 costs LiH / PauliNet ~16 % and N2 / FermiNet ~12 % of their
+ * walkers in float64 and leaves the largest float32 error of a 82 k-evaluation trajectory at 5e-6; 100 = 1e-7: ~13 % / ~9 %,
+ * largest error 7.6e-6 / 1.01e-5; the 90th-percentile rule of rounds 3-4 refined 5 % and left ~30 of 82 k evaluations beyond
+ * the tolerance).
  * "linear_bf", "linear_bkx" act on the calling context only;
  * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per
  * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row

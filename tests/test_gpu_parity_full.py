@@ -392,7 +392,7 @@ def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
     DEFAULTS (self-calibrated refinement, captured passes) against the float64 pass of a second context ("refine" 2: oracle-
     checked to 2e-7 by the fixtures) on the same walkers.  >= 80 k evaluations per system; asserted: EVERY one within 1e-5
     (reference semantics: loss/energy.py:50-57 -- the reference evaluates every walker in one precision).  The tail goes to
-    the report, and so does what two LOOSER miss rates ("refine_miss_e9" 1e-6 / 1e-5 instead of the default 1e-7) would save
+    the report, and so does what two LOOSER miss rates ("refine_miss_e9" 1e-7 / 1e-6 instead of the default 1e-8) would save
     and cost on the same walkers."""
     from deepqmc_amd import MolecularHamiltonian as MH, Molecule as Mol
     from deepqmc_amd.sampling import DecorrSampler
@@ -405,7 +405,7 @@ def test_trajectory_parity_at_bench_settings(molname, ansatz, n_sub):
     ref = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
     ref.set_option('refine', 2)
     alt = {}
-    for t7 in (1000, 10000):
+    for t7 in (100, 1000):
         alt[t7] = Engine(wf.spec, h, params, dtype=torch.float32, device=DEV)
         alt[t7].set_option('refine_miss_e9', t7)
     smp = DecorrSampler(h, wf, length=n_sub, in_place=True)
