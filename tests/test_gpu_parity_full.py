@@ -498,12 +498,12 @@ def test_split_f64_attention_kernel_equals_the_one_wave_kernel_on_device(name):
     assert rel_o.max() < 1e-6
 
 
-@pytest.mark.parametrize('name,ratio_max', [('lih_paulinet_4096', 0.95), ('n2_ferminet_4096', 0.80)])
+@pytest.mark.parametrize('name,ratio_max', [('lih_paulinet_4096', 0.95), ('n2_ferminet_4096', 0.90)])
 def test_float64_tail_lowers_the_float32_error_on_device(name, ratio_max):
     """The float64 tail of a float32 pass (engine.hip above tail_f64: the backflow head, envelopes x backflow, determinants and
     E_loc on the float64 twin for every walker, the float32 head's activations read in place) ON the MI355X, refinement off:
-    the mean float32 error of E_loc against the oracle drops (measured: x 0.81 LiH / PauliNet, x 0.63 N2 / FermiNet -- the
-    scale m of the error model the score threshold is derived from); the captured pass (eager first call, capture on the
+    the mean float32 error of E_loc against the oracle drops (measured: x 0.79 LiH / PauliNet, x 0.81 N2 / FermiNet; x 0.81 and
+    x 0.63 before the linear kernels got their fresh per-chunk accumulators -- the head no longer stands out as much); the captured pass (eager first call, capture on the
     second, replays afterwards) stays bit-identical; psi signs equal the oracle's."""
     d, meta, h, eng = load(name)
     r = torch.as_tensor(d['r'], device=DEV)
