@@ -66,7 +66,7 @@ BOUNDS = {
 }
 
 
-def load(name):
+def load(name, dtype=torch.float32):
     path = os.path.join(ROOT, 'tests', 'golden', f'parity_{name}.npz')
     if not os.path.exists(path):
         pytest.skip(f'fixture {path} not generated')
@@ -84,7 +84,9 @@ def load(name):
     else:
         h = MolecularHamiltonian(mol=mol)
     tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=meta['param_seed'], perturb_envelopes=meta['perturb_envelopes'])
-    eng = Engine(spec, h, tree, dtype=torch.float32, device=DEV, norm_eps=meta['norm_eps'])
+    # (a float64 context is built at the float32-rounded geometry the fixtures were generated at -- the one a float32 context sees)
+    R = None if dtype == torch.float32 else mol.coords.astype(np.float32).astype(np.float64)
+    eng = Engine(spec, h, tree, dtype=dtype, device=DEV, norm_eps=meta['norm_eps'], R=R)
     return d, meta, h, eng
 
 
@@ -475,27 +477,32 @@ def test_ecp_thresholds_hold_on_a_second_table_256():
 def test_split_f64_attention_kernel_equals_the_one_wave_kernel_on_device(name):
     """The eight-wave float64 attention kernel of the Laplacian pass (kernel_attention_mfma.hip: k_attention_mfma_split<double>, a PAIR of
     waves per query row block; the default of every float64 pass, i.e. of the whole local energy of the attention ansatzes) against the
-    four-wave kernel it replaced (option "attention_split" 0) on the SAME walkers on the device: the float32 instance of the split kernel
-    once misbehaved on this hardware while agreeing in the emulation (engine_pass.inl, DQMC_OP_ATTENTION), so the float64 instance is
-    pinned here directly -- not only through the oracle fixtures, where a 1e-8 defect of the reference energies would pass."""
-    d, meta, h, eng = load(name)
-    r = torch.as_tensor(d['r'], device=DEV)[:128]
-    eng.set_option('refine', 2)                       # the whole pass on the float64 twin
+    four-wave kernel it replaced (option "attention_split" 0) on the SAME walkers on the device, in a float64 context so that nothing is
+    narrowed on the way out: the float32 instance of the split kernel once misbehaved on this hardware while agreeing in the emulation
+    (engine_pass.inl, DQMC_OP_ATTENTION), so the float64 instance is pinned here directly -- not only through the oracle fixtures, where
+    a 1e-8 defect of the reference energies would pass."""
+    d, meta, h, eng = load(name, dtype=torch.float64)
+    r = torch.as_tensor(d['r'][:128].astype(np.float64), device=DEV)
     out = {}
     for split in (1, 0):
-        eng.set_option('twin.attention_split', split)
+        eng.set_option('attention_split', split)
         e, stats, grad = eng.local_energy(r, return_grad=True)
-        out[split] = (e.double().cpu().numpy(), grad.double().cpu().numpy(), stats['hamil/lap'].double().cpu().numpy())
+        out[split] = (e.cpu().numpy(), grad.cpu().numpy(), stats['hamil/lap'].cpu().numpy())
     ref = d['e_loc'][:128]
     rel = np.abs(out[1][0] - out[0][0]) / np.maximum(1.0, np.abs(out[0][0]))
     rel_o = np.abs(out[1][0] - ref) / np.maximum(1.0, np.abs(ref))
     report(f'{name}_attention_split_vs_one_wave', {'max_rel_between_kernels': float(rel.max()), 'max_rel_to_oracle_split': float(rel_o.max()),
                                                    'identical': bool(np.array_equal(out[1][0], out[0][0]))})
-    # (results are float32 values of a float64 pass: the two kernels sum in different orders, ~1e-13 apart before the narrowing)
-    assert rel.max() < 3e-7, rel.max()
-    assert np.abs(out[1][1] - out[0][1]).max() <= 3e-6 * max(1.0, np.abs(out[0][1]).max())
-    assert (np.abs(out[1][2] - out[0][2]) / np.maximum(1.0, np.abs(out[0][2]))).max() < 3e-7
-    assert rel_o.max() < 1e-6
+    # (two summation orders of the same float64 arithmetic; the oracle fixture holds float32-rounded geometry: ~5e-8)
+    assert rel.max() < 1e-10, rel.max()
+    assert not np.array_equal(out[1][0], out[0][0])          # (the switch did select another kernel)
+    assert np.abs(out[1][1] - out[0][1]).max() <= 1e-9 * max(1.0, np.abs(out[0][1]).max())
+    assert (np.abs(out[1][2] - out[0][2]) / np.maximum(1.0, np.abs(out[0][2]))).max() < 1e-10
+    # against the oracle: benzene 5e-12.  (The TransPsiformer folds its nuclear stream on the host at the context's geometry; the float64
+    # context built here does not reproduce the mixed float32 / float64 geometry of the fixture -- 3e-5, recorded; its oracle parity is
+    # asserted through the float32 context's float64 pass in test_f32_parity_at_baseline_size: 5.8e-8.)
+    if not meta['ansatz'] == 'transpsiformer':
+        assert rel_o.max() < 1e-9, rel_o.max()
 
 
 @pytest.mark.parametrize('name,ratio_max', [('lih_paulinet_4096', 0.95), ('n2_ferminet_4096', 0.90)])
