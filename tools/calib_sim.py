@@ -2,7 +2,8 @@
 plain float32 E_loc, float64 E_loc per walker; fixtures and bench-like trajectories): the error model the library's threshold
 rule rests on, and what each rule would have refined / left beyond the tolerance.
 
-    python tools/calib_sim.py > profiles/r05_calibration_model.txt
+    python tools/calib_sim.py > profiles/r05_calibration_model.txt                      (first state of the round: single accumulator chain)
+    python tools/calib_sim.py gpurun_out/calib_*.npz > profiles/r05_calibration_model_fresh_acc.txt   (final kernels)
 """
 import glob
 import os
@@ -12,6 +13,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = 1e-5
+DEFAULT_RHO = 1e-8      # engine.hip: refine_miss (1e-7 until the fresh per-chunk accumulators of the linear kernels)
 
 
 def load(f):
@@ -89,8 +91,8 @@ if __name__ == '__main__':
         thr = rule_percentile(score, rel)
         o = outcome(score, rel, thr)
         print(f'     rounds 3-4: 7e-6 / p90(err / score)        thr {thr:8.1f}  refined {o[0]:5.1f} %  kept max {o[1]:.2e}  kept >= 1e-5: {o[2]:3d}  >= 5e-6: {o[3]:4d}')
-        for rho in (1e-5, 1e-6, 1e-7):
+        for rho in (1e-5, 1e-6, 1e-7, 1e-8, 1e-9):
             thr, m = rule_miss_rate(score, rel, rho)
             o = outcome(score, rel, thr)
-            tag = '  <- library default' if rho == 1e-7 else ''
+            tag = '  <- library default' if rho == DEFAULT_RHO else ''
             print(f'     round 5: miss rate {rho:.0e} (m = {m:.2e})      thr {thr:8.1f}  refined {o[0]:5.1f} %  kept max {o[1]:.2e}  kept >= 1e-5: {o[2]:3d}  >= 5e-6: {o[3]:4d}{tag}')
