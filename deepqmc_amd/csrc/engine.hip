@@ -344,7 +344,11 @@ struct Engine : dqmc_ctx {
   int no_twin = 0;        // option "no_twin" 1: this float32 context never creates its float64 twin -- ensure_twin answers like a program
                           // without a float64 kernel set (DQMC_E_UNSUPPORTED): plain float32 everywhere (refinement off by itself,
                           // float32 tail, float32 ECP quadrature)
-  // float64 TAIL of a float32 forward-Laplacian pass (option "tail_f64", default 1; engine_refine.inl: run_tail).  The last
+  // float64 TAIL of a float32 forward-Laplacian pass (option "tail_f64"; engine_refine.inl: run_tail).  DEFAULT 0 since the float32
+  // linear kernels sum every k chunk into a fresh accumulator (kernel_linear.hip: FRESH): with the accumulator chain gone the head no longer
+  // stands out (m x 0.87 / x 0.91 with the tail instead of x 0.81 / x 0.63), and the tail costs more than the walkers it saves the twin --
+  // same call, tail on / off: LiH 5.54-5.70 / 5.51 ms per step (15.4 / 17.9 % refined), N2 54.3 / 49.2 ms (10.7 / 11.5 %).  What follows is
+  // the reasoning it was built on, measured with the single accumulator chain:  The last
   // linear layer -- the backflow head whose output multiplies the envelopes into the Slater matrices -- is where a float32
   // rounding hurts most: everything after it is the ill-conditioned part of the path (inverse of A, CI cancellation), which
   // amplifies a relative error of the matrix entries by the walker's score, while the roundings of earlier layers average
@@ -358,7 +362,7 @@ struct Engine : dqmc_ctx {
   // float64 twin for EVERY walker of an unchunked Laplacian pass: the twin's linear kernel reads the head's float32
   // activations where they lie (LinArgs::src_f32), the few other inputs (the Jastrow row) are widened into the twin's
   // workspace, the twin's k_final flags / scores for this context, the results are narrowed back.
-  int tail_f64 = 1;
+  int tail_f64 = 0;
   int k_tail = -1;                   // first op of the tail; -1: this program has none (analyse_tail)
   std::vector<char> in_tail;         // per op: runs on the twin when a pass hands over its tail
   std::vector<int> tail_in;          // buffers the head writes and the tail reads ...

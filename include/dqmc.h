@@ -341,10 +341,11 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * "linear_f64_split" (float64 contexts, 1): layers over 96- / 128-lane groups with a PAIR of waves per group (two waves per
  * SIMD instead of one); "attention_split" (float64 contexts, 1): eight-wave attention kernel, a pair of waves per query row
  * block; "attention_ncb" (-1: kernel instance per number of key tiles in float32, four-tile instance in float64);
- * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance; "tail_f64" (float32 contexts, 1):
+ * "mlp_fuse" (1): row-wise two-layer MLPs in one launch where the chained kernel has an instance; "tail_f64" (float32 contexts, 0):
  * the ops from the backflow head on -- the LINEAR ops that write what ORBITALS reads, ORBITALS, SLOGDET, FINAL -- of an unchunked
  * forward-Laplacian pass run on the float64 twin for every walker, reading the float32 head's activations in place (the float32 error
- * of E_loc x 0.81 LiH / x 0.63 N2); "no_twin" (0; set before the first local-energy call): never create the float64 twin, i.e. plain
+ * of E_loc x 0.81 LiH / x 0.63 N2 with the single accumulator chain of the linear kernels, x 0.87 / x 0.91 since their fresh per-chunk
+ * accumulators -- less than the tail costs, hence off by default); "no_twin" (0; set before the first local-energy call): never create the float64 twin, i.e. plain
  * float32 everywhere, as for a program without a float64 kernel set; "ecp_mixed" (1),
  * "ecp_heavy_e6" (10000), "ecp_skip_e12" (100), "ecp_dlog_floor_e6" (30): mixed-precision non-local ECP quadrature
  * (dqmc_ecp_counts); passes of fewer than 64 walkers are never captured into graphs.
