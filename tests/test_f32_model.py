@@ -39,3 +39,34 @@ def test_float32_error_follows_node_cancellation_not_conditioning():
     missed = rel > 1e-5
     assert flagged.mean() < 0.45                                   # the criterion is selective ...
     assert (missed & ~flagged).sum() <= max(1, int(0.02 * n)), (missed & ~flagged).sum()   # ... and catches the tail
+
+
+def test_accumulator_chain_is_where_the_float32_error_is_made():
+    """Round 5 (kernel_linear.hip: FRESH / BF_FRESH).  The rounding model with the linear layers accumulating like the matrix pipe
+    (f32_model.InterpAcc: the accumulator rounded after every k-step of 4) on equilibrated LiH walkers of the BASELINE fixture:
+    ONE chain over the whole K of a layer against a fresh accumulator per 16 k -- the typical float32 error of E_loc falls to
+    0.55-0.85 of what it was (the MI355X measured x 0.73 on the median, x 0.70 on the scale m of the refinement: DESIGN section 4);
+    exact accumulation would give ~x 0.5, and the three node-feature layers (ops 13 / 27 / 41 of the PauliNet program, K = 384) carry
+    most of what is left (512 walkers: chain 8.9e-8, chunks of 16 7.0e-8, of 32 6.4e-8, node-feature layers exact 5.4e-8, all exact 4.5e-8)."""
+    from f32_model import InterpAcc
+    d = np.load(os.path.join(ROOT, 'tests', 'golden', 'parity_lih_paulinet_4096.npz'))
+    meta = json.loads(str(d['meta']))
+    mol, spec, h, prog = setup(meta['molecule'], meta['ansatz'])
+    n = 160
+    r = d['r'][:n].astype(np.float64)
+    R = mol.coords.astype(np.float32).astype(np.float64)
+    ref = d['e_loc'][:n]
+    gm = {}
+    for key, kw in (('chain', {}), ('chunk16', {'chunk': 16}), ('exact', {'chunk': 4, 'comp': True}), ('chunk16+g', {'chunk': 16, 'exact_ops': g_layers(prog)})):
+        out = InterpAcc(prog, mol.charges, geom.F32_EPS, **kw).run(r, R, True)
+        rel = np.abs(out['e_loc'] - ref) / np.maximum(1.0, np.abs(ref))
+        gm[key] = float(np.exp(np.mean(np.log(rel + 1e-13))))
+    assert 0.5 < gm['chunk16'] / gm['chain'] < 0.9, gm
+    assert gm['exact'] < 0.75 * gm['chain'], gm
+    assert gm['chunk16+g'] < 0.97 * gm['chunk16'], gm          # (x 0.77 on 512 walkers; x 0.92 on these 160)
+
+
+def g_layers(prog):
+    """LINEAR ops that write the node features x1, x2, ... (the wide concat layers of the GNN)"""
+    names = {prog.buf_names[k] for k in prog.buf_names if k.startswith('x') and k[1:].isdigit() and int(k[1:]) > 0}
+    return [k for k, op in enumerate(prog.ops) if op.kind == 3 and op.i[17] in names]
