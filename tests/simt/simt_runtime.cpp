@@ -1,6 +1,12 @@
 // Fiber scheduler of the SIMT emulation shim (test infrastructure only; see hip/hip_runtime.h).
+//
+// Context switches: on x86-64 a twelve-instruction stack switch (callee-saved registers + stack pointer) instead of swapcontext, which
+// saves and restores the signal mask with two system calls per switch -- an emulated MFMA is ~250 switches per wave, and the CPU suite
+// spent most of its time in rt_sigprocmask.  Other architectures keep ucontext.
 #include <hip/hip_runtime.h>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <vector>
 
@@ -9,15 +15,67 @@ dim3 threadIdx, blockIdx, blockDim, gridDim;
 namespace simt {
 namespace {
 constexpr size_t STACK = 256 * 1024;
+#if defined(__x86_64__)
+extern "C" void simt_switch(void** save_sp, void* load_sp);
+asm(R"(
+  .text
+  .globl simt_switch
+  .type simt_switch,@function
+simt_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+  .size simt_switch,.-simt_switch
+)");
+struct Ctx { void* sp = nullptr; };
+#else
+struct Ctx { ucontext_t uc; };
+#endif
 struct Fiber {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   bool done = false;
   dim3 tid;
   int linear = 0;
 };
 std::vector<Fiber> fibers;
-ucontext_t sched_ctx;
+Ctx sched_ctx;
+void fiber_main();
+#if defined(__x86_64__)
+inline void ctx_switch(Ctx& from, Ctx& to) { simt_switch(&from.sp, to.sp); }
+void ctx_make(Fiber& f) {
+  // initial frame: six callee-saved registers, then the "return address" of the first switch = fiber_main, entered with the stack
+  // pointer where a call would have left it (8 mod 16)
+  uintptr_t top = ((uintptr_t)f.stack + STACK) & ~(uintptr_t)15;
+  uint64_t* a = (uint64_t*)(top - 16);
+  a[0] = (uint64_t)(uintptr_t)&fiber_main;
+  a[1] = 0;
+  uint64_t* sp = a - 6;
+  for (int k = 0; k < 6; ++k) sp[k] = 0;
+  f.ctx.sp = sp;
+}
+#else
+inline void ctx_switch(Ctx& from, Ctx& to) { swapcontext(&from.uc, &to.uc); }
+void ctx_make(Fiber& f) {
+  getcontext(&f.ctx.uc);
+  f.ctx.uc.uc_stack.ss_sp = f.stack;
+  f.ctx.uc.uc_stack.ss_size = STACK;
+  f.ctx.uc.uc_link = nullptr;
+  makecontext(&f.ctx.uc, fiber_main, 0);
+}
+#endif
 int cur = -1;
 int n_threads = 0;
 const std::function<void()>* g_body = nullptr;
@@ -33,7 +91,7 @@ struct Wave {
 std::vector<Wave> waves;
 
 void yield() {
-  swapcontext(&fibers[cur].ctx, &sched_ctx);
+  ctx_switch(fibers[cur].ctx, sched_ctx);
 }
 void fiber_main() {
   (*g_body)();
@@ -45,7 +103,7 @@ void fiber_main() {
   if (live > 0 && bar_arrived == live && bar_arrived > 0) { bar_arrived = 0; ++bar_gen; }
   Wave& w = waves[f.linear >> 6];
   if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; ++w.gen; }
-  swapcontext(&f.ctx, &sched_ctx);
+  for (;;) ctx_switch(f.ctx, sched_ctx);        // (never resumed: the scheduler skips finished fibers)
 }
 void wave_sync() {
   Wave& w = waves[fibers[cur].linear >> 6];
@@ -111,11 +169,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
           f.linear = t;
           f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
           ++waves[t >> 6].live;
-          getcontext(&f.ctx);
-          f.ctx.uc_stack.ss_sp = f.stack;
-          f.ctx.uc_stack.ss_size = STACK;
-          f.ctx.uc_link = nullptr;
-          makecontext(&f.ctx, fiber_main, 0);
+          ctx_make(f);
         }
         int remaining = n_threads;
         while (remaining > 0) {
@@ -125,7 +179,7 @@ void run_grid(dim3 grid, dim3 block, const std::function<void()>& body) {
             cur = t;
             threadIdx = f.tid;
             blockIdx = dim3(bx, by, bz);
-            swapcontext(&sched_ctx, &f.ctx);
+            ctx_switch(sched_ctx, f.ctx);
             if (f.done) --remaining;
           }
         }
