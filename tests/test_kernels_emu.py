@@ -400,3 +400,36 @@ def test_emu_f64_split_group_linear(z, emb):
     e0, _, g0 = eng.local_energy(torch.as_tensor(r), return_grad=True)
     np.testing.assert_allclose(e.numpy(), e0.numpy(), rtol=1e-11, atol=1e-11)
     np.testing.assert_allclose(grad.numpy(), g0.numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_emu_48_lane_laplacian_tiles_with_fresh_accumulators():
+    """N2 (14 electrons: 48-lane groups, three row blocks per wave) through the float32 Laplacian pass of a reduced FermiNet: the tiles of
+    kernel_linear.hip that sum every k chunk into a FRESH accumulator -- `k_linear<float,3,NR,1,1>` for the shallow layers and
+    `k_linear_bf<3,NR,1,1,9>` (option "linear_bf" 2, the default: the 48-lane Laplacian tiles on the bf16 pipe; its partial accumulators per
+    column block for NR = 4, per row block for the narrow layers) -- against the float64 engine on the same walkers: E_loc, its kinetic
+    terms and the gradient of log|psi| within float32 accuracy, psi signs equal."""
+    import dataclasses
+    spec = dataclasses.replace(ferminet(), embedding_dim=64, two_particle_dim=16, n_interactions=2, n_determinants=2)
+    mol = Molecule.from_name('N2')
+    h = MolecularHamiltonian(mol=mol)
+    tree = init_params(spec, h.n_up, h.n_down, h.n_nuc, seed=5, perturb_envelopes=0.1)
+    B = 2
+    r = make_walkers(mol, h.n_elec, B)
+    r32 = r.astype(np.float32)
+    e64 = Engine(spec, h, tree, dtype=torch.float64, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    ref, sref, gref = e64.local_energy(torch.as_tensor(r32.astype(np.float64)), return_grad=True)
+    eng = Engine(spec, h, tree, dtype=torch.float32, device='cpu', lib=emu_lib(), norm_eps=geom.F32_EPS)
+    eng.set_option('refine', 0)
+    out = {}
+    for bf in (2, 0):                       # default (bf16 pipe for these tiles) / float32 MFMAs everywhere
+        eng.set_option('linear_bf', bf)
+        e, st, g = eng.local_energy(torch.as_tensor(r32), return_grad=True)
+        out[bf] = e.numpy().astype(np.float64)
+        np.testing.assert_allclose(out[bf], ref.numpy(), rtol=2e-4, atol=2e-4)       # (plain float32 on RAW Gaussian walkers: 6e-5 observed)
+        np.testing.assert_allclose(st['hamil/lap'].numpy(), sref['hamil/lap'].numpy(), rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(g.numpy(), gref.numpy(), rtol=2e-4, atol=2e-4)
+        s32, _ = eng.wf_eval(torch.as_tensor(r32))
+        s64, _ = e64.wf_eval(torch.as_tensor(r32.astype(np.float64)))
+        np.testing.assert_array_equal(s32.numpy(), s64.numpy())
+    eng.set_option('linear_bf', 2)
+    assert not np.array_equal(out[2], out[0])          # (the option did select the other kernel)
