@@ -21,6 +21,7 @@
 
 #include "../../include/dqmc.h"
 #include "kernels.h"
+#include "spec_device.h"
 
 namespace {
 
@@ -213,6 +214,10 @@ struct Engine : dqmc_ctx {
   int fused_bf = 1;              // option "fused_bf": float32 layers of the value path on the bf16 matrix pipe (three-piece split, six products; float engines only)
   std::vector<char> op_bf;       // per scheduled op: packed in the bf16 plane layout
   std::vector<std::vector<dqmc::FDesc>> plan_lists;   // the four wave lists (kept for "fused_print")
+  // plan-specialised sub-step kernel (csrc/gen/*.hip, spec_device.h): found by the hash of the program; its weight tape
+  const dqmc::SpecKernel* spec_k = nullptr;
+  uint32_t* d_tape = nullptr;
+  int fused_spec = 1;            // option "fused_spec": 0 = always the descriptor-driven kernel
   dqmc::FDesc* d_descs = nullptr;
   int32_t* d_wave_begin = nullptr;
   dqmc::FusedBuf* d_fbufs2 = nullptr;
@@ -425,6 +430,7 @@ struct Engine : dqmc_ctx {
     if (d_ops) (void)hipFree(d_ops);
     if (d_wpk_off) (void)hipFree(d_wpk_off);
     if (d_wpk) (void)hipFree(d_wpk);
+    if (d_tape) (void)hipFree(d_tape);
   }
 
   int init(const dqmc_system* s, const double* charges, const dqmc_buf* b, int nb, const dqmc_op* o, int no,
@@ -455,6 +461,7 @@ struct Engine : dqmc_ctx {
     analyse_chains();
     analyse_streams();
     analyse_tail();
+    if (sizeof(real) == 4) spec_k = dqmc::find_spec_kernel(program_hash());
     rc = set_weights(w, nw);
     if (rc) return rc;
     return build_fused_plan();

@@ -1,6 +1,17 @@
 // engine_mcmc.inl -- member functions of Engine<real>, included INSIDE the struct body by engine.hip (one translation unit):
 // Metropolis / Langevin / exchange drivers, energy records, dqmc_debug_read.
 
+  // algorithmic flops of the linear layers of one value-only evaluation, per walker (the count run_fused2 reports)
+  double substep_flops() const {
+    double flops = 0;
+    for (int k = 0; k < fused_n_ops; ++k)
+      if (ops[k].kind == DQMC_OP_LINEAR) {
+        int ktot = 0;
+        for (int p = 0; p < ops[k].i[0]; ++p) ktot += ops[k].i[3 + 4 * p];
+        flops += 2.0 * ops[k].i[20] * (double)ktot * ops[k].i[21];
+      }
+    return flops;
+  }
   int mcmc(void* r_, void* logpsi_, int32_t* sign, int32_t* age, void* tau_, const void* R_, int B, int n_sub,
            int max_age, double target, uint64_t seed, const void* noise_, const void* unif_, uint8_t* accept_out,
            double* stats7) override {
@@ -57,8 +68,21 @@
         mc.jas_width = fin.i[0] >= 0 ? bufs[fin.i[0]].width : 0;
         mc.cc_off = fin.i[1]; mc.cusp_kind = fin.i[2]; mc.al_off = fin.i[3];
         mc.same_scale = fin.f[0]; mc.anti_scale = fin.f[1];
-        rc = run_fused2(nullptr, R, B, li, &mc);
-        if (rc) return rc;
+        if (spec_k && fused_spec && d_tape) {
+          // the plan-specialised kernel of this program (csrc/gen, spec_device.h): one wave per tile of 16 / N walkers
+          if constexpr (sizeof(real) == 4) {
+            dqmc::SpecArgs sa{};
+            sa.tape = d_tape; sa.w = reinterpret_cast<const float*>(d_w); sa.R = reinterpret_cast<const float*>(R);
+            sa.B = B; sa.eps = sys.norm_eps; sa.mc = mc;
+            sa.prof = fused_dbg ? d_prof : nullptr;
+            t_begin("fused_substep", (double)B * substep_flops());
+            spec_k->launch(st, sa, (B + spec_k->walkers_per_block - 1) / spec_k->walkers_per_block);
+            t_end();
+          }
+        } else {
+          rc = run_fused2(nullptr, R, B, li, &mc);
+          if (rc) return rc;
+        }
         if (s + 1 == n_sub) {
           t_begin("mcmc", 0);
           dqmc::launch_tau_finalize<real>(st, tau, (const real*)d_tau_ring, d_nacc, s, B, target, d_acc);

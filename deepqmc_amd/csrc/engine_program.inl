@@ -321,7 +321,37 @@
     }
     HIP_TRY(hipMemcpyAsync(d_w, wtmp.data(), sizeof(real) * n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int rc_t = pack_spec_tape();
+    if (rc_t) return rc_t;
     if (fused_n_ops > 0) return pack_fused_weights();
+    return DQMC_OK;
+  }
+  // FNV-1a over the integers that define the program's structure (deepqmc_amd/codegen/substep.py: program_hash computes the
+  // same value when it generates a plan-specialised kernel)
+  uint64_t program_hash() const {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&](int32_t v) {
+      for (int k = 0; k < 4; ++k) { h = (h ^ (uint64_t)((uint32_t)v >> (8 * k) & 0xffu)) * 0x100000001b3ull; }
+    };
+    mix(sys.n_up); mix(sys.n_down); mix(sys.n_nuc); mix(sys.n_det); mix((int32_t)bufs.size()); mix((int32_t)ops.size()); mix((int32_t)n_itable);
+    for (const auto& b : bufs) { mix(b.rows); mix(b.width); }
+    for (const auto& o : ops) {
+      mix(o.kind);
+      for (int k = 0; k < 28; ++k) mix(o.i[k]);
+      for (int k = 0; k < 4; ++k) { int32_t bits; memcpy(&bits, &o.f[k], 4); mix(bits); }
+    }
+    for (int32_t v : h_itable) mix(v);
+    return h;
+  }
+  int pack_spec_tape() {
+    if constexpr (sizeof(real) == 4) {
+      if (!spec_k) return DQMC_OK;
+      std::vector<uint32_t> tape((size_t)spec_k->tape_bytes / 4);
+      dqmc::spec_pack_tape(*spec_k, reinterpret_cast<const float*>(wtmp.data()), tape.data());
+      if (!d_tape) HIP_TRY(hipMalloc((void**)&d_tape, (size_t)spec_k->tape_bytes));
+      HIP_TRY(hipMemcpyAsync(d_tape, tape.data(), (size_t)spec_k->tape_bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
     return DQMC_OK;
   }
   // ---- fused value-only evaluation (kernel_fused2.hip) ----------------------------------
@@ -350,6 +380,7 @@
     if (s == "tail_f64") { tail_f64 = value; return DQMC_OK; }
     if (s == "no_twin") { if (value && twin) return fail(DQMC_E_ARG, "no_twin must be set before the first local-energy call creates the twin"); no_twin = value; return DQMC_OK; }
     if (s == "fused_substep") { fused_substep = value; return DQMC_OK; }
+    if (s == "fused_spec") { fused_spec = value; return DQMC_OK; }
     if (s == "split_bcast") { split_bcast = value; return DQMC_OK; }
     if (s == "dual_stream") { dual_stream = value; return DQMC_OK; }
     if (s == "multi_stream") { multi_stream = value; return DQMC_OK; }

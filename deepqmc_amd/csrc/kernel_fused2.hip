@@ -25,6 +25,7 @@
 // DESIGN.md section 4) showed ~3.4 k cycles of such setup per unit against ~1.2 k cycles of MFMA work.
 #include "common.h"
 #include "kernels.h"
+#include "spec_device.h"      // fused2_det (shared with the plan-specialised sub-step kernels)
 
 #ifndef DQMC_UNIFORM
 #define DQMC_UNIFORM __attribute__((address_space(4)))   // constant address space: uniform loads are scalar
@@ -662,53 +663,6 @@ __device__ __forceinline__ void fused2_generic(const Fused2Args<real>& a, OpPtr 
     }
     default:
       break;
-  }
-}
-
-// LU with partial pivoting of one N x N Slater matrix (LDS, `real` entries as the ORBITALS op would have stored
-// them) in double registers: sign and log|det| -- the arithmetic of k_slogdet_small, value lane only.
-template <typename real, int N>
-__device__ __forceinline__ void fused2_det(const real* m, double& logabs, int& sgn) {
-  double A[N][N];
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-#pragma unroll
-    for (int j = 0; j < N; ++j) A[i][j] = (double)m[i * N + j];
-  logabs = 0.0;
-  sgn = 1;
-#pragma unroll
-  for (int p = 0; p < N; ++p) {
-    int best = p;
-    double bv = fabs(A[p][p]);
-#pragma unroll
-    for (int i = p + 1; i < N; ++i) {
-      const double v = fabs(A[i][p]);
-      if (v > bv) { bv = v; best = i; }
-    }
-#pragma unroll
-    for (int i = p + 1; i < N; ++i) {
-      const bool sw = (best == i);
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        const double a0 = A[p][j], a1 = A[i][j];
-        A[p][j] = sw ? a1 : a0; A[i][j] = sw ? a0 : a1;
-      }
-    }
-    if (best != p) sgn = -sgn;
-    const double piv = A[p][p];
-    logabs += log(fabs(piv));
-    if (piv < 0) sgn = -sgn;
-    if (piv == 0) sgn = 0;
-    const double ip = 1.0 / piv;
-#pragma unroll
-    for (int j = 0; j < N; ++j) A[p][j] *= ip;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      if (i == p) continue;
-      const double f = A[i][p];
-#pragma unroll
-      for (int j = 0; j < N; ++j) A[i][j] -= f * A[p][j];
-    }
   }
 }
 
