@@ -27,8 +27,18 @@ def main(argv):
     gen_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'csrc', 'gen')
     os.makedirs(gen_dir, exist_ok=True)
     rc = 0
-    for (name, mol_name, ansatz) in TARGETS:
-        src = generate(name, target_program(mol_name, ansatz))
+    targets = [(n, m, a, {}) for (n, m, a) in TARGETS]
+    # development: DQMC_CODEGEN_VARIANTS="suffix:key=value,key=value;..." adds variants of the FIRST target (same program hash;
+    # the library picks one by DQMC_SPEC_VARIANT=<name>); never committed
+    for item in filter(None, os.environ.get('DQMC_CODEGEN_VARIANTS', '').split(';')):
+        suffix, _, kv = item.partition(':')
+        opts = {}
+        for pair in filter(None, kv.split(',')):
+            k_, _, v_ = pair.partition('=')
+            opts[k_] = tuple(int(x) for x in v_.split('/')) if '/' in v_ else (int(v_) if v_.lstrip('-').isdigit() else v_)
+        targets.append((f'{TARGETS[0][0]}__{suffix}', TARGETS[0][1], TARGETS[0][2], opts))
+    for (name, mol_name, ansatz, opts) in targets:
+        src = generate(name, target_program(mol_name, ansatz), **opts)
         path = os.path.join(gen_dir, f'substep_{name}.hip')
         old = open(path).read() if os.path.exists(path) else None
         if check:
@@ -41,7 +51,7 @@ def main(argv):
             print(f'wrote {path} ({len(src.splitlines())} lines)')
         else:
             print(f'{path}: up to date')
-    inc = ''.join(f'DQMC_SPEC_KERNEL({name})\n' for (name, _, _) in TARGETS)
+    inc = ''.join(f'DQMC_SPEC_KERNEL({name})\n' for (name, _, _, _) in targets)
     ipath = os.path.join(gen_dir, 'spec_list.inc')
     old = open(ipath).read() if os.path.exists(ipath) else None
     if old != inc:

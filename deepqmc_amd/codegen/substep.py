@@ -32,7 +32,17 @@ OP_ORBITALS, OP_SLOGDET, OP_FINAL, OP_ATTENTION, OP_CONST = 8, 9, 10, 11, 12
 
 STAGE_FRAGS = 16          # 1 KB fragments per ring stage
 RING = 3
-PF = 6                    # tape fragments read ahead of their first use
+DEFAULTS = dict(
+    pf=6,                 # tape fragments read ahead of their first use
+    fold_tanh=1,          # 1: the factor 2 log2(e) of tanh(x) = 1 - 2 / (1 + exp2(x 2 log2 e)) is folded into the packed weights and bias
+    barrier='asm',       # 'sync': __syncthreads() per ring stage; 'asm': s_waitcnt lgkmcnt(k) + s_barrier (the wave's own ring
+                          #   stores are older than its last k LDS reads: no drain of the prefetched fragments)
+    wpos=(1, 4, 7, 9),    # fragment positions inside a stage at which a quarter of the next stage is stored / the one after requested
+    lazy_ring=1,          # 1: the first ring stage is stored and awaited at the first tape read, not in the prologue
+    waves=4,              # waves (= tiles of 4 walkers) per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
+    sched='',             # -amdgpu-sched-strategy of the translation unit ('' = the compiler's default)
+    group_barrier=1,      # 1: __builtin_amdgcn_sched_barrier(0) in front of every batch of tape reads
+)
 N_OP_I = 28
 
 
@@ -90,8 +100,13 @@ class GBuf:
 
 
 class Gen:
-    def __init__(self, name, n_up, n_down, n_nuc, n_det, bufs, ops, itable):
+    def __init__(self, name, n_up, n_down, n_nuc, n_det, bufs, ops, itable, **opts):
         self.name = name
+        self.opt = dict(DEFAULTS)
+        for k_, v_ in opts.items():
+            if k_ not in self.opt:
+                raise KeyError(k_)
+            self.opt[k_] = v_
         self.n_up, self.n_down, self.n_nuc, self.K = n_up, n_down, n_nuc, n_det
         self.N = n_up + n_down
         self.bufs, self.ops, self.itable = bufs, ops, [int(v) for v in itable]
@@ -123,18 +138,18 @@ class Gen:
         return f'{p}{self.uid}'
 
     # ---- tape ----
-    def tape_triple(self, w_off, ldw, col0, ncol, rows32):
+    def tape_triple(self, w_off, ldw, col0, ncol, rows32, scale=1.0):
         assert len(rows32) == 32
-        self.entries.append(dict(kind=0, w_off=w_off, ldw=ldw, col0=col0, ncol=ncol, map=len(self.maps)))
+        self.entries.append(dict(kind=0, w_off=w_off, ldw=ldw, col0=col0, ncol=ncol, map=len(self.maps), scale=scale))
         self.maps.extend(rows32)
         f = self.n_frag
         self.n_frag += 3
         self.frag_kind += [0, 0, 0]
         return f
 
-    def tape_gather(self, idx256):
+    def tape_gather(self, idx256, scale=1.0):
         assert len(idx256) == 256
-        self.entries.append(dict(kind=1, w_off=0, ldw=0, col0=0, ncol=0, map=len(self.maps)))
+        self.entries.append(dict(kind=1, w_off=0, ldw=0, col0=0, ncol=0, map=len(self.maps), scale=scale))
         self.maps.extend(idx256)
         f = self.n_frag
         self.n_frag += 1
@@ -427,6 +442,7 @@ class Gen:
                 raise Unsupported('residual source without f32 registers')
         self.c(f'// op {k} LINEAR -> buffer {dst}: {len(chunks)} k-chunks x {nb} blocks x {len(rbs)} row block(s), act {act}' + (f', residual {res}' if res >= 0 else ''))
         tag = f'L{k}'
+        wscale = 2.8853900817779268 if (act == 1 and self.opt['fold_tanh']) else 1.0      # 2 log2(e): tanh(x) = 1 - 2 / (1 + 2^(x 2 log2 e))
         # ---- bias fragments ----
         bias_frag = []
         if bias_off >= 0:
@@ -438,7 +454,7 @@ class Gen:
                             col = 16 * bb + 4 * gq + s
                             if col < nout:
                                 idx[(bb - f0) * 16 + gq * 4 + s] = bias_off + col
-                bias_frag.append(self.tape_gather(idx))
+                bias_frag.append(self.tape_gather(idx, wscale))
         dual = nb * len(rbs) == 1       # a lone accumulator would be one dependency chain: split it into small and large terms
         for rb in rbs:
             self.c(f'f32x4 {tag}b_{rb}[{nb}];' + (f' f32x4 {tag}s_{rb}[{nb}];' if dual else ''))
@@ -456,8 +472,10 @@ class Gen:
         # ---- products: chunk outer, blocks inner in pairs; the six products of a block (small terms first) alternate with
         # those of its partner, so consecutive MFMAs never share an accumulator ----
         prods = [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]      # (weight plane, activation plane)
-        for ch in chunks:
+        for ci, ch in enumerate(chunks):
             ops_b = {}
+            if len(chunks) * nb >= 64:
+                self.stamp(f'op {k} chunk {ci}')
             if ch[0] == 'rep':
                 _, group, rows32 = ch
                 for rb in rbs:
@@ -482,13 +500,15 @@ class Gen:
                 fr = {}
                 for bb in grp:
                     ncol = max(0, min(16, nout - 16 * bb))
-                    fr[bb] = self.tape_triple(w_off, ldw, 16 * bb, ncol, rows32)
+                    fr[bb] = self.tape_triple(w_off, ldw, 16 * bb, ncol, rows32, wscale)
                 self.use(fr[grp[-1]] + 2)
                 for (wp, xp) in prods:
                     for bb in grp:
                         for rb in rbs:
                             acc = f'{tag}s_{rb}[{bb}]' if (dual and wp + xp == 2) else f'{tag}b_{rb}[{bb}]'
                             self.c(f'{acc} = mfma_bf16(t{fr[bb] + wp}, {ops_b[rb][xp]}, {acc});')
+        if len(chunks) * nb >= 64:
+            self.stamp(f'op {k} epilogue')
         # ---- epilogue ----
         scale = '0.70710678118654752440f' if normalize else None
         for rb in rbs:
@@ -498,7 +518,7 @@ class Gen:
                 for s in range(4):
                     e = f'({tag}s_{rb}[{bb}][{s}] + {tag}b_{rb}[{bb}][{s}])' if dual else f'({tag}b_{rb}[{bb}][{s}])'
                     if act == 1:
-                        e = f'tanh_value{e}'
+                        e = f'tanh_scaled{e}' if wscale != 1.0 else f'tanh_value{e}'
                     elif act == 2:
                         e = f'silu_value{e}'
                     if gres is not None:
@@ -756,6 +776,7 @@ class Gen:
         out: List[str] = []
         A = out.append
         kname = f'k_substep_{self.name}'
+        A('// hipcc-flags:' + (f' -mllvm -amdgpu-sched-strategy={self.opt["sched"]}' if self.opt['sched'] else ''))
         A(f'// GENERATED by deepqmc_amd/codegen/substep.py for program hash 0x{self.hash:016x} -- do not edit; regenerate with')
         A('//   python -m deepqmc_amd.codegen')
         A('// One Metropolis sub-step (propose -> psi -> accept) of a tile of 4 walkers per wave, activations in registers, weights from')
@@ -765,24 +786,31 @@ class Gen:
         A('namespace dqmc {')
         A('namespace {')
         A('using namespace dqmc::spec;')
-        A(f'template <bool PROF> __global__ void __launch_bounds__(256) {kname}(const SpecArgs a) {{')
+        nw = self.opt['waves']
+        nthr = 64 * nw
+        npc = (STAGE_FRAGS * 64) // nthr      # 16-byte pieces per thread and ring stage
+        wpos = list(self.opt['wpos'])[:npc] if len(self.opt['wpos']) >= npc else list(self.opt['wpos'])
+        if len(wpos) != npc:
+            raise ValueError('wpos must name one position per piece')
+        A(f'template <bool PROF> __global__ void __launch_bounds__({nthr}) {kname}(const SpecArgs a) {{')
         A('  HIP_DYNAMIC_SHARED(char, smem_raw)')
         A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
         A('  const int c = lane & 15, g = lane >> 4, wl = c >> 2, el = c & 3;')
         A('  (void)wl;')
-        A('  const long bw = (long)blockIdx.x * 16 + wave * 4 + (c >> 2);      // this lane\'s walker')
+        A(f'  const long bw = (long)blockIdx.x * {4 * nw} + wave * 4 + (c >> 2);      // this lane\'s walker')
         A('  const bool live = bw < a.B;')
         A('  const long bc = live ? bw : (long)a.B - 1;')
         A('  const char* ring_lane = smem_raw + lane * 16;')
         A('  const char* ring_g = smem_raw + g * 16;')
         A('  V16* ring_t = reinterpret_cast<V16*>(smem_raw) + tid;')
-        A('  const V16* tape = reinterpret_cast<const V16*>(a.tape) + tid;')
+        A(f'  const TapeRsrc tape = tape_rsrc(a.tape, {tape_bytes});')
+        A('  const int tid16 = tid * 16;')
         A('  const bool stamp_ = PROF && a.prof != nullptr && blockIdx.x == 0 && lane == 0;')
         A('  if (stamp_) a.prof[wave * 256] = clock64();')
         A('  // ring prologue: stage 0 -> LDS, stage 1 -> registers')
-        A('  V16 rq0, rq1, rq2, rq3;')
-        for q in range(4):
-            A(f'  rq{q} = tape[{q * 256}];')
+        A('  V16 ' + ', '.join(f'rq{q}' for q in range(npc)) + ';')
+        for q in range(npc):
+            A(f'  rq{q} = tape_load<{q * nthr * 16}>(tape, tid16);')
         # sampler state + proposal while the first stage is in flight
         A('  // step size of this sub-step from the previous one\'s acceptance (the arithmetic of k_tau_update)')
         A('  float tau;')
@@ -810,25 +838,40 @@ class Gen:
         A('  const float u_b = reinterpret_cast<const float*>(a.mc.unif)[bc];')
         A('  const int age_b = a.mc.age[bc];')
         A('  const float px = __shfl(rp, c, 64), py = __shfl(rp, c + 16, 64), pz = __shfl(rp, c + 32, 64);')
-        for q in range(4):
-            A(f'  ring_t[{q * 256}] = rq{q};')
-        if n_stage > 1:
-            for q in range(4):
-                A(f'  rq{q} = tape[{STAGE_FRAGS * 64 + q * 256}];')
-        A('  __syncthreads();')
+        def ring_start():
+            for q in range(npc):
+                A(f'  ring_t[{q * nthr}] = rq{q};')
+            if n_stage > 1:
+                for q in range(npc):
+                    A(f'  rq{q} = tape_load<{(STAGE_FRAGS * 64 + q * nthr) * 16}>(tape, tid16);')
+            A('  __syncthreads();')
+        started = False
+        if not self.opt['lazy_ring']:
+            ring_start(); started = True
         # body with the tape reads hoisted PF fragments ahead
         emitted = 0
 
+        # LDS reads a wave issues between its last ring store of a stage and the barrier that ends the stage
+        def reads_after_last_store(s):
+            return sum(1 for f2 in range(s * STAGE_FRAGS + wpos[-1], min(self.n_frag, (s + 1) * STAGE_FRAGS)) if self.frag_kind[f2] == 0)
+
         def emit_read(f):
+            nonlocal started
+            if not started:
+                ring_start(); started = True
             s, o = divmod(f, STAGE_FRAGS)
             if o == 0 and s >= 1:
-                A('  __syncthreads();')
-            if o % 4 == 2:
-                q = o // 4
+                kk = min(6, reads_after_last_store(s - 1))
+                if self.opt['barrier'] == 'asm' and kk >= 1:
+                    A(f'  ring_barrier<{kk}>();')
+                else:
+                    A('  __syncthreads();')
+            if o in wpos:
+                q = wpos.index(o)
                 if s + 1 < n_stage:
-                    A(f'  ring_t[{((s + 1) % RING) * STAGE_FRAGS * 64 + q * 256}] = rq{q};')
+                    A(f'  ring_t[{((s + 1) % RING) * STAGE_FRAGS * 64 + q * nthr}] = rq{q};')
                 if s + 2 < n_stage:
-                    A(f'  rq{q} = tape[{(s + 2) * STAGE_FRAGS * 64 + q * 256}];')
+                    A(f'  rq{q} = tape_load<{((s + 2) * STAGE_FRAGS * 64 + q * nthr) * 16}>(tape, tid16);')
             if self.frag_kind[f] == 0:
                 A(f'  const BfFrag t{f} = ld_frag(ring_lane + {self.lds_off(f)});')
         n_stamp = 0
@@ -839,7 +882,9 @@ class Gen:
                 self.stamp_labels.append(v)
                 A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp}] = clock64();      // before {v}')
             elif kind == 'u':
-                target = min(self.n_frag, int(v) + 1 + PF)
+                target = min(self.n_frag, int(v) + 1 + self.opt['pf'])
+                if self.opt['group_barrier'] and emitted < target:
+                    A('  __builtin_amdgcn_sched_barrier(0);')
                 while emitted < target:
                     emit_read(emitted)
                     emitted += 1
@@ -873,12 +918,12 @@ class Gen:
         A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp + 1}] = clock64();')
         A('}')
         A(f'void launch_{self.name}(hipStream_t st, const SpecArgs& a, int n_blocks) {{')
-        A(f'  if (a.prof) hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<true>), dim3((unsigned)n_blocks), dim3(256), {lds_bytes}, st, a);')
-        A(f'  else hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<false>), dim3((unsigned)n_blocks), dim3(256), {lds_bytes}, st, a);')
+        A(f'  if (a.prof) hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<true>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
+        A(f'  else hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<false>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
         A('}')
         A(f'const SpecTapeEntry entries_{self.name}[] = {{')
         for e in self.entries:
-            A(f'  {{{e["kind"]}, {e["w_off"]}, {e["ldw"]}, {e["col0"]}, {e["ncol"]}, {e["map"]}}},')
+            A(f'  {{{e["kind"]}, {e["w_off"]}, {e["ldw"]}, {e["col0"]}, {e["ncol"]}, {e["map"]}, {e["scale"]!r}f}},')
         A('};')
         A(f'const int32_t maps_{self.name}[] = {{')
         for k in range(0, len(self.maps), 32):
@@ -887,14 +932,14 @@ class Gen:
         A(f'const char* const stamps_{self.name} = "' + '|'.join(self.stamp_labels) + '";')
         A('}  // namespace')
         A(f'const SpecKernel* spec_kernel_{self.name}() {{')
-        A(f'  static const SpecKernel k = {{0x{self.hash:016x}ull, "{self.name}", 16, {lds_bytes}, {tape_bytes}, {len(self.entries)}, entries_{self.name}, maps_{self.name}, launch_{self.name}, stamps_{self.name}}};')
+        A(f'  static const SpecKernel k = {{0x{self.hash:016x}ull, "{self.name}", {4 * nw}, {lds_bytes}, {tape_bytes}, {len(self.entries)}, entries_{self.name}, maps_{self.name}, launch_{self.name}, stamps_{self.name}}};')
         A('  return &k;')
         A('}')
         A('}  // namespace dqmc')
         return '\n'.join(out) + '\n'
 
 
-def generate(name, program) -> str:
+def generate(name, program, **opts) -> str:
     """HIP source of the specialised sub-step kernel of `program` (deepqmc_amd.program.Program)."""
-    g = Gen(name, program.n_up, program.n_down, program.n_nuc, program.spec.n_determinants, program.bufs, program.ops, program.itable)
+    g = Gen(name, program.n_up, program.n_down, program.n_nuc, program.spec.n_determinants, program.bufs, program.ops, program.itable, **opts)
     return g.source()

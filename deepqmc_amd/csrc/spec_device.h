@@ -77,6 +77,45 @@ __device__ __forceinline__ BfFrag ld_frag(const char* p) {
   return f;
 }
 
+// 16 bytes of the weight tape per lane: a buffer load whose constant part travels in a scalar register (no address arithmetic
+// on the vector pipe; a flat global_load needs two 64-bit VALU adds per constant offset beyond 4 KB).
+struct TapeRsrc {
+#if defined(__HIPCC__)
+  __amdgpu_buffer_rsrc_t rs;
+#else
+  const char* base;
+#endif
+};
+__device__ __forceinline__ TapeRsrc tape_rsrc(const void* tape, int bytes) {
+  TapeRsrc t;
+#if defined(__HIPCC__)
+  t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(tape), 0, bytes, 0x00020000);
+#else
+  t.base = reinterpret_cast<const char*>(tape);
+#endif
+  return t;
+}
+template <int OFF> __device__ __forceinline__ V16 tape_load(const TapeRsrc& t, int lane_bytes) {
+#if defined(__HIPCC__)
+  typedef u32 u4_ __attribute__((ext_vector_type(4)));
+  const u4_ v = __builtin_amdgcn_raw_buffer_load_b128(t.rs, lane_bytes, OFF, 0);
+  return __builtin_bit_cast(V16, v);
+#else
+  return *reinterpret_cast<const V16*>(t.base + OFF + lane_bytes);
+#endif
+}
+
+// Barrier between two stages of the weight ring.  A wave's own ring stores are older than its last K LDS reads (the generator
+// places them so), LDS operations complete in order, so "at most K outstanding" means the stores have landed; the prefetched
+// fragment reads stay in flight across the barrier (__syncthreads() would drain them: s_waitcnt lgkmcnt(0)).
+template <int K> __device__ __forceinline__ void ring_barrier() {
+#if defined(__HIPCC__)
+  asm volatile("s_waitcnt lgkmcnt(%0)\n\ts_barrier" ::"n"(K) : "memory");
+#else
+  __syncthreads();
+#endif
+}
+
 // v from lane (l & ~3) | P[l & 3] of the same 4-lane quad
 template <int P0, int P1, int P2, int P3> __device__ __forceinline__ float quad_perm(float v) {
 #if defined(__HIPCC__)
@@ -96,6 +135,8 @@ __device__ __forceinline__ float tanh_value(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
   return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
+// the same with the factor 2 log2(e) already in the argument (folded into the layer's packed weights and bias)
+__device__ __forceinline__ float tanh_scaled(float y) { return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(y) + 1.0f), 1.0f); }
 __device__ __forceinline__ float silu_value(float v) { return v / (1 + r_exp<float>(-v)); }
 
 // two floats -> their three bf16 pieces, packed (low half = a, high half = b); the residuals are exact
@@ -126,6 +167,7 @@ struct SpecTapeEntry {
   int32_t kind;
   int32_t w_off, ldw, col0, ncol;
   int32_t map;              // kind 0: first of 32 ints in `maps`; kind 1: first of 256 ints in `maps`
+  float scale;              // every value is multiplied by this before it is split / stored (tanh layers: 2 log2 e)
 };
 struct SpecKernel {
   uint64_t hash;            // of the program it was generated from (engine.hip: program_hash)

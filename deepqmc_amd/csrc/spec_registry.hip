@@ -2,6 +2,7 @@
 // deepqmc_amd/codegen) and the host-side packer of their weight tapes.
 #include "spec_device.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace dqmc {
@@ -18,9 +19,15 @@ static const SpecGetter kSpecKernels[] = {
     nullptr};
 
 const SpecKernel* find_spec_kernel(uint64_t hash) {
-  for (const SpecGetter* k = kSpecKernels; *k; ++k)
-    if ((*k)()->hash == hash) return (*k)();
-  return nullptr;
+  const char* want = getenv("DQMC_SPEC_VARIANT");      // development: several generated variants of one program
+  const SpecKernel* first = nullptr;
+  for (const SpecGetter* k = kSpecKernels; *k; ++k) {
+    const SpecKernel* sk = (*k)();
+    if (sk->hash != hash) continue;
+    if (!first) first = sk;
+    if (want && strcmp(want, sk->name) == 0) return sk;
+  }
+  return first;
 }
 
 // piece pl (0..2) of the three-bf16 split of a float (round to nearest even, exact residuals: common.h bf_split8)
@@ -52,7 +59,7 @@ void spec_pack_tape(const SpecKernel& k, const float* w, uint32_t* tape) {
             uint32_t word = 0;
             for (int h = 0; h < 2; ++h) {
               const int row = map[8 * g + 2 * j + h];
-              const float v = (row >= 0 && c < t.ncol) ? w[(size_t)t.w_off + (size_t)row * t.ldw + t.col0 + c] : 0.0f;
+              const float v = (row >= 0 && c < t.ncol) ? w[(size_t)t.w_off + (size_t)row * t.ldw + t.col0 + c] * t.scale : 0.0f;
               word |= (uint32_t)bf16_piece(v, pl) << (16 * h);
             }
             f[lane * 4 + j] = word;
@@ -63,7 +70,7 @@ void spec_pack_tape(const SpecKernel& k, const float* w, uint32_t* tape) {
     } else {
       uint32_t* f = tape + frag * 256;
       for (int q = 0; q < 256; ++q) {
-        const float v = map[q] >= 0 ? w[map[q]] : 0.0f;
+        const float v = map[q] >= 0 ? w[map[q]] * t.scale : 0.0f;
         memcpy(f + q, &v, 4);
       }
       frag += 1;

@@ -25,7 +25,9 @@ out = np.zeros(1024)
 eng._check(eng.lib.dqmc_debug_read(eng._ctx, -3, out.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), out.size))
 stp = out.reshape(4, 256)
 ops = eng.program.ops
-labels = ['prologue'] + [f'op {k} kind {op.kind} {op.note[-40:]}' for k, op in enumerate(ops[:-3])] + ['tail (slater, det, CI, cusp)', 'accept']
+from deepqmc_amd.codegen.substep import Gen
+g_ = Gen('x', eng.program.n_up, eng.program.n_down, eng.program.n_nuc, eng.program.spec.n_determinants, eng.program.bufs, eng.program.ops, eng.program.itable); g_.source()
+labels = ['prologue'] + g_.stamp_labels
 t0 = stp[:, 0].min()
 for w in range(4):
     row = stp[w]; n = int((row > 0).sum())
