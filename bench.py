@@ -510,12 +510,17 @@ def main():
                  'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + determinants + '
                                   'accept; float32 layers as v_mfma_f32_16x16x32_bf16 x6 on three-piece bf16 splits of the operands, '
                                   'shallow layers v_mfma_f32_16x16x4_f32)'}
+        spec_name = eng.substep_kernel() if hasattr(eng, 'substep_kernel') else ''
+        if spec_name:
+            names['fused_substep'] = (f'{spec_name} (plan-specialised sub-step kernel, deepqmc_amd/csrc/gen: one wave per tile of 4 walkers, activations '
+                                      'in registers, weights streamed through an LDS ring; float32 layers as v_mfma_f32_16x16x32_bf16 x6 on '
+                                      'three-piece bf16 splits)')
         cands = {k: rep[k] for k in names if k in rep and rep[k]['ms'] > 0}
         dom = max(cands, key=lambda k: cands[k]['ms']) if cands else 'linear'
         lin = rep.get(dom, {'ms': 0.0, 'launches': 0, 'flops': 0.0})
         total_ms = sum(v['ms'] for v in rep.values()) or 1.0       # (float32 context + its float64 twin)
         achieved = lin['flops'] / (lin['ms'] * 1e-3) / 1e12 if lin['ms'] > 0 else 0.0
-        traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused2_value', 'fused_substep': 'k_fused2_value'}[dom],
+        traffic, traffic_src = committed_traffic({'linear': 'k_linear', 'fused_psi': 'k_fused2_value', 'fused_substep': (spec_name.split('<')[0] if spec_name else 'k_fused2_value')}[dom],
                                                  f'{args.molecule}/{args.ansatz}/{B}/{args.dtype}')
         roofline = {
             'bound': 'mfma', 'kernel': names[dom],

@@ -45,6 +45,7 @@ SIGNATURES = [
     ('dqmc_last_chunks', c_int, [c_void_p, POINTER(c_int)]),
     ('dqmc_ecp_counts', c_int, [c_void_p, POINTER(c_int64)]),
     ('dqmc_refine_counters', c_int, [c_void_p, POINTER(c_int64)]),
+    ('dqmc_substep_kernel', c_int, [c_void_p, c_char_p, c_size_t]),
     ('dqmc_refine_scores', c_int, [c_void_p, POINTER(c_double), c_int]),
     ('dqmc_set_option', c_int, [c_void_p, c_char_p, c_int]),
     ('dqmc_timing_enable', c_int, [c_void_p, c_int]),

@@ -39,6 +39,8 @@ DEFAULTS = dict(
                           #   stores are older than its last k LDS reads: no drain of the prefetched fragments)
     wpos=(1, 4, 7, 9),    # fragment positions inside a stage at which a quarter of the next stage is stored / the one after requested
     lazy_ring=1,          # 1: the first ring stage is stored and awaited at the first tape read, not in the prologue
+    share_means=1,        # 1: the per-walker (spin-mean) pieces of a wide layer are multiplied ONCE for the 16 walkers of a workgroup --
+                          #   each wave takes a quarter of the output blocks with the walkers as the 16 MFMA columns -- instead of 4 x per tile
     waves=4,              # waves (= tiles of 4 walkers) per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
     sched='',             # -amdgpu-sched-strategy of the translation unit ('' = the compiler's default)
     group_barrier=1,      # 1: __builtin_amdgcn_sched_barrier(0) in front of every batch of tape reads
@@ -122,6 +124,7 @@ class Gen:
         self.pairs: Dict[int, List[Tuple[int, int]]] = {}
         self.uid = 0
         self.tail = None
+        self.xch_bytes = 0                              # LDS behind the ring: operand / result exchange of the shared mean products
 
     # ---- code stream ----
     def c(self, text):
@@ -129,6 +132,11 @@ class Gen:
 
     def use(self, frag):
         self.stream.append(('u', frag))
+
+    def use_exact(self, frag):
+        """ring cursor exactly past `frag` (no read-ahead): for code that reads fragments itself and therefore BEHIND the cursor --
+        it may only touch the cursor's stage and the one before (the slot two stages back is being refilled)"""
+        self.stream.append(('x', frag))
 
     def stamp(self, label):
         self.stream.append(('s', label))
@@ -138,13 +146,14 @@ class Gen:
         return f'{p}{self.uid}'
 
     # ---- tape ----
-    def tape_triple(self, w_off, ldw, col0, ncol, rows32, scale=1.0):
+    def tape_triple(self, w_off, ldw, col0, ncol, rows32, scale=1.0, explicit=False):
+        """explicit: the generated code reads the fragments itself (a wave-dependent address), no automatic read ahead"""
         assert len(rows32) == 32
         self.entries.append(dict(kind=0, w_off=w_off, ldw=ldw, col0=col0, ncol=ncol, map=len(self.maps), scale=scale))
         self.maps.extend(rows32)
         f = self.n_frag
         self.n_frag += 3
-        self.frag_kind += [0, 0, 0]
+        self.frag_kind += [2, 2, 2] if explicit else [0, 0, 0]
         return f
 
     def tape_gather(self, idx256, scale=1.0):
@@ -469,6 +478,52 @@ class Gen:
                     self.c(f'{tag}b_{rb}[{bb}] = f32x4{{0, 0, 0, 0}};')
                 if dual:
                     self.c(f'{tag}s_{rb}[{bb}] = f32x4{{0, 0, 0, 0}};')
+        # ---- per-walker pieces shared by the four tiles of the workgroup (option share_means) ----
+        shared = [ch for ch in chunks if ch[0] == 'blk' and ch[1].lazy_mean is not None]
+        do_share = bool(self.opt['share_means']) and self.opt['waves'] == 4 and rbs == ('n',) and nb % 4 == 0 and len(shared) >= 4
+        if do_share:
+            chunks = [ch for ch in chunks if not (ch[0] == 'blk' and ch[1].lazy_mean is not None)]
+            nbw = nb // 4                                      # output blocks per wave
+            xch = RING * STAGE_FRAGS * 1024                    # operand fragments [chunk][plane] x 1 KB, then results [block] x 1 KB
+            res = xch + len(shared) * 3 * 1024
+            self.xch_bytes = max(self.xch_bytes, len(shared) * 3 * 1024 + nb * 1024)
+            self.c(f'// per-walker pieces once per workgroup: {len(shared)} k-chunks, wave w multiplies output blocks {nbw} w .. for all 16 walkers')
+            self.c('{ const int xl_ = ((wave * 4 + (c >> 2)) + 16 * g) * 16;      // B-operand slot of this lane\'s walker (written by its el == 0 lanes)')
+            for ci, ch in enumerate(shared):
+                _, gb, t, rows32 = ch
+                xh, xm, xl = self.chunk_planes(gb, 'n', t)
+                for pl, v in enumerate((xh, xm, xl)):
+                    self.c(f'  if (el == 0) st_frag(smem_raw + {xch + (ci * 3 + pl) * 1024} + xl_, {v});')
+            self.c('}')
+            self.c('__syncthreads();')
+            for j in range(nbw):
+                self.c(f'f32x4 {tag}m{j} = f32x4{{0, 0, 0, 0}};')
+            def rd(ci):          # this wave's weight fragments of chunk ci + the chunk's shared operand
+                # tape order (chunk, block-of-the-wave j, wave): the four waves' triples of one (chunk, j) are adjacent, so the
+                # explicit reads lag the ring cursor by < one stage (the slot two stages back is being refilled)
+                _, gb, t, rows32 = shared[ci]
+                for j in range(nbw):
+                    frs = []
+                    for w in range(4):
+                        bb = w * nbw + j
+                        ncol = max(0, min(16, nout - 16 * bb))
+                        frs.append(self.tape_triple(w_off, ldw, 16 * bb, ncol, rows32, wscale, explicit=True))
+                    self.use_exact(frs[-1] + 2)      # (12 fragments back at most: < one stage)
+                    for pl in range(3):
+                        o = [self.lds_off(frs[w] + pl) for w in range(4)]
+                        self.c(f'const BfFrag {tag}w{ci}_{j}_{pl} = ld_frag(ring_lane + (wave_s == 0 ? {o[0]} : wave_s == 1 ? {o[1]} : wave_s == 2 ? {o[2]} : {o[3]}));')
+                for pl in range(3):
+                    self.c(f'const BfFrag {tag}x{ci}_{pl} = ld_frag(smem_raw + {xch + (ci * 3 + pl) * 1024} + lane * 16);')
+            rd(0)
+            for ci in range(len(shared)):
+                if ci + 1 < len(shared):
+                    rd(ci + 1)
+                for (wp, xp) in [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]:
+                    for j in range(nbw):
+                        self.c(f'{tag}m{j} = mfma_bf16({tag}w{ci}_{j}_{wp}, {tag}x{ci}_{xp}, {tag}m{j});')
+            for j in range(nbw):
+                self.c(f'*reinterpret_cast<f32x4*>(smem_raw + {res} + (wave * {nbw} + {j}) * 1024 + lane * 16) = {tag}m{j};')
+            self.c('__syncthreads();')
         # ---- products: chunk outer, blocks inner in pairs; the six products of a block (small terms first) alternate with
         # those of its partner, so consecutive MFMAs never share an accumulator ----
         prods = [(2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)]      # (weight plane, activation plane)
@@ -507,6 +562,11 @@ class Gen:
                         for rb in rbs:
                             acc = f'{tag}s_{rb}[{bb}]' if (dual and wp + xp == 2) else f'{tag}b_{rb}[{bb}]'
                             self.c(f'{acc} = mfma_bf16(t{fr[bb] + wp}, {ops_b[rb][xp]}, {acc});')
+        if do_share:
+            self.c('{ const int xr_ = ((wave * 4 + (c >> 2)) + 16 * g) * 16;')
+            for bb in range(nb):
+                self.c(f'  {tag}b_n[{bb}] += *reinterpret_cast<const f32x4*>(smem_raw + {res} + {bb * 1024} + xr_);')
+            self.c('}')
         if len(chunks) * nb >= 64:
             self.stamp(f'op {k} epilogue')
         # ---- epilogue ----
@@ -772,7 +832,7 @@ class Gen:
         self.run()
         n_stage = (self.n_frag + STAGE_FRAGS - 1) // STAGE_FRAGS
         tape_bytes = n_stage * STAGE_FRAGS * 1024
-        lds_bytes = RING * STAGE_FRAGS * 1024
+        lds_bytes = RING * STAGE_FRAGS * 1024 + self.xch_bytes
         out: List[str] = []
         A = out.append
         kname = f'k_substep_{self.name}'
@@ -796,6 +856,8 @@ class Gen:
         A('  HIP_DYNAMIC_SHARED(char, smem_raw)')
         A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
         A('  const int c = lane & 15, g = lane >> 4, wl = c >> 2, el = c & 3;')
+        A('  const int wave_s = __builtin_amdgcn_readfirstlane(wave);')
+        A('  (void)wave_s;')
         A('  (void)wl;')
         A(f'  const long bw = (long)blockIdx.x * {4 * nw} + wave * 4 + (c >> 2);      // this lane\'s walker')
         A('  const bool live = bw < a.B;')
@@ -881,8 +943,8 @@ class Gen:
                 n_stamp += 1
                 self.stamp_labels.append(v)
                 A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp}] = clock64();      // before {v}')
-            elif kind == 'u':
-                target = min(self.n_frag, int(v) + 1 + self.opt['pf'])
+            elif kind in ('u', 'x'):
+                target = min(self.n_frag, int(v) + 1 + (self.opt['pf'] if kind == 'u' else 0))
                 if self.opt['group_barrier'] and emitted < target:
                     A('  __builtin_amdgcn_sched_barrier(0);')
                 while emitted < target:
@@ -918,6 +980,9 @@ class Gen:
         A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp + 1}] = clock64();')
         A('}')
         A(f'void launch_{self.name}(hipStream_t st, const SpecArgs& a, int n_blocks) {{')
+        A(f'  static const bool lds_ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<true>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess &&')
+        A(f'                             hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<false>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess;')
+        A('  (void)lds_ok_;')
         A(f'  if (a.prof) hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<true>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
         A(f'  else hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<false>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
         A('}')

@@ -77,6 +77,7 @@ struct dqmc_ctx {
   virtual int debug_read(int buf, double* out, size_t n) = 0;
   virtual int option(const char* name, int value) = 0;
   virtual int refine_scores(double* out, int n) { (void)out; (void)n; return DQMC_E_UNSUPPORTED; }
+  virtual int substep_kernel(char* name_out, size_t n) { (void)n; name_out[0] = 0; return 0; }
   int64_t refine_counters[4] = {0, 0, 0, 0};   // local-energy / psi_grad calls; of them whole-batch float64; probe calls; walkers refined (sum)
   virtual dqmc_ctx* twin_ctx() { return nullptr; }
                                                          // (the float64 refinement twin of a float32 context, once it exists)
@@ -657,6 +658,10 @@ int dqmc_refine_info(dqmc_ctx* ctx, double* out4) {
   if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");
   for (int k = 0; k < 4; ++k) out4[k] = ctx->refine_info[k];
   return DQMC_OK;
+}
+int dqmc_substep_kernel(dqmc_ctx* ctx, char* name_out, size_t n) {
+  if (!ctx || !name_out || n < 1) return fail(DQMC_E_ARG, "null argument");
+  return ctx->substep_kernel(name_out, n);
 }
 int dqmc_refine_counters(dqmc_ctx* ctx, int64_t* out4) {
   if (!ctx || !out4) return fail(DQMC_E_ARG, "null argument");

@@ -12,6 +12,12 @@
       }
     return flops;
   }
+  int substep_kernel(char* name_out, size_t n) override {
+    name_out[0] = 0;
+    if (!(spec_k && fused_spec && d_tape)) return 0;
+    snprintf(name_out, n, "k_substep_%s", spec_k->name);
+    return 1;
+  }
   int mcmc(void* r_, void* logpsi_, int32_t* sign, int32_t* age, void* tau_, const void* R_, int B, int n_sub,
            int max_age, double target, uint64_t seed, const void* noise_, const void* unif_, uint8_t* accept_out,
            double* stats7) override {

@@ -157,11 +157,18 @@
       if (tail_r[b] && head_w[b]) { tail_in.push_back(b); tail_direct[b] = !nonlin_r[b]; }
     }
     // a tail LINEAR op reads its pieces either all as float32 (direct) or all from the twin's workspace
-    for (int k = 0; k < no; ++k) {
-      if (!in_tail[k] || ops[k].kind != DQMC_OP_LINEAR) continue;
-      bool all_direct = true;
-      for (int p = 0; p < ops[k].i[0]; ++p) all_direct = all_direct && tail_direct[ops[k].i[1 + 4 * p]];
-      if (!all_direct) for (int p = 0; p < ops[k].i[0]; ++p) tail_direct[ops[k].i[1 + 4 * p]] = 0;
+    // (to a fixpoint: demoting a buffer for one op can leave an EARLIER op that shares it mixed)
+    for (bool changed = true; changed;) {
+      changed = false;
+      for (int k = 0; k < no; ++k) {
+        if (!in_tail[k] || ops[k].kind != DQMC_OP_LINEAR) continue;
+        bool all_direct = true, any_direct = false;
+        for (int p = 0; p < ops[k].i[0]; ++p) { const bool d = tail_direct[ops[k].i[1 + 4 * p]]; all_direct = all_direct && d; any_direct = any_direct || d; }
+        if (!all_direct && any_direct) {
+          for (int p = 0; p < ops[k].i[0]; ++p) tail_direct[ops[k].i[1 + 4 * p]] = 0;
+          changed = true;
+        }
+      }
     }
     for (int b = 0; b < nb; ++b) tail_alloc[b] = tail_written[b] || (tail_r[b] && head_w[b] && !tail_direct[b]);
     k_tail = first;

@@ -265,7 +265,7 @@
       HIP_TRY(hipStreamSynchronize(st));
       if (n > B) n = B;
       if (!probe) {
-        if (n <= 0) return DQMC_OK;
+        if (n <= 0) { mostly_flagged(0, B); return DQMC_OK; }      // (a float32 look that flags nothing leaves the direct mode: reset the hysteresis state)
         rc = ensure_twin();
         if (rc == DQMC_E_UNSUPPORTED && refine == 1) { refine = 0; return DQMC_OK; }   // no float64 kernel set for this program: float32 stands
         if (rc) return rc;

@@ -392,12 +392,12 @@ __global__ void __launch_bounds__(256) k_refine_scatter(const int32_t* __restric
 // widen: a float32 activation buffer (or the walker positions) into the float64 twin's workspace, four elements per thread
 __global__ void __launch_bounds__(256) k_widen(const float* __restrict__ src, double* __restrict__ dst, long n) {
   const long e = 4 * ((long)blockIdx.x * blockDim.x + threadIdx.x);
-  if (e + 3 < n) {
-    const Vec4<float> v = *reinterpret_cast<const Vec4<float>*>(src + e);          // (buffers are 256-byte aligned, widths multiples of 4)
+  if (e + 3 < n && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {      // (workspace buffers are 256-byte aligned; a caller's r / R view may not be)
+    const Vec4<float> v = *reinterpret_cast<const Vec4<float>*>(src + e);
     *reinterpret_cast<Vec2<double>*>(dst + e) = Vec2<double>{{(double)v.v[0], (double)v.v[1]}};
     *reinterpret_cast<Vec2<double>*>(dst + e + 2) = Vec2<double>{{(double)v.v[2], (double)v.v[3]}};
   } else {
-    for (long k = e; k < n; ++k) dst[k] = (double)src[k];
+    for (long k = e; k < n && k < e + 4; ++k) dst[k] = (double)src[k];
   }
 }
 void launch_widen(hipStream_t st, const float* src, double* dst, long n) {

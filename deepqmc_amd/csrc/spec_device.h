@@ -105,6 +105,12 @@ template <int OFF> __device__ __forceinline__ V16 tape_load(const TapeRsrc& t, i
 #endif
 }
 
+__device__ __forceinline__ void st_frag(char* p, const BfFrag& f) {
+  V16 v;
+  v[0] = f.w[0]; v[1] = f.w[1]; v[2] = f.w[2]; v[3] = f.w[3];
+  *reinterpret_cast<V16*>(p) = v;
+}
+
 // Barrier between two stages of the weight ring.  A wave's own ring stores are older than its last K LDS reads (the generator
 // places them so), LDS operations complete in order, so "at most K outstanding" means the stores have landed; the prefetched
 // fragment reads stay in flight across the barrier (__syncthreads() would drain them: s_waitcnt lgkmcnt(0)).

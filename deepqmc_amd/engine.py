@@ -340,6 +340,14 @@ class Engine:
         self._check(self.lib.dqmc_refine_counters(self._ctx, out))
         return {'calls': int(out[0]), 'direct_f64_calls': int(out[1]), 'probe_calls': int(out[2]), 'walkers_refined': int(out[3])}
 
+    def substep_kernel(self) -> str:
+        """Name of the plan-specialised sub-step kernel bound to this context's program (dqmc_substep_kernel), '' if none."""
+        buf = ctypes.create_string_buffer(128)
+        rc = self.lib.dqmc_substep_kernel(self._ctx, buf, 128)
+        if rc < 0:
+            self._check(rc)
+        return buf.value.decode()
+
     def refine_scores(self, n: int) -> np.ndarray:
         """Error-predictor scores of the first n walkers of the last float32 forward-Laplacian pass (dqmc_refine_scores)."""
         out = np.empty(int(n), np.float64)
@@ -361,6 +369,11 @@ class Engine:
 
     def set_option(self, name: str, value: int):
         self._check(self.lib.dqmc_set_option(self._ctx, name.encode(), int(value)))
+        self.__dict__.setdefault('_options', {})[name] = int(value)      # (what the caller chose: apply(return_mos=True) restores it)
+
+    def get_option(self, name: str, default: int) -> int:
+        """The value last set through set_option (the library has no getter), else `default`."""
+        return self.__dict__.get('_options', {}).get(name, default)
 
     def timing(self, enable=True):
         self._check(self.lib.dqmc_timing_enable(self._ctx, int(enable)))

@@ -111,6 +111,7 @@ class NeuralNetworkWaveFunction:
                 raise NotImplementedError('return_mos (wf/nn_wave_function.py:144): only full-determinant programs expose '
                                           'their orbital matrices; spin-factorised ones store block-diagonal matrices')
             import numpy as np
+            prev_fused = eng.get_option('fused', 1)
             eng.set_option('fused', 0)              # every activation buffer stays readable (include/dqmc.h: "fused")
             try:
                 eng.wf_eval(r, R)
@@ -118,7 +119,7 @@ class NeuralNetworkWaveFunction:
                 N, K = self.hamil.n_elec, self.spec.n_determinants
                 A = eng.debug_read('orbitals', B)[:, :, 0, :N * N].reshape(B, K, N, N)     # rows = electrons, columns = orbitals
             finally:
-                eng.set_option('fused', 1)
+                eng.set_option('fused', prev_fused)      # (the caller's own choice, not the default)
             A = torch.as_tensor(np.ascontiguousarray(A), dtype=self.dtype, device=self.device)
             return A[:, :, :self.hamil.n_up], A[:, :, self.hamil.n_up:]
         sign, log = eng.wf_eval(r, R)

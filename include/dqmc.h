@@ -265,7 +265,9 @@ int dqmc_debug_lanes(dqmc_ctx* ctx);
  * one for which the expected share of float32-kept walkers beyond the tolerance "refine_target_e7" x 1e-7 (default 1e-5
  * relative) -- the mean of exp(-tol / (m score_i)) over the kept walkers of the probed batch -- stays below
  * "refine_miss_e9" x 1e-9 (default 1e-8).  A batch with more than
- * "refine_direct_pct" (60 %) of its walkers above the threshold is evaluated in float64 whole, and so are the next 15 calls;
+ * "refine_direct_pct" (60 %) of its walkers above the threshold is evaluated in float64 whole, and so are the next
+ * "refine_direct_calls" (15) calls -- a stay that doubles with every float32 look that confirms the mode, at most
+ * "refine_direct_backoff" times --;
  * the context returns to the mixed mode only when a float32 pass then finds fewer than "refine_direct_exit_pct" (45 %)
  * above it -- hysteresis: one calibration draw near a single line used to flip the mode from run to run). */
 int dqmc_last_refined(dqmc_ctx* ctx);
@@ -282,6 +284,11 @@ int dqmc_last_chunks(dqmc_ctx* ctx, int* out2);
  * float64 whole ("direct" mode or "refine" 2), calibration probe calls, walkers re-evaluated in float64 (sum of
  * dqmc_last_refined)} -- what a caller needs to say which mode its steps actually ran in (bench.py: config.refine_engaged). */
 int dqmc_refine_counters(dqmc_ctx* ctx, int64_t* out4);
+/* Which kernel dqmc_mcmc_steps launches per Metropolis sub-step (sampling/electron_samplers.py:102-138): writes the name of the
+ * PLAN-SPECIALISED kernel bound to this context's program (deepqmc_amd/csrc/gen/, generated by deepqmc_amd/codegen from the
+ * layer program and matched by a hash of its structure; option "fused_spec" 0 switches it off) into name_out[n] and returns
+ * 1; returns 0 with an empty string when the program runs on the descriptor-driven kernel or the one-launch-per-op path. */
+int dqmc_substep_kernel(dqmc_ctx* ctx, char* name_out, size_t n);
 /* The error-predictor scores (see dqmc_last_refined) of the first n walkers of the context's last float32 forward-Laplacian
  * pass, copied to the host: together with the threshold of dqmc_refine_info they say which walkers kept their float32
  * result.  DQMC_E_UNSUPPORTED if the last call ran no such pass (float64 context, "refine" 0 / 2, direct mode). */

@@ -338,6 +338,18 @@ def test_return_mos_released_engines_and_numpy_spin_input():
     K, N = wf.spec.n_determinants, h.n_elec
     assert up.shape == (B, K, h.n_up, N) and dn.shape == (B, K, h.n_down, N)
     sgn, logdet = torch.linalg.slogdet(torch.cat([up, dn], dim=2))                 # [B, K]
+    # orientation (a determinant does not see a transposition): rows are ELECTRONS, columns orbitals -- electron i's row against
+    # the oracle's orbital matrix A[k, i, :] of the same walker
+    from oracle import wf as owf_
+    from oracle import geom as ogeom_
+    A_ref, _ = owf_.orbitals(owf_.to_torch(params), wf.spec, torch.as_tensor(r[0], dtype=torch.float64), torch.as_tensor(h.mol.coords, dtype=torch.float64), h.n_up, wf.norm_eps if hasattr(wf, 'norm_eps') else ogeom_.F64_EPS)
+    np.testing.assert_allclose(torch.cat([up, dn], dim=2)[0].numpy(), A_ref.detach().numpy(), rtol=1e-9, atol=1e-12)
+    # a caller's own choice of the value-path kernels survives the call (it used to be reset to the default)
+    eng_ = wf.engine(params)
+    eng_.set_option('fused', 2)
+    wf.apply(params, r, return_mos=True)
+    assert eng_.get_option('fused', 1) == 2
+    eng_.set_option('fused', 1)
     eng = wf.engine(params)
     np.testing.assert_allclose(logdet.numpy(), eng.debug_read('logdet', B)[:, :, 0], rtol=1e-10, atol=1e-10)
     np.testing.assert_array_equal(sgn.numpy().astype(np.int32), eng.debug_read('sign_k', B))

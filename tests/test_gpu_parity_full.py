@@ -18,10 +18,11 @@ with the oracle to float32 OUTPUT rounding (< 2e-7) for 100 % of the walkers.
 How the default gets there (engine.hip: lap_refined): the float32 error of E_loc is predicted per
 walker by score = (|lap| + |grad|^2) / max(1, |E_loc|) x conditioning record of the Slater matrices; on the first call
 (and every 32nd) <= 256 extra walkers are evaluated in float64; measured, err = m x score x (exponential factor), the sample
-gives m, and the threshold is the largest one whose kept walkers miss 1e-5 at an expected rate <= 1e-7; walkers above it are
-re-evaluated by the float64 twin.  LiH / PauliNet refines ~10 % of the fixture's walkers (~27 % along the bench trajectory),
-N2 / FermiNet ~30 %, the Psiformers and the random-init TransPsiformer nearly all -- those run in the direct float64 mode.
-Everything lands in gpurun_out/parity_report.json -> profiles/r04_parity_report.json.
+gives m, and the threshold is the largest one whose kept walkers miss 1e-5 at an expected rate <= 1e-8 (the shipped default,
+`refine_miss_e9` = 10; 1e-7 until the fresh accumulators of round 5); walkers above it are
+re-evaluated by the float64 twin.  LiH / PauliNet refines ~8 % of the fixture's walkers (~18 % along the bench trajectory),
+N2 / FermiNet ~12 %, the Psiformers and the random-init TransPsiformer nearly all -- those run in the direct float64 mode.
+Everything lands in gpurun_out/parity_report.json -> profiles/r0N_parity_report.json.
 """
 import json
 import os
@@ -45,7 +46,7 @@ OUT = os.path.join(ROOT, 'gpurun_out')
 
 # name: (min fraction within 1e-5, p50 bound, p99 bound, max bound, log|psi| p99 bound)
 # Every set asserts the north-star tolerance itself -- EVERY walker within 1e-5 -- with ONE documented exception.  Round 5: the
-# score threshold now promises a miss rate of 1e-7 under the measured exponential error model (engine.hip, above refine_thresh),
+# score threshold promises a miss rate of 1e-8 (`refine_miss_e9` 10) under the measured exponential error model (engine.hip, above refine_thresh),
 # which refines 2-3 x more walkers than the 90th-percentile rule of rounds 3-4 did (profiles/r05_calibration_model.txt).
 BOUNDS = {
     'lih_paulinet_4096': (1.0, 1e-6, 1e-5, 1e-5, 1e-5),
