@@ -39,6 +39,10 @@ DEFAULTS = dict(
                           #   stores are older than its last k LDS reads: no drain of the prefetched fragments)
     wpos=(1, 4, 7, 9),    # fragment positions inside a stage at which a quarter of the next stage is stored / the one after requested
     lazy_ring=1,          # 1: the first ring stage is stored and awaited at the first tape read, not in the prologue
+    sgb=0,                # > 0: every scheduling region (between the sched_barriers of group_barrier) ends with a
+                          #   sched_group_barrier pipeline {1 MFMA, sgb VALU} x its MFMAs
+    defer_epi=1,          # 1: the epilogue (activation, residual, bf16 split) of a layer is interleaved with the MFMAs of the NEXT linear layer
+                          #   when nothing in between reads its output: one wave per SIMD has no other wave to hide VALU behind
     share_means=1,        # 1: the per-walker (spin-mean) pieces of a wide layer are multiplied ONCE for the 16 walkers of a workgroup --
                           #   each wave takes a quarter of the output blocks with the walkers as the 16 MFMA columns -- instead of 4 x per tile
     waves=4,              # waves (= tiles of 4 walkers) per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
@@ -272,6 +276,7 @@ class Gen:
                 self.op_feat_ee(op)
             elif op.kind == OP_LINEAR:
                 self.op_linear(k, op)
+                self.stream.append(('ee', k))
             elif op.kind == OP_SPIN_MEAN:
                 self.op_spin_mean(op)
             elif op.kind == OP_CONV:
@@ -478,6 +483,7 @@ class Gen:
                     self.c(f'{tag}b_{rb}[{bb}] = f32x4{{0, 0, 0, 0}};')
                 if dual:
                     self.c(f'{tag}s_{rb}[{bb}] = f32x4{{0, 0, 0, 0}};')
+        self.stream.append(('lb', k))
         # ---- per-walker pieces shared by the four tiles of the workgroup (option share_means) ----
         shared = [ch for ch in chunks if ch[0] == 'blk' and ch[1].lazy_mean is not None]
         do_share = bool(self.opt['share_means']) and self.opt['waves'] == 4 and rbs == ('n',) and nb % 4 == 0 and len(shared) >= 4
@@ -562,6 +568,7 @@ class Gen:
                         for rb in rbs:
                             acc = f'{tag}s_{rb}[{bb}]' if (dual and wp + xp == 2) else f'{tag}b_{rb}[{bb}]'
                             self.c(f'{acc} = mfma_bf16(t{fr[bb] + wp}, {ops_b[rb][xp]}, {acc});')
+        self.stream.append(('le', k))
         if do_share:
             self.c('{ const int xr_ = ((wave * 4 + (c >> 2)) + 16 * g) * 16;')
             for bb in range(nb):
@@ -570,6 +577,7 @@ class Gen:
         if len(chunks) * nb >= 64:
             self.stamp(f'op {k} epilogue')
         # ---- epilogue ----
+        self.stream.append(('eb', k))
         scale = '0.70710678118654752440f' if normalize else None
         for rb in rbs:
             drb = rb
@@ -613,6 +621,8 @@ class Gen:
                                 self.c(f'{gd.name}p_{drb}[0][{tt}].w[{j}] = 0u; {gd.name}p_{drb}[1][{tt}].w[{j}] = 0u; {gd.name}p_{drb}[2][{tt}].w[{j}] = 0u;')
                             else:
                                 self.c(f'split2({src[2 * j]}, {src[2 * j + 1]}, {gd.name}p_{drb}[0][{tt}].w[{j}], {gd.name}p_{drb}[1][{tt}].w[{j}], {gd.name}p_{drb}[2][{tt}].w[{j}]);')
+
+    # (the marker that closes the epilogue is appended by run())
 
     def op_spin_mean(self, op):
         src, dst = op.i[0], op.i[1]
@@ -827,9 +837,108 @@ class Gen:
             self.c(f'logpsi += (double)__shfl({gj.name}_n[0][0], (threadIdx.x & 63) & 15, 64);')
         self.tail = True
 
+    @staticmethod
+    def op_rw(op):
+        i = op.i
+        if op.kind in (OP_FEAT_EN, OP_FEAT_EE, OP_CONST):
+            return set(), {i[0]}
+        if op.kind == OP_LINEAR:
+            rd = {i[1 + 4 * p] for p in range(i[0])}
+            if i[25] >= 0:
+                rd.add(i[25])
+            return rd, {i[17]}
+        if op.kind in (OP_SPIN_MEAN, OP_ROW_SUM):
+            return {i[0]}, {i[1]}
+        if op.kind == OP_CONV:
+            return {i[0], i[1]}, {i[2]}
+        if op.kind == OP_EDGE_SUM:
+            return {i[0]}, {i[2]}
+        if op.kind == OP_ORBITALS:
+            return {i[0]}, {i[1]}
+        if op.kind == OP_FINAL:
+            return ({i[0]} if i[0] >= 0 else set()), set()
+        return set(), set()
+
+    def can_defer(self, k, k2):
+        """may the epilogue of LINEAR op k run inside the product loop of LINEAR op k2 > k?"""
+        rd_k, wr_k = self.op_rw(self.ops[k])
+        dst = self.ops[k].i[17]
+        for j in range(k + 1, k2 + 1):
+            rd, wr = self.op_rw(self.ops[j])
+            if dst in rd:
+                return False
+            if j < k2 and (wr & (rd_k | {dst})):
+                return False
+            # spin means are produced where they are consumed: a consumer of a mean of dst reads dst
+            if self.ops[j].kind == OP_LINEAR:
+                for p in range(self.ops[j].i[0]):
+                    sb = self.ops[j].i[1 + 4 * p]
+                    for o2 in self.ops[:j]:
+                        if o2.kind == OP_SPIN_MEAN and o2.i[1] == sb and o2.i[0] == dst:
+                            return False
+        return True
+
+    def defer_epilogues(self):
+        st = self.stream
+        out = []
+        i = 0
+        while i < len(st):
+            it = st[i]
+            if it[0] == 'eb':
+                k = it[1]
+                j = next(n for n in range(i, len(st)) if st[n] == ('ee', k))
+                E = st[i + 1:j]
+                n = next((q for q in range(j + 1, len(st)) if st[q][0] == 'lb'), None)
+                if self.opt['defer_epi'] and n is not None and self.can_defer(k, st[n][1]):
+                    k2 = st[n][1]
+                    m = next(q for q in range(n, len(st)) if st[q] == ('le', k2))
+                    body = st[n + 1:m]
+                    mf = [q for q, b in enumerate(body) if b[0] == 'c' and 'mfma_bf16(' in b[1]]
+                    if mf and E:
+                        out.extend(st[j + 1:n])
+                        per = -(-len(E) // len(mf))
+                        nb_, e0 = [], 0
+                        for q, b in enumerate(body):
+                            nb_.append(b)
+                            if q in mf and e0 < len(E):
+                                nb_.extend(E[e0:e0 + per])
+                                e0 += per
+                        nb_.extend(E[e0:])
+                        out.extend(nb_)
+                        i = m
+                        continue
+                out.extend(E)
+                i = j + 1
+                continue
+            out.append(it)
+            i += 1
+        self.stream = [x for x in out if x[0] not in ('lb', 'le', 'eb', 'ee')]
+
+    def add_group_pipelines(self, lines):
+        res, region = [], []
+
+        def flush():
+            m = sum(1 for l in region if 'mfma_bf16(' in l)
+            v = sum(5 * l.count('tanh_') + 11 * l.count('split2(') + 2 * l.count('quad_') for l in region)
+            res.extend(region)
+            if m >= 2 and v >= 4:
+                q = min(int(self.opt['sgb']), -(-v // m))
+                for _ in range(m):
+                    res.append(f'  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, {q}, 0);')
+            region.clear()
+        for l in lines:
+            if '__builtin_amdgcn_sched_barrier(0);' in l:
+                flush()
+                res.append(l)
+            else:
+                region.append(l)
+        res.extend(region)
+        return res
+
     # ---- final assembly ----
     def source(self):
         self.run()
+        self.defer_epilogues()
         n_stage = (self.n_frag + STAGE_FRAGS - 1) // STAGE_FRAGS
         tape_bytes = n_stage * STAGE_FRAGS * 1024
         lds_bytes = RING * STAGE_FRAGS * 1024 + self.xch_bytes
@@ -979,6 +1088,8 @@ class Gen:
         A('  if (lane == 0 && n_acc) atomicAdd(a.mc.counters + a.mc.s % 3, n_acc);')
         A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp + 1}] = clock64();')
         A('}')
+        if self.opt['sgb']:
+            out[:] = self.add_group_pipelines(out)
         A(f'void launch_{self.name}(hipStream_t st, const SpecArgs& a, int n_blocks) {{')
         A(f'  static const bool lds_ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<true>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess &&')
         A(f'                             hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<false>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess;')

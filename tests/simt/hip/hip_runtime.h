@@ -104,6 +104,7 @@ inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 // (lanes are fibers here: the wave-level ordering point has to yield to the other lanes, which a shuffle does)
 inline void __builtin_amdgcn_wave_barrier() { (void)__shfl(0, 0, 64); }
 // constant address space qualifier of the fused kernel's descriptor pointers

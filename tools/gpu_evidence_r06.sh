@@ -1,15 +1,15 @@
 #!/bin/bash
-# Round-5 evidence in one GPU call: smoke, the whole -m gpu suite, HBM traffic (VMC step + E_loc pass), headline bench with
+# Round-6 evidence in one GPU call: smoke, the whole -m gpu suite, HBM traffic (VMC step + E_loc pass), headline bench with
 # the CPU baseline, rocprofv3 kernel stats of the headline and of configs 3-5, SQ counters (headline per family; N2 / benzene /
 # C4H4 per kernel instantiation, i.e. the float64 kernels that make up 65 % of configs 4-5), the other configurations, the
-# E_loc timeline, the MFMA rates with the clock they ran at.  Everything lands in gpurun_out/; tools/collect_profiles_r05.sh
+# E_loc timeline, the MFMA rates with the clock they ran at.  Everything lands in gpurun_out/; tools/collect_profiles_r06.sh
 # copies the summaries into profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd); mkdir -p gpurun_out; [ -z "$SKIP_PYTEST" ] && rm -f gpurun_out/parity_report.json gpurun_out/gpu_mem.log
 nproc > gpurun_out/device.log; rocm-smi --showclocks >> gpurun_out/device.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
 if [ -z "$SKIP_PYTEST" ]; then timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log; fi    # (SKIP_PYTEST=1: the suite ran in a call of its own at the same commit)
 tools/run_traffic.sh > gpurun_out/traffic.log 2>&1
-cp gpurun_out/pmc_hbm_traffic.json profiles/r05_pmc_hbm_traffic.json           # bench.py reports roofline.traffic_from_profile from here
+cp gpurun_out/pmc_hbm_traffic.json profiles/r06_pmc_hbm_traffic.json           # bench.py reports roofline.traffic_from_profile from here
 tools/run_traffic_eloc.sh 1 > gpurun_out/traffic_eloc.log 2>&1
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err; echo "bench rc=$?" >> gpurun_out/bench.err
 tools/prof_cfg.sh lih --steps 5 --warmup 5 --repeats 1 > gpurun_out/prof_lih.txt 2>&1

@@ -5,10 +5,10 @@ acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 for d in sys.argv[1:]:
     for path in glob.glob(d + '/*counter_collection.csv'):
         for row in csv.DictReader(open(path)):
-            m = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+)', row['Kernel_Name'])
+            m = re.match(r'(?:void\s+)?(?:dqmc::)?(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+)', row['Kernel_Name'])
             fam = m.group(1) if m else row['Kernel_Name'][:40]
             if os.environ.get('PMC_FULLNAME'):          # keep the template arguments (one entry per instantiation)
-                m2 = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+(?:<[^>]*>)?)', row['Kernel_Name'])
+                m2 = re.match(r'(?:void\s+)?(?:dqmc::)?(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+(?:<[^>]*>)?)', row['Kernel_Name'])
                 fam = m2.group(1) if m2 else fam
             a = acc[fam][row['Counter_Name']]
             a[0] += 1; a[1] += float(row['Counter_Value'])

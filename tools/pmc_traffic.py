@@ -10,10 +10,10 @@ from collections import defaultdict
 
 def family(name):
     if os.environ.get('PMC_FULLNAME'):          # one entry per template instantiation (float32 pass vs float64 twin)
-        m = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+(?:<[^>]*>)?)', name)
+        m = re.match(r'(?:void\s+)?(?:dqmc::)?(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+(?:<[^>]*>)?)', name)
         if m:
             return m.group(1)
-    m = re.match(r'(?:void\s+)?(?:dqmc::)?(k_[a-z_0-9]+)', name)
+    m = re.match(r'(?:void\s+)?(?:dqmc::)?(?:\(anonymous namespace\)::)?(k_[a-z_0-9]+)', name)
     return m.group(1) if m else name.split('(')[0][:40]
 
 def reduce_csv(path, counter):

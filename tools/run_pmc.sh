@@ -22,5 +22,5 @@ import json
 import os
 d = json.load(open('gpurun_out/%s.json' % os.environ.get('PMC_OUT', 'pmc_sq')))
 for k in d:
-    if k.startswith(('k_fused2_value', 'k_linear', 'k_attention')): print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a.startswith(('frac_', 'valu_per', 'mfma_busy', 'launches'))}))
+    if k.startswith(('k_fused2_value', 'k_substep', 'k_linear', 'k_attention')): print(k, json.dumps({a: (round(b, 3) if isinstance(b, float) else b) for a, b in d[k].items() if a.startswith(('frac_', 'valu_per', 'mfma_busy', 'launches'))}))
 PY
