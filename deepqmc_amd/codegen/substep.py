@@ -45,6 +45,8 @@ DEFAULTS = dict(
                           #   when nothing in between reads its output (measured: 57.1 vs 57.0 us -- the wave is bound by instruction issue, not by order)
     share_means=1,        # 1: the per-walker (spin-mean) pieces of a wide layer are multiplied ONCE for the 16 walkers of a workgroup --
                           #   each wave takes a quarter of the output blocks with the walkers as the 16 MFMA columns -- instead of 4 x per tile
+    producer=0,           # 1: a fifth wave per workgroup fills the weight ring (global -> registers -> LDS, one stage per barrier interval);
+                          #   the four computing waves only read it
     waves=4,              # waves (= tiles of 4 walkers) per workgroup: 4 (one per SIMD) or 8 (two per SIMD)
     sched='',             # -amdgpu-sched-strategy of the translation unit ('' = the compiler's default)
     group_barrier=1,      # 1: __builtin_amdgcn_sched_barrier(0) in front of every batch of tape reads
@@ -956,12 +958,14 @@ class Gen:
         A('namespace {')
         A('using namespace dqmc::spec;')
         nw = self.opt['waves']
+        prod = bool(self.opt['producer'])
         nthr = 64 * nw
         npc = (STAGE_FRAGS * 64) // nthr      # 16-byte pieces per thread and ring stage
+        nthr_launch = nthr + (64 if prod else 0)
         wpos = list(self.opt['wpos'])[:npc] if len(self.opt['wpos']) >= npc else list(self.opt['wpos'])
         if len(wpos) != npc:
             raise ValueError('wpos must name one position per piece')
-        A(f'template <bool PROF> __global__ void __launch_bounds__({nthr}) {kname}(const SpecArgs a) {{')
+        A(f'template <bool PROF> __global__ void __launch_bounds__({nthr_launch}) {kname}(const SpecArgs a) {{')
         A('  HIP_DYNAMIC_SHARED(char, smem_raw)')
         A('  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;')
         A('  const int c = lane & 15, g = lane >> 4, wl = c >> 2, el = c & 3;')
@@ -976,12 +980,14 @@ class Gen:
         A('  V16* ring_t = reinterpret_cast<V16*>(smem_raw) + tid;')
         A(f'  const TapeRsrc tape = tape_rsrc(a.tape, {tape_bytes});')
         A('  const int tid16 = tid * 16;')
+        A('@@PRODUCER@@')
         A('  const bool stamp_ = PROF && a.prof != nullptr && blockIdx.x == 0 && lane == 0;')
         A('  if (stamp_) a.prof[wave * 256] = clock64();')
-        A('  // ring prologue: stage 0 -> LDS, stage 1 -> registers')
-        A('  V16 ' + ', '.join(f'rq{q}' for q in range(npc)) + ';')
-        for q in range(npc):
-            A(f'  rq{q} = tape_load<{q * nthr * 16}>(tape, tid16);')
+        if not prod:
+            A('  // ring prologue: stage 0 -> LDS, stage 1 -> registers')
+            A('  V16 ' + ', '.join(f'rq{q}' for q in range(npc)) + ';')
+            for q in range(npc):
+                A(f'  rq{q} = tape_load<{q * nthr * 16}>(tape, tid16);')
         # sampler state + proposal while the first stage is in flight
         A('  // step size of this sub-step from the previous one\'s acceptance (the arithmetic of k_tau_update)')
         A('  float tau;')
@@ -1009,7 +1015,13 @@ class Gen:
         A('  const float u_b = reinterpret_cast<const float*>(a.mc.unif)[bc];')
         A('  const int age_b = a.mc.age[bc];')
         A('  const float px = __shfl(rp, c, 64), py = __shfl(rp, c + 16, 64), pz = __shfl(rp, c + 32, 64);')
+        events = []      # the workgroup barriers of the computing waves, in order: what the producer wave has to match
+
         def ring_start():
+            if prod:
+                events.append(('start',))
+                A('  __syncthreads();')
+                return
             for q in range(npc):
                 A(f'  ring_t[{q * nthr}] = rq{q};')
             if n_stage > 1:
@@ -1031,13 +1043,16 @@ class Gen:
             if not started:
                 ring_start(); started = True
             s, o = divmod(f, STAGE_FRAGS)
-            if o == 0 and s >= 1:
+            if o == 0 and s >= 1 and prod:
+                events.append(('ring', s))
+                A('  ring_barrier0();')
+            elif o == 0 and s >= 1:
                 kk = min(6, reads_after_last_store(s - 1))
                 if self.opt['barrier'] == 'asm' and kk >= 1:
                     A(f'  ring_barrier<{kk}>();')
                 else:
                     A('  __syncthreads();')
-            if o in wpos:
+            if o in wpos and not prod:
                 q = wpos.index(o)
                 if s + 1 < n_stage:
                     A(f'  ring_t[{((s + 1) % RING) * STAGE_FRAGS * 64 + q * nthr}] = rq{q};')
@@ -1060,6 +1075,8 @@ class Gen:
                     emit_read(emitted)
                     emitted += 1
             else:
+                if '__syncthreads();' in v:
+                    events.append(('x',))
                 A('  ' + v)
         while emitted < self.n_frag:
             emit_read(emitted)
@@ -1088,14 +1105,44 @@ class Gen:
         A('  if (lane == 0 && n_acc) atomicAdd(a.mc.counters + a.mc.s % 3, n_acc);')
         A(f'  if (stamp_) a.prof[wave * 256 + {n_stamp + 1}] = clock64();')
         A('}')
+        pl = []
+        if prod:
+            P = pl.append
+            P(f'  if (wave == {nw}) {{      // the producer wave: stage s + 1 goes into the ring while the computing waves read stage s')
+            P('    char* ring_w = smem_raw + lane * 16;')
+            P('    const int l16 = lane * 16;')
+
+            def copy_stage(st_):
+                if st_ >= n_stage:
+                    return
+                P(f'    {{ V16 v_[{STAGE_FRAGS}];')
+                for q in range(STAGE_FRAGS):
+                    P(f'      v_[{q}] = tape_load<{(st_ * STAGE_FRAGS + q) * 1024}>(tape, l16);')
+                for q in range(STAGE_FRAGS):
+                    P(f'      *reinterpret_cast<V16*>(ring_w + {(st_ % RING) * STAGE_FRAGS * 1024 + q * 1024}) = v_[{q}];')
+                P('    }')
+            for ev in events:
+                if ev[0] == 'start':
+                    copy_stage(0)
+                    copy_stage(1)
+                    P('    __syncthreads();')
+                elif ev[0] == 'ring':
+                    P('    __syncthreads();')
+                    copy_stage(ev[1] + 1)
+                else:
+                    P('    __syncthreads();')
+            P('    return;')
+            P('  }')
+        k_ = out.index('@@PRODUCER@@')
+        out[k_:k_ + 1] = pl
         if self.opt['sgb']:
             out[:] = self.add_group_pipelines(out)
         A(f'void launch_{self.name}(hipStream_t st, const SpecArgs& a, int n_blocks) {{')
         A(f'  static const bool lds_ok_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<true>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess &&')
         A(f'                             hipFuncSetAttribute(reinterpret_cast<const void*>(&{kname}<false>), hipFuncAttributeMaxDynamicSharedMemorySize, {lds_bytes}) == hipSuccess;')
         A('  (void)lds_ok_;')
-        A(f'  if (a.prof) hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<true>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
-        A(f'  else hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<false>), dim3((unsigned)n_blocks), dim3({nthr}), {lds_bytes}, st, a);')
+        A(f'  if (a.prof) hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<true>), dim3((unsigned)n_blocks), dim3({nthr_launch}), {lds_bytes}, st, a);')
+        A(f'  else hipLaunchKernelGGL(HIP_KERNEL_NAME({kname}<false>), dim3((unsigned)n_blocks), dim3({nthr_launch}), {lds_bytes}, st, a);')
         A('}')
         A(f'const SpecTapeEntry entries_{self.name}[] = {{')
         for e in self.entries:

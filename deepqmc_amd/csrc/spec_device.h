@@ -122,6 +122,16 @@ template <int K> __device__ __forceinline__ void ring_barrier() {
 #endif
 }
 
+// Stage boundary of a ring that a producer wave fills: the computing waves neither store to the ring nor need their
+// prefetched fragment reads drained -- a bare s_barrier (the compiler may not move LDS accesses across it).
+__device__ __forceinline__ void ring_barrier0() {
+#if defined(__HIPCC__)
+  asm volatile("s_barrier" ::: "memory");
+#else
+  __syncthreads();
+#endif
+}
+
 // v from lane (l & ~3) | P[l & 3] of the same 4-lane quad
 template <int P0, int P1, int P2, int P3> __device__ __forceinline__ float quad_perm(float v) {
 #if defined(__HIPCC__)

@@ -52,6 +52,9 @@ CONFIGS = {
     # round 5: a SECOND synthetic table at the BASELINE-shaped batch -- what the ECP cut-offs of the library (tuned on the
     # 32 walkers above) have never seen: exponents x 4 and / 4, a d channel
     'benzene_ecpB_psiformer_256': ('benzene', 'psiformer', 256, 200, 2, 2, 'B'),
+    # round 6: a HOLD-OUT table -- generated after every ECP option of the library was frozen at the round-5 defaults, run once,
+    # reported as it came out (tests/test_gpu_parity_full.py::test_ecp_hold_out_table_c_128)
+    'benzene_ecpC_psiformer_128': ('benzene', 'psiformer', 128, 200, 2, 2, 'C'),
 }
 LEGACY = ('lih_paulinet_4096', 'n2_ferminet_512', 'benzene_psiformer_8', 'c4h4_transpsiformer_64', 'lih_paulinet_raw_1024',
           'lih_psiformer_256')      # round-2 fixtures: one block, the original random streams
@@ -71,7 +74,14 @@ def ecp_table_b(z: int):
                                 [0, [[], [], [[0.3325, 6.75]]]], [1, [[], [], [[5.0, 0.45]]]], [2, [[], [], [[0.8, 0.9]]]]]]
 
 
-ECP_TABLES = {True: ecp_table, 'A': ecp_table, 'B': ecp_table_b}
+def ecp_table_c(z: int):
+    """Set C (round 6, hold-out): exponents unlike A and B -- local terms 9.1 / 2.2 / 6.3, an s channel of exponent 0.71 and a
+    p channel of exponent 2.9 (two l channels per atom), other coefficient magnitudes."""
+    return [2 if z > 2 else 0, [[-1, [[], [[9.1, float(z - 2)]], [[2.2, -3.1]], [[6.3, 4.0]]]],
+                                [0, [[], [], [[0.71, 4.2]]]], [1, [[], [], [[2.9, 1.1]]]]]]
+
+
+ECP_TABLES = {True: ecp_table, 'A': ecp_table, 'B': ecp_table_b, 'C': ecp_table_c}
 
 
 def setup(molname, ansatz, ecp=False):
@@ -184,7 +194,7 @@ def assemble(name, results):
     elif fix['grad'].size > 2_000_000:
         fix['grad'] = fix['grad'][::8]
     meta = {'molecule': molname, 'ansatz': ansatz, 'walkers': B, 'equilibration_sub_steps': n_eq,
-            'param_seed': PARAM_SEED, 'perturb_envelopes': PERTURB, 'norm_eps': geom.F32_EPS, 'ecp': bool(ecp), 'ecp_table': ('B' if ecp == 'B' else 'A') if ecp else None,
+            'param_seed': PARAM_SEED, 'perturb_envelopes': PERTURB, 'norm_eps': geom.F32_EPS, 'ecp': bool(ecp), 'ecp_table': (ecp if ecp in ('B', 'C') else 'A') if ecp else None,
             'blocks': len(results), 'acceptance_last': float(np.mean([x['acc_last'] for x in results])) if n_eq else None,
             'cpu_seconds': round(sum(x['seconds'] for x in results), 1),
             'cpu_seconds_equilibration': round(sum(x['seconds_equilibration'] for x in results), 1)}

@@ -159,7 +159,9 @@ def test_f32_parity_at_baseline_size(name):
         assert prof['frac_within_1e-5'] >= frac_min, (key, prof)
         assert prof['p50'] < p50_max and prof['p99'] < p99_max and prof['max'] < max_max, (key, prof)
     if phi is not None:
-        assert out['ecp']['V_loc_rel_err_max'] < 1e-5 and out['ecp']['V_nl_abs_err_max'] < 1e-5 * np.abs(d['e_loc']).max(), out['ecp']
+        # (V_nl enters E_loc ~ 40 Ha: its absolute error is held to 1e-6 of that, ten times inside the tolerance of E_loc itself;
+        # observed 5.9e-7 Ha on set A, 1.3e-5 on B, 2.3e-5 on the hold-out C)
+        assert out['ecp']['V_loc_rel_err_max'] < 1e-5 and out['ecp']['V_nl_abs_err_max'] < 1e-6 * np.abs(d['e_loc']).max(), out['ecp']
     assert np.quantile(lp, 0.99) < lp99_max and np.quantile(lp_rel, 0.99) < 5e-5, payload['logpsi_abs_err']
     if has_f64:
         assert out['eloc_f64']['max'] < 2e-7, out['eloc_f64']          # float32 output rounding of a float64 evaluation
@@ -477,7 +479,37 @@ def test_ecp_thresholds_hold_on_a_second_table_256():
     for key in ('first_call', 'second_call'):
         p = out[key]
         assert p['frac_within_1e-5'] == 1.0 and p['max'] < 1e-5, (key, p)
-        assert p['V_nl_abs_err_max'] < 1e-5 * np.abs(d['e_loc']).max(), (key, p)
+        assert p['V_nl_abs_err_max'] < 1e-6 * np.abs(d['e_loc']).max(), (key, p)      # (1.3e-5 Ha of |E| ~ 42 Ha: 3e-7 relative)
+
+
+def test_ecp_hold_out_table_c_128():
+    """Round 6, the hold-out asked for by the round-5 review: EVERY option of the ECP path frozen at the round-5 defaults
+    ("ecp_heavy_e6" 10000, "ecp_skip_e12" 100, "ecp_dlog_floor_e6" 30 -- the last one was re-tuned after looking at set B),
+    THEN a third synthetic table generated (tests/golden/make_parity_fixtures.py: ecp_table_c -- local exponents 9.1 / 2.2 /
+    6.3, an s channel of exponent 0.71 and a p channel of exponent 2.9, other coefficient magnitudes) at 128
+    |psi|^2-equilibrated benzene walkers, run ONCE at library defaults and reported as it came out
+    (profiles/r06_parity_report.json: ecp_set_c_hold_out_128).  Nothing is tuned on this set; the assertion is a
+    sanity band only -- a failure of the 1e-5 tolerance on a hold-out is a finding to report, not a threshold to move
+    (reference: ecp/gaussian_type_ecp.py:161-255, one precision and no cut-off there)."""
+    d, meta, h, eng = load('benzene_ecpC_psiformer_128')
+    assert meta['ecp_table'] == 'C'
+    r = torch.as_tensor(d['r'], device=DEV)
+    phi = torch.as_tensor(d['ecp_phi'], dtype=torch.float32, device=DEV)
+    out = {}
+    for key in ('first_call', 'second_call'):
+        e, stats = eng.local_energy(r, rng=0, ecp_phi=phi)
+        rel, prof = profile(e.double().cpu().numpy(), d['e_loc'])
+        v_nl = stats['hamil/V_nl'].double().cpu().numpy()
+        prof.update({'n_refined': eng.last_refined(), 'pairs': eng.ecp_counts(), 'refine_info': eng.refine_info(),
+                     'n_beyond_1e-5': int((rel >= 1e-5).sum()),
+                     'V_nl_abs_err_max': float(np.abs(v_nl - d['stats'][3]).max()), 'V_nl_abs_err_p50': float(np.median(np.abs(v_nl - d['stats'][3]))),
+                     'V_nl_abs_mean': float(np.abs(d['stats'][3]).mean()), 'E_abs_max': float(np.abs(d['e_loc']).max())})
+        out[key] = prof
+    report('ecp_set_c_hold_out_128', out)
+    for key in ('first_call', 'second_call'):
+        p = out[key]
+        assert p['frac_within_1e-5'] >= 0.95 and p['max'] < 1e-4, (key, p)       # sanity band; the recorded numbers are the result
+        assert p['V_nl_abs_err_max'] < 1e-6 * np.abs(d['e_loc']).max(), (key, p)
 
 
 @pytest.mark.parametrize('name', ['benzene_psiformer_256', 'c4h4_transpsiformer_512'])
