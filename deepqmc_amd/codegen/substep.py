@@ -39,6 +39,7 @@ DEFAULTS = dict(
                           #   stores are older than its last k LDS reads: no drain of the prefetched fragments)
     wpos=(1, 4, 7, 9),    # fragment positions inside a stage at which a quarter of the next stage is stored / the one after requested
     lazy_ring=1,          # 1: the first ring stage is stored and awaited at the first tape read, not in the prologue
+    dpp_fold=0,           # 1: sender gathers / sums over electrons as v_fmac_f32_dpp / v_add_f32_dpp (one instruction) instead of v_mov_b32_dpp + op
     sgb=0,                # > 0: every scheduling region (between the sched_barriers of group_barrier) ends with a
                           #   sched_group_barrier pipeline {1 MFMA, sgb VALU} x its MFMAs
     defer_epi=0,          # 1: the epilogue (activation, residual, bf16 split) of a layer is interleaved with the MFMAs of the NEXT linear layer
@@ -252,7 +253,7 @@ class Gen:
                     x = f'{src}[{bb}][{s}]'
                     acc = f'quad_bcast<{e0}>({x})'        # (0 + x_e0) + x_e1 ... as the generic kernel's loop
                     for e in range(e0 + 1, e1):
-                        acc = f'({acc} + quad_bcast<{e}>({x}))'
+                        acc = f'quad_add<{e}, {e}, {e}, {e}>({acc}, {x})' if self.opt['dpp_fold'] else f'({acc} + quad_bcast<{e}>({x}))'
                     vals.append(f'({acc} * {inv!r}f)' if e1 > e0 else '0.0f')
             for j in range(4):
                 if vals[2 * j] == '0.0f':
@@ -691,6 +692,9 @@ class Gen:
             for s in range(4):
                 e = None
                 for d in ds:
+                    if self.opt['dpp_fold']:
+                        e = f'quad_fmac<{0 ^ d}, {1 ^ d}, {2 ^ d}, {3 ^ d}>({e if e is not None else "0.0f"}, {gw.name}_e{d}[{bb}][{s}], {gh.name}_n[{bb}][{s}])'
+                        continue
                     term = f'{gw.name}_e{d}[{bb}][{s}] * quad_xor<{d}>({gh.name}_n[{bb}][{s}])'
                     e = f'(0.0f + {term})' if e is None else f'({e} + {term})'
                 self.c(f'{gd.name}_n[{db}][{s}] = {e};')
@@ -718,7 +722,7 @@ class Gen:
                 x = f'{gs.name}_n[{bb}][{s}]'
                 acc = f'(0.0f + quad_bcast<0>({x}))'
                 for e in range(1, self.N):
-                    acc = f'({acc} + quad_bcast<{e}>({x}))'
+                    acc = f'quad_add<{e}, {e}, {e}, {e}>({acc}, {x})' if self.opt['dpp_fold'] else f'({acc} + quad_bcast<{e}>({x}))'
                 self.c(f'{gd.name}_n[{bb}][{s}] = {acc};')
         if n_lin:
             self.c(f'BfFrag {gd.name}p_n[3][{gd.nch}];')

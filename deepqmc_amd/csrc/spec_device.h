@@ -143,6 +143,25 @@ template <int P0, int P1, int P2, int P3> __device__ __forceinline__ float quad_
   return __shfl(v, (l & ~3) | p[l & 3], 64);
 #endif
 }
+// acc + w * h[quad_perm] and a + b[quad_perm] as ONE VALU instruction each (v_fmac_f32_dpp / v_add_f32_dpp: the permuted operand rides in
+// the instruction's DPP modifier; the compiler keeps the v_mov_b32_dpp of the builtin as an instruction of its own)
+template <int P0, int P1, int P2, int P3> __device__ __forceinline__ float quad_fmac(float acc, float w, float h) {
+#if defined(__HIPCC__)
+  asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(h), "v"(w), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
+  return acc;
+#else
+  return __builtin_fmaf(w, quad_perm<P0, P1, P2, P3>(h), acc);
+#endif
+}
+template <int P0, int P1, int P2, int P3> __device__ __forceinline__ float quad_add(float a, float b) {
+#if defined(__HIPCC__)
+  float r;
+  asm("v_add_f32_dpp %0, %1, %2 quad_perm:[%3,%4,%5,%6] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(b), "v"(a), "n"(P0), "n"(P1), "n"(P2), "n"(P3));
+  return r;
+#else
+  return a + quad_perm<P0, P1, P2, P3>(b);
+#endif
+}
 template <int X> __device__ __forceinline__ float quad_xor(float v) { return quad_perm<(0 ^ X), (1 ^ X), (2 ^ X), (3 ^ X)>(v); }
 template <int E> __device__ __forceinline__ float quad_bcast(float v) { return quad_perm<E, E, E, E>(v); }
 
