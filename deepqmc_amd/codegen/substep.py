@@ -131,6 +131,8 @@ class Gen:
         self.pairs: Dict[int, List[Tuple[int, int]]] = {}
         self.uid = 0
         self.tail = None
+        self.writers_done: Dict[int, int] = {}            # LINEAR ops emitted so far per destination buffer (row-partitioned outputs)
+        self.conv_done: Dict[int, set] = {}               # blocks of a convolution's destination written so far
         self.xch_bytes = 0                              # LDS behind the ring: operand / result exchange of the shared mean products
 
     # ---- code stream ----
@@ -214,15 +216,6 @@ class Gen:
         if len(prs) != len(by_d) * self.N:
             raise Unsupported('duplicate edge rows')
         return tuple(f'e{d}' for d in sorted(by_d))
-
-    def declare(self, gb: GBuf, f32: bool, planes: bool):
-        for rb in gb.rbs:
-            if f32 and not gb.has_f32:
-                self.c(f'float {gb.name}_{rb}[{gb.nb}][4];')
-            if planes and not gb.has_planes:
-                self.c(f'BfFrag {gb.name}p_{rb}[3][{gb.nch}];')
-        gb.has_f32 = gb.has_f32 or f32
-        gb.has_planes = gb.has_planes or planes
 
     def emit_split_blocks(self, gb: GBuf, rb, blocks):
         """planes of the chunks completed by `blocks` (f32 registers must hold them)"""
@@ -413,16 +406,12 @@ class Gen:
         flush_rep()
         # ---- destination ----
         drows = self.bufs[dst][0]
+        dkey = (dst, -1)
         if rbs == ('n',):
-            if drows == self.N:
-                dkey = (dst, -1)
-            elif drows == 1:
-                dkey = (dst, -1)
-            else:
+            if drows not in (self.N, 1):
                 raise Unsupported('linear layer into a multi-row per-walker buffer')
             d_rbs = ('n',)
         else:
-            dkey = (dst, -1)
             if dst not in self.pairs:
                 self.pairs[dst] = [None] * drows
             src_b = i[1]
@@ -436,7 +425,6 @@ class Gen:
         if dkey not in self.g:
             self.g[dkey] = GBuf(f'b{dst}', dwidth, 'blocks', ())
             self.g[dkey].has_f32, self.g[dkey].has_planes = need_f32, need_pl
-            self.writers_done = getattr(self, 'writers_done', {})
             self.writers_done[dst] = 0
         gd = self.g[dkey]
         for rb in d_rbs:                      # registers of row blocks this op is the first to write
@@ -448,7 +436,7 @@ class Gen:
                     self.c(f'BfFrag {gd.name}p_{rb}[3][{gd.nch}];')
         first_writer = self.writers_done[dst] == 0
         self.writers_done[dst] += 1
-        n_writers = sum(1 for o2 in self.ops if o2.kind == OP_LINEAR and o2.i[17] == dst and (rbs != ('n',) or True))
+        n_writers = sum(1 for o2 in self.ops if o2.kind == OP_LINEAR and o2.i[17] == dst)
         last_writer = self.writers_done[dst] == n_writers
         if dcol0 % 32 and need_pl:
             raise Unsupported('destination column offset inside a k-chunk')
@@ -700,7 +688,6 @@ class Gen:
                 self.c(f'{gd.name}_n[{db}][{s}] = {e};')
         if gd.has_planes:
             # chunks whose two blocks are both written by now
-            self.conv_done = getattr(self, 'conv_done', {})
             done = self.conv_done.setdefault(dst, set())
             done |= blocks
             ready = {b for b in blocks if (b ^ 1) in done or (b ^ 1) >= gd.nb}
