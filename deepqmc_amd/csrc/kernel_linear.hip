@@ -76,6 +76,15 @@ __device__ __forceinline__ TileId tile_of_block() {
   return t;
 }
 
+// A wave-uniform element offset into scalar registers: base (a kernel argument) + offset is then the SGPR base of the global
+// loads / stores, which take a 32-bit lane offset on top; values the compiler merely knows to be uniform stay in vector
+// registers and every access pays a 64-bit vector add.
+__device__ __forceinline__ long uniform_off(long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long)(((unsigned long long)hi << 32) | lo);
+}
+
 template <int BN> struct BStride { static constexpr int v = ((BN + 16) % 32 == 16) ? BN + 16 : BN + 32; };
 
 // Where the epilogue puts its results.  HbmSink: the layer's output buffer (+ residual).  LdsSink: the hidden tile of a
@@ -117,6 +126,43 @@ template <typename real> struct HbmSink {
   }
   __device__ __forceinline__ real fetch(int slot, int t, int col, bool ok) const { return fetch_at((slot ? rrow0[1] : rrow0[0]) + t, col, ok); }
   __device__ __forceinline__ void put(int slot, int t, int tile_row, int col, real o, real r, bool ok) { put_at((slot ? drow0[1] : drow0[0]) + t, tile_row, col, o, r, ok); }
+  // Uniform-base access (the 16-lane-block groups): `g` is WAVE-UNIFORM, so the 64-bit row arithmetic of a group runs once on
+  // the scalar unit and a lane adds a 32-bit element offset (row t of the group, column c of the wave's tile) -- the per-lane
+  // form above spent ~30 vector instructions per element on 64-bit multiplies that every lane of the wave computed alike.
+  static constexpr bool fills = false;     // (elements that do not exist are skipped, not zero-filled)
+  real* udst; const real* ures;
+  __device__ __forceinline__ void ugroup(int g, int col_w0) {
+    const int b = g / nrows, rr = g - b * nrows;
+    udst = dst + uniform_off(((long)b * rpw_dst + r0_dst + rr) * TP * ld_dst + col0_dst + col_w0);
+    ures = res ? res + uniform_off(((long)b * rpw_res + r0_res + rr) * TP * ld_res + col0_dst + col_w0) : nullptr;
+  }
+  // (32-bit BYTE offsets: an element index the compiler would have to scale by sizeof(real) in 64 bits, per access)
+  __device__ __forceinline__ real ufetch(int t, int c) const {
+    return ures ? *reinterpret_cast<const real*>(reinterpret_cast<const char*>(ures) + (unsigned)((t * ld_res + c) * (int)sizeof(real))) : (real)0;
+  }
+  __device__ __forceinline__ void uput(int t, int /*tile_row*/, int c, real o, real r) {
+    if (ures != nullptr) o = (r + o) * res_scale;
+    *reinterpret_cast<real*>(reinterpret_cast<char*>(udst) + (unsigned)((t * ld_dst + c) * (int)sizeof(real))) = o;
+  }
+  // a PAIR of consecutive groups g, g + 1 (the two 8-lane groups of a row block): the base is group g's, a lane of group
+  // g + 1 adds the (uniform, small, non-negative) distance in bytes
+  unsigned udd, urd;
+  __device__ __forceinline__ void ugroup2(int g, bool second, int col_w0) {
+    ugroup(g, col_w0);
+    udd = urd = 0;
+    if (second) {
+      const int b0 = g / nrows, rr0 = g - b0 * nrows, b1 = (g + 1) / nrows, rr1 = g + 1 - b1 * nrows;
+      udd = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long)(b1 - b0) * rpw_dst + (rr1 - rr0)) * TP * ld_dst) * (long)sizeof(real)));
+      urd = (unsigned)__builtin_amdgcn_readfirstlane((int)((((long)(b1 - b0) * rpw_res + (rr1 - rr0)) * TP * ld_res) * (long)sizeof(real)));
+    }
+  }
+  __device__ __forceinline__ real ufetch2(bool h, int t, int c) const {
+    return ures ? *reinterpret_cast<const real*>(reinterpret_cast<const char*>(ures) + ((h ? urd : 0u) + (unsigned)((t * ld_res + c) * (int)sizeof(real)))) : (real)0;
+  }
+  __device__ __forceinline__ void uput2(bool h, int t, int /*tile_row*/, int c, real o, real r) {
+    if (ures != nullptr) o = (r + o) * res_scale;
+    *reinterpret_cast<real*>(reinterpret_cast<char*>(udst) + ((h ? udd : 0u) + (unsigned)((t * ld_dst + c) * (int)sizeof(real)))) = o;
+  }
 };
 template <typename real> struct LdsSink {
   real* hs;
@@ -127,6 +173,14 @@ template <typename real> struct LdsSink {
   __device__ __forceinline__ void put_at(long, int tile_row, int col, real o, real, bool ok) { hs[tile_row * stride + col] = ok ? o : (real)0; }
   __device__ __forceinline__ real fetch(int, int, int, bool) const { return (real)0; }
   __device__ __forceinline__ void put(int, int, int tile_row, int col, real o, real, bool ok) { put_at(0, tile_row, col, o, (real)0, ok); }
+  static constexpr bool fills = true;      // rows / columns that do not exist are written as zeros (the second product reads whole chunks)
+  int ucol;
+  __device__ __forceinline__ void ugroup(int, int col_w0) { ucol = col_w0; }
+  __device__ __forceinline__ real ufetch(int, int) const { return (real)0; }
+  __device__ __forceinline__ void uput(int, int tile_row, int c, real o, real) { hs[tile_row * stride + ucol + c] = o; }
+  __device__ __forceinline__ void ugroup2(int, bool, int col_w0) { ucol = col_w0; }
+  __device__ __forceinline__ real ufetch2(bool, int, int) const { return (real)0; }
+  __device__ __forceinline__ void uput2(bool, int, int tile_row, int c, real o, real) { hs[tile_row * stride + ucol + c] = o; }
 };
 
 // the nonlinearity alone, for a compile-time activation code (value rows: no derivatives, no per-element dispatch)
@@ -200,61 +254,92 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
   constexpr int GB = GPW > 0 ? MR / GPW : 1;
   const int lane = threadIdx.x & 63, cl = lane & 15;
   if (HALF) {
-    // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15); a lane's four rows
-    // (Mfma::row_of) may belong to one group (f32 layout) or to both (f64 layout), so the value lane and
-    // the sum of squared derivative lanes of each group are gathered with quad reductions.
+    // row block i holds groups 2*i (rows 0..7) and 2*i + 1 (rows 8..15), both wave-uniform (see the GPW > 0 branch below:
+    // scalar bases, 32-bit lane offsets).  float32 layout: a lane's four rows 4 q + 0..3 lie in ONE group (h = q >> 1): its
+    // value lane comes from lane 32 h + column, register 0, sum_c J_c^2 from the lane 16 apart; float64 layout (rows
+    // q + 4 reg): registers 0, 1 belong to the first group, 2, 3 to the second, every lane evaluates both.
+    constexpr bool F32L = sizeof(real) == 4;
+    const int wmu = __builtin_amdgcn_readfirstlane(wm);
+    const int Tm1 = a.T - 1;
+    const int q = lane >> 4;
+    real bvh[NR];
+    bool col_ok[NR];
+#pragma unroll
+    for (int n = 0; n < NR; ++n) {
+      const int col = col_w0 + n * 16 + cl;
+      col_ok[n] = col < ldw;
+      bvh[n] = (bias != nullptr && col_ok[n]) ? bias[col] : (real)0;
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      bool g_ok[2];
+      const int g0 = ((bx * 4 + wmu) * MR + i) * 2;
+      const bool ok0 = g0 < n_groups, ok1 = g0 + 1 < n_groups;      // wave-uniform
+      if (!ok0) {
+        if constexpr (Sink::fills) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int g = ((bx * 4 + wm) * MR + i) * 2 + h;
-        g_ok[h] = g < n_groups;
-        sink.group(h, g_ok[h] ? g : 0);
+          for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) sink.uput2(false, 0, wm * (16 * MR) + i * 16 + Mfma<real>::row_of(lane, rg), n * 16 + cl, (real)0, (real)0);
+        }
+        continue;
       }
-      real bvh[NR];                           // (bias columns and the residuals of the whole row block before its first store: HbmSink::fetch)
-#pragma unroll
-      for (int n = 0; n < NR; ++n) { const int col = col_w0 + n * 16 + cl; bvh[n] = (bias != nullptr && col < ldw) ? bias[col] : (real)0; }
-      real rres[NR][4];
+      sink.ugroup2(g0, ok1, col_w0);
+      real rres[NR][4];                           // (the residuals of the whole row block before its first store)
 #pragma unroll
       for (int n = 0; n < NR; ++n)
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, col = col_w0 + n * 16 + cl;
-          rres[n][rg] = sink.fetch(h, row & 7, col, col < ldw && (h ? g_ok[1] : g_ok[0]));
+          const int row = Mfma<real>::row_of(lane, rg);
+          const bool h = row >> 3;
+          rres[n][rg] = (col_ok[n] && (!h || ok1)) ? sink.ufetch2(h, row & 7, n * 16 + cl) : (real)0;
         }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-        const int col = col_w0 + n * 16 + cl;
-        const bool col_ok = col < ldw;
-        real v_part[2] = {0, 0}, s_part[2] = {0, 0};
+        real y[2], d1[2], d2S[2];
+        if constexpr (F32L) {
+          real v = __shfl(acc[i][n][0], (lane & 32) + cl, 64) + bvh[n];
+          real s_part = 0;
+#pragma unroll
+          for (int rg = 0; rg < 4; ++rg) {
+            const int tt = (4 * q + rg) & 7;
+            const real x = acc[i][n][rg];
+            if (tt > 0 && tt < Tm1) s_part += x * x;
+          }
+          const real S = s_part + __shfl_xor(s_part, 16, 64);
+          real d2;
+          act_derivs<real>(act, v, y[0], d1[0], d2);
+          d2S[0] = d2 * S;
+          y[1] = y[0]; d1[1] = d1[0]; d2S[1] = d2S[0];
+        } else {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const real v = __shfl(acc[i][n][2 * h], cl, 64) + bvh[n];
+            real s_part = 0;
+#pragma unroll
+            for (int rg = 2 * h; rg < 2 * h + 2; ++rg) {
+              const int tt = Mfma<real>::row_of(lane, rg) & 7;
+              const real x = acc[i][n][rg];
+              if (tt > 0 && tt < Tm1) s_part += x * x;
+            }
+            const real S = quad_sum<real>(s_part);
+            real d2;
+            act_derivs<real>(act, v, y[h], d1[h], d2);
+            d2S[h] = d2 * S;
+          }
+        }
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
+          const int row = Mfma<real>::row_of(lane, rg), tt = row & 7;
+          const bool h = row >> 3;
+          const int hs_ = F32L ? 0 : (rg >> 1);
           const real x = acc[i][n][rg];
-          const real vx = tt == 0 ? x : (real)0, sx = (tt > 0 && tt < a.T - 1) ? x * x : (real)0;
-          v_part[0] += h ? (real)0 : vx; v_part[1] += h ? vx : (real)0;
-          s_part[0] += h ? (real)0 : sx; s_part[1] += h ? sx : (real)0;
-        }
-        real y[2], d1[2], d2[2], S[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          real v = quad_sum<real>(v_part[h]);
-          S[h] = quad_sum<real>(s_part[h]);
-          if (bias != nullptr && col_ok) v += bvh[n];
-          act_derivs<real>(act, v, y[h], d1[h], d2[h]);
-        }
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int row = Mfma<real>::row_of(lane, rg), h = row >> 3, tt = row & 7;
-          const real x = acc[i][n][rg];
-          const real yh = h ? y[1] : y[0], d1h = h ? d1[1] : d1[0], d2h = h ? d2[1] : d2[0], Sh = h ? S[1] : S[0];
-          real o;
-          if (tt == 0) o = yh;
-          else if (tt < a.T - 1) o = d1h * x;
-          else if (tt == a.T - 1) o = d1h * x + d2h * Sh;
-          else o = 0;
-          sink.put(h, tt, wm * (16 * MR) + i * 16 + row, col, o, rres[n][rg], col_ok && (h ? g_ok[1] : g_ok[0]));
+          real o = d1[hs_] * x;
+          if (tt == Tm1) o += d2S[hs_];
+          if (tt == 0) o = y[hs_];
+          if (tt > Tm1) o = 0;
+          const bool ok = col_ok[n] && (!h || ok1);
+          if constexpr (Sink::fills) sink.uput2(h, tt, wm * (16 * MR) + i * 16 + row, n * 16 + cl, ok ? o : (real)0, rres[n][rg]);
+          else if (ok) sink.uput2(h, tt, wm * (16 * MR) + i * 16 + row, n * 16 + cl, o, rres[n][rg]);
         }
       }
     }
@@ -336,64 +421,69 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
     }
   } else if (GPW > 0) {
     constexpr int NG = GPW > 0 ? GPW : 1;
-    // Everything the stores of this tile depend on is requested BEFORE the first store (a load cannot pass an earlier store
-    // to a possibly aliasing buffer): bias columns always; the residuals of the whole tile where they fit (HOIST: at most 32
-    // registers -- the 16- / 32- / 48-lane tiles of the small and mid-size systems), else per column block in batches of FB
-    // row blocks.
-    constexpr bool HOIST = NG * GB * NR * 4 * (int)(sizeof(real) / 4) <= 32;
-    long drow[NG], rrow[NG];
-    bool g_ok[NG];
-    int bw[NG];
-#pragma unroll
-    for (int gj = 0; gj < NG; ++gj) {
-      const int g = (bx * 4 + wm) * GPW + gj;
-      g_ok[gj] = g < n_groups;               // wave-uniform
-      bw[gj] = (g_ok[gj] ? g : 0) / a.nrows;
-      sink.rows(g_ok[gj] ? g : 0, drow[gj], rrow[gj]);
-    }
+    // A group (walker, row) is GB consecutive row blocks of ONE wave, so everything that names the group -- its index, its
+    // walker, the 64-bit bases of its destination / residual / per-walker rows -- is wave-uniform: computed on the scalar unit
+    // (the wave index goes through readfirstlane: as a function of threadIdx.x the compiler had to assume it varies per lane
+    // and ran all of it, 64-bit multiplies included, on the vector unit for every element: 7 vector instructions per MFMA for
+    // the K = 192 node layer of LiH, 30-60 for the narrow edge layers).  A lane adds 32-bit offsets t * ld + column.
+    // Everything the stores of a group depend on is requested BEFORE its first store (a load cannot pass an earlier store
+    // to a possibly aliasing buffer): the per-walker rows, and the residuals of the whole group where they fit (HOIST: at
+    // most 32 registers), else per column block in batches of FB row blocks.
+    constexpr bool HOIST = GB * NR * 4 * (int)(sizeof(real) / 4) <= 32;
+    const int wmu = __builtin_amdgcn_readfirstlane(wm);
+    const int Tm1 = a.T - 1;
     real bv[NR];
+    bool col_ok[NR];
 #pragma unroll
     for (int n = 0; n < NR; ++n) {
       const int col = col_w0 + n * 16 + cl;
-      bv[n] = (bias != nullptr && col < ldw) ? bias[col] : (real)0;
-    }
-    real rall[HOIST ? NG : 1][HOIST ? NR : 1][HOIST ? GB : 1][4];
-    if constexpr (HOIST) {
-#pragma unroll
-      for (int gj = 0; gj < NG; ++gj)
-#pragma unroll
-        for (int n = 0; n < NR; ++n)
-#pragma unroll
-          for (int tb = 0; tb < GB; ++tb)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int col = col_w0 + n * 16 + cl;
-              rall[gj][n][tb][rg] = sink.fetch_at(rrow[gj] + tb * 16 + Mfma<real>::row_of(lane, rg), col, col < ldw && g_ok[gj]);
-            }
+      col_ok[n] = col < ldw;
+      bv[n] = (bias != nullptr && col_ok[n]) ? bias[col] : (real)0;
     }
 #pragma unroll
     for (int gj = 0; gj < NG; ++gj) {
-      if (pre != nullptr && g_ok[gj]) {  // per-walker part of the pre-activation (all lanes: the layer is linear in them)
+      const int g = (bx * 4 + wmu) * GPW + gj;
+      if (g >= n_groups) {                       // wave-uniform
+        if constexpr (Sink::fills) {
+#pragma unroll
+          for (int n = 0; n < NR; ++n)
+#pragma unroll
+            for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+              for (int rg = 0; rg < 4; ++rg)
+                sink.uput(0, wm * (16 * MR) + (gj * GB + tb) * 16 + Mfma<real>::row_of(lane, rg), n * 16 + cl, (real)0, (real)0);
+        }
+        continue;
+      }
+      sink.ugroup(g, col_w0);
+      if (pre != nullptr) {                      // per-walker part of the pre-activation (all lanes: the layer is linear in them)
+        const real* pw = pre + uniform_off((long)(g / a.nrows) * a.TP * a.ld_pre + col_w0);
 #pragma unroll
         for (int n = 0; n < NR; ++n) {
-          const int col = col_w0 + n * 16 + cl;
-          if (col < ldw) {
+          if (col_ok[n]) {
 #pragma unroll
             for (int tb = 0; tb < GB; ++tb)
 #pragma unroll
               for (int rg = 0; rg < 4; ++rg) {
                 const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
-                acc[gj * GB + tb][n][rg] += pre[((long)bw[gj] * a.TP + t) * a.ld_pre + col];
+                acc[gj * GB + tb][n][rg] += *reinterpret_cast<const real*>(reinterpret_cast<const char*>(pw) + (unsigned)((t * a.ld_pre + n * 16 + cl) * (int)sizeof(real)));
               }
           }
         }
       }
+      real rall[HOIST ? NR : 1][HOIST ? GB : 1][4];
+      if constexpr (HOIST) {
+#pragma unroll
+        for (int n = 0; n < NR; ++n)
+#pragma unroll
+          for (int tb = 0; tb < GB; ++tb)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+              rall[n][tb][rg] = col_ok[n] ? sink.ufetch(tb * 16 + Mfma<real>::row_of(lane, rg), n * 16 + cl) : (real)0;
+      }
 #pragma unroll
       for (int n = 0; n < NR; ++n) {
-        const int col = col_w0 + n * 16 + cl;
-        const bool col_ok = col < ldw;
-        real v = __shfl(acc[gj * GB][n][0], cl, 64);
-        if (bias != nullptr && col_ok) v += bv[n];
+        real v = __shfl(acc[gj * GB][n][0], cl, 64) + bv[n];
         real s_part = 0;
 #pragma unroll
         for (int tb = 0; tb < GB; ++tb)
@@ -401,11 +491,12 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           for (int rg = 0; rg < 4; ++rg) {
             const int t = tb * 16 + Mfma<real>::row_of(lane, rg);
             const real x = acc[gj * GB + tb][n][rg];
-            if (t >= 1 && t < a.T - 1) s_part += x * x;
+            if (t >= 1 && t < Tm1) s_part += x * x;
           }
         const real S = quad_sum<real>(s_part);
         real y, d1, d2;
         act_derivs<real>(act, v, y, d1, d2);
+        const real d2S = d2 * S;
         // (not hoisted: float64 two row blocks at a time -- the tall tiles have no registers to spare; GB = 4 in float32 too:
         // 16 more registers would cost the 64-lane tiles a workgroup per CU)
         constexpr int FB = HOIST ? GB : (((sizeof(real) == 8 && GB > 2) || GB == 4) ? 2 : GB);
@@ -416,23 +507,25 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           for (int tb = 0; tb < FB; ++tb)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-              if constexpr (HOIST) rres[tb][rg] = rall[gj][n][tb][rg];
-              else rres[tb][rg] = (tb0 + tb < GB) ? sink.fetch_at(rrow[gj] + (tb0 + tb) * 16 + Mfma<real>::row_of(lane, rg), col, col_ok && g_ok[gj]) : (real)0;
+              if constexpr (HOIST) rres[tb][rg] = rall[n][tb][rg];
+              else rres[tb][rg] = (tb0 + tb < GB && col_ok[n]) ? sink.ufetch((tb0 + tb) * 16 + Mfma<real>::row_of(lane, rg), n * 16 + cl) : (real)0;
             }
+          if (Sink::fills || col_ok[n]) {
 #pragma unroll
-          for (int tb = tb0; tb < tb0 + FB && tb < GB; ++tb)
+            for (int tb = tb0; tb < tb0 + FB && tb < GB; ++tb)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              const int row = Mfma<real>::row_of(lane, rg);
-              const int t = tb * 16 + row;
-              const real x = acc[gj * GB + tb][n][rg];
-              real o;
-              if (t == 0) o = y;
-              else if (t < a.T - 1) o = d1 * x;
-              else if (t == a.T - 1) o = d1 * x + d2 * S;
-              else o = 0;
-              sink.put_at(drow[gj] + t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, col, o, rres[tb - tb0][rg], col_ok && g_ok[gj]);
-            }
+              for (int rg = 0; rg < 4; ++rg) {
+                const int row = Mfma<real>::row_of(lane, rg);
+                const int t = tb * 16 + row;
+                const real x = acc[gj * GB + tb][n][rg];
+                real o = d1 * x;
+                if (t == Tm1) o += d2S;
+                if (t == 0) o = y;
+                if (t > Tm1) o = 0;
+                if (Sink::fills && !col_ok[n]) o = 0;
+                sink.uput(t, wm * (16 * MR) + (gj * GB + tb) * 16 + row, n * 16 + cl, o, rres[tb - tb0][rg]);
+              }
+          }
         }
       }
     }
@@ -1006,7 +1099,10 @@ template <typename real, int MR, int NR, int GPW, int WN> struct BfLaunch {
 template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, WN> {
   static bool run(hipStream_t st, const LinArgs<float>& a, unsigned gx, unsigned gy) {
     if (!bf_pays(a, GPW == 0 ? 6 : 9)) return false;
-    if (a.cfg_bf >= 2 && !(GPW > 0 && MR == 3 && WN == 1)) return false;      // 2: only the 48-lane Laplacian tiles (measured faster there)
+    // 2 (default): the Laplacian tiles of the 48-lane groups (11-15 electrons: measured faster there) and of the 16-lane groups (up
+    // to 4 electrons: same speed since the epilogue went lean, but the nine-product sum rounds less often than the f32 MFMA chain --
+    // LiH / PauliNet, 4096 walkers: 872 -> 739 walkers re-evaluated in float64 per E_loc call, 2.41 -> 2.30 ms per call)
+    if (a.cfg_bf >= 2 && !(GPW > 0 && ((MR == 3 && WN == 1) || MR == GPW))) return false;
     launch_bf<MR, NR, GPW, WN>(st, a, gx, gy);
     return true;
   }

@@ -324,8 +324,9 @@ int dqmc_ecp_counts(dqmc_ctx* ctx, int64_t* out3);
  * fused kernel whose pieces are whole octets wide run on the bf16 matrix pipe -- operands split into three bf16 pieces,
  * six v_mfma_f32_16x16x32_bf16 per 16 x 16 x 32 block, float32-class results; 2: only the layers deep enough to pay by
  * the stricter rule; 0: v_mfma_f32_16x16x4_f32 everywhere); "linear_bf" (2): the same split with nine
- * products for the per-op linear kernel -- 2: only the Laplacian tiles of the 48-lane groups (11-15 electrons), where it is
- * faster; 1: every layer deep enough (measured slower elsewhere); 0: never; "dual_stream" (1): edge stream of the Laplacian pass on a
+ * products for the per-op linear kernel -- 2: the Laplacian tiles of the 48-lane groups (11-15 electrons), where it is
+ * faster, and of the 16-lane groups (up to 4 electrons), where it costs the same and rounds less often (fewer walkers reach the
+ * float64 pass); 1: every layer deep enough (measured slower elsewhere); 0: never; "dual_stream" (1): edge stream of the Laplacian pass on a
  * companion HIP stream; options prefixed "twin." go to the float64 refinement twin;
  * "pass_graph" (1): a forward-Laplacian pass that fits one workspace chunk is captured into a hipGraph on its second call
  * with the same buffers and batch size and replayed afterwards (one hipGraphLaunch instead of ~40 launches and their
