@@ -1109,7 +1109,8 @@ template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, W
 };
 
 // A/B hook (dqmc_set_option "linear_bkx", per context: LinArgs::cfg_bkx): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
-// 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both
+// 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 (default) = both (LiH / PauliNet E_loc
+// pass 2.41 -> 2.38 ms with the float32 small tiles included)
 // float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
 // alone are 96 / 128 registers and ONE wave per SIMD remains (hence the split groups below)
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {

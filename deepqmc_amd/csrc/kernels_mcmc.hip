@@ -118,13 +118,14 @@ __device__ __forceinline__ double block_max(double v, double* sh) {
 }
 
 // compute_stats (electron_samplers.py:154-163): acceptance, tau, age mean/max, log|psi| mean/std
-// (population), mean pairwise e-e distance.  One 256-thread block.
+// (population), mean pairwise e-e distance.  One 1024-thread block (16 waves: with 256 threads a thread walked 16 walkers x N (N - 1) / 2
+// float64 square roots, 29 us on the critical path of every VMC step).
 template <typename real>
-__global__ void __launch_bounds__(256) k_sampler_stats(const real* __restrict__ r, const real* __restrict__ logpsi,
+__global__ void __launch_bounds__(1024) k_sampler_stats(const real* __restrict__ r, const real* __restrict__ logpsi,
                                                        const int32_t* __restrict__ age, const real* __restrict__ tau,
                                                        const double* __restrict__ acc, int B, int N, double eps,
                                                        double* __restrict__ out7) {
-  __shared__ double sh[4];
+  __shared__ double sh[16];
   double s_age = 0, m_age = 0, s_lp = 0, s_d = 0;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     s_age += age[b];
@@ -160,9 +161,9 @@ __global__ void __launch_bounds__(256) k_sampler_stats(const real* __restrict__ 
 // Per-rank record {n, sum_w, sum_wE, sum_E, M2, min, max} of the energy reduction
 // (observable.py:474-479, parallel.py:175-225), merged across ranks on the host.
 template <typename real>
-__global__ void __launch_bounds__(256) k_energy_stats(const real* __restrict__ e, const real* __restrict__ w, int B,
-                                                      double* __restrict__ out7) {
-  __shared__ double sh[4];
+__global__ void __launch_bounds__(1024) k_energy_stats(const real* __restrict__ e, const real* __restrict__ w, int B,
+                                                       double* __restrict__ out7) {
+  __shared__ double sh[16];
   double sw = 0, swe = 0, se = 0, mn = INFINITY, mx = -INFINITY;
   for (int b = threadIdx.x; b < B; b += blockDim.x) {
     const double x = (double)e[b], ww = w ? (double)w[b] : 1.0;
@@ -212,12 +213,12 @@ void launch_tau_finalize(hipStream_t st, real* tau, const real* tau_ring, int32_
 template <typename real>
 void launch_sampler_stats(hipStream_t st, const real* r, const real* logpsi, const int32_t* age, const real* tau,
                           const double* acc, int B, int N, double eps, double* stats7) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sampler_stats<real>), dim3(1), dim3(256), 0, st, r, logpsi, age, tau, acc, B, N,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sampler_stats<real>), dim3(1), dim3(1024), 0, st, r, logpsi, age, tau, acc, B, N,
                      eps, stats7);
 }
 template <typename real>
 void launch_energy_stats(hipStream_t st, const real* e_loc, const real* w, int B, double* out7) {
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_energy_stats<real>), dim3(1), dim3(256), 0, st, e_loc, w, B, out7);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_energy_stats<real>), dim3(1), dim3(1024), 0, st, e_loc, w, B, out7);
 }
 
 // ---- Metropolis-adjusted Langevin sampler and opposite-spin exchange steps --------------------------------

@@ -11,7 +11,7 @@ for L in "$@"; do
   python - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in rows[:14]: print('%9.1f us x %4s  %5.1f%%  %s' % (float(r['AverageNs']) / 1e3, r['Calls'], float(r['Percentage']), r['Name'][:100]))
+for r in rows[:int(__import__("os").environ.get("NTOP","14"))]: print('%9.1f us x %4s  %5.1f%%  %s' % (float(r['AverageNs']) / 1e3, r['Calls'], float(r['Percentage']), r['Name'][:100]))
 PY
 done
 cp /tmp/keep.so deepqmc_amd/csrc/libdqmc_hip.so
