@@ -108,6 +108,10 @@ template <typename real, int VW> struct VecN {
   __device__ __forceinline__ void axpy(real s, const VecN& a) { for (int j = 0; j < VW; ++j) v[j] += s * a.v[j]; }
 };
 
+// a * b + c with one rounding
+template <typename real> __device__ __forceinline__ real r_fma(real a, real b, real c);
+template <> __device__ __forceinline__ float r_fma<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double r_fma<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
 template <typename real> __device__ __forceinline__ real r_tanh(real x);
 // f32 tanh in ~15 VALU instructions (libm tanhf is ~100 and dominated the small layers of the
 // fused kernel): odd polynomial for |x| < 0.25 (truncation < 3e-9), (1 - e)/(1 + e) with

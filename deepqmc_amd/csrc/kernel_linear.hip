@@ -333,8 +333,8 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
           const bool h = row >> 3;
           const int hs_ = F32L ? 0 : (rg >> 1);
           const real x = acc[i][n][rg];
-          real o = d1[hs_] * x;
-          if (tt == Tm1) o += d2S[hs_];
+          // (ONE fused multiply-add on every lane: d1 x rounded on its own and d2 S added afterwards costs the Laplacian lane a rounding per layer)
+          real o = r_fma<real>(d1[hs_], x, tt == Tm1 ? d2S[hs_] : (real)0);
           if (tt == 0) o = y[hs_];
           if (tt > Tm1) o = 0;
           const bool ok = col_ok[n] && (!h || ok1);
@@ -518,8 +518,9 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
                 const int row = Mfma<real>::row_of(lane, rg);
                 const int t = tb * 16 + row;
                 const real x = acc[gj * GB + tb][n][rg];
-                real o = d1 * x;
-                if (t == Tm1) o += d2S;
+                // (ONE fused multiply-add on every lane: with d1 x rounded on its own and d2 S added afterwards the Laplacian lane pays a
+                // rounding more per layer -- N2 / FermiNet: 12.6 % -> 17.4 % of the walkers re-evaluated in float64)
+                real o = r_fma<real>(d1, x, t == Tm1 ? d2S : (real)0);
                 if (t == 0) o = y;
                 if (t > Tm1) o = 0;
                 if (Sink::fills && !col_ok[n]) o = 0;
@@ -1109,8 +1110,9 @@ template <int MR, int NR, int GPW, int WN> struct BfLaunch<float, MR, NR, GPW, W
 };
 
 // A/B hook (dqmc_set_option "linear_bkx", per context: LinArgs::cfg_bkx): 1 = 16-wide chunks everywhere, 2 = 32-wide chunks for the float32 small tiles,
-// 3 = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 (default) = both (LiH / PauliNet E_loc
-// pass 2.41 -> 2.38 ms with the float32 small tiles included)
+// 3 (default) = for the float64 small tiles (the refinement twin's batches of a few hundred walkers), 4 = both (float32 too: LiH / PauliNet
+// E_loc pass 2.41 -> 2.38 ms, but the fresh accumulator of a 32-wide chunk rounds twice as often as that of a 16-wide one -- N2 / FermiNet:
+// error scale m 4.1e-9 -> 4.7e-9, 14.4 % -> 17.4 % of the walkers re-evaluated in float64, 49.1 -> 50.6 ms per step)
 // float64, 96- / 128-lane groups (28 / 42 electrons): MR = 6 / 8 row blocks per wave; with two column blocks the accumulators
 // alone are 96 / 128 registers and ONE wave per SIMD remains (hence the split groups below)
 template <typename real> static bool wide_chunks(const LinArgs<real>& a) {

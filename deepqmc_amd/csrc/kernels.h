@@ -73,7 +73,7 @@ template <typename real> struct LinArgs {
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out);
-constexpr int LINEAR_BF_DEFAULT = 2, LINEAR_BKX_DEFAULT = 4;      // (kernel_linear.hip: what the values select)
+constexpr int LINEAR_BF_DEFAULT = 2, LINEAR_BKX_DEFAULT = 3;      // (kernel_linear.hip: what the values select)
 
 // ---- kernel_fused2.hip: LDS-resident value-only psi evaluation, descriptor driven ----
 struct FusedBuf {
