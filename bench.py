@@ -504,7 +504,8 @@ def main():
         sync()
         rep = eng.timing_report()
         eng.timing(False)
-        names = {'linear': 'k_linear (forward-Laplacian linear layer, v_mfma_f32_16x16x4_f32)',
+        names = {'linear': 'k_linear / k_linear_bf (forward-Laplacian linear layer: v_mfma_f32_16x16x4_f32, or float32 products as nine '
+                           'v_mfma_f32_16x16x32_bf16 on three-piece bf16 splits where option linear_bf selects them)',
                  'fused_psi': 'k_fused2_value (LDS-resident psi evaluation; float32 layers as v_mfma_f32_16x16x32_bf16 x6 on '
                               'three-piece bf16 splits, shallow layers v_mfma_f32_16x16x4_f32)',
                  'fused_substep': 'k_fused2_value (one launch per Metropolis sub-step: propose + LDS-resident psi + determinants + '

@@ -76,6 +76,18 @@ __device__ __forceinline__ TileId tile_of_block() {
   return t;
 }
 
+#ifdef DQMC_LIN_PROBE
+#define LIN_PROBE(a, bit) (((a).cfg_probe >> (bit)) & 1)
+template <typename real> static LinArgs<real> with_probe(const LinArgs<real>& a0) {      // (host: the probe bits of this process)
+  LinArgs<real> a = a0;
+  static const int pr = getenv("DQMC_LIN_PROBE") ? atoi(getenv("DQMC_LIN_PROBE")) : 0;
+  a.cfg_probe = pr;
+  return a;
+}
+#else
+#define LIN_PROBE(a, bit) 0
+#endif
+
 // A wave-uniform element offset into scalar registers: base (a kernel argument) + offset is then the SGPR base of the global
 // loads / stores, which take a 32-bit lane offset on top; values the compiler merely knows to be uniform stay in vector
 // registers and every access pays a 64-bit vector add.
@@ -637,6 +649,10 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = acc_t{0, 0, 0, 0};
 
+#ifdef DQMC_LIN_PROBE
+  if ((a.cfg_probe >> 4) && (((blockIdx.x + blockIdx.y * gridDim.x) >> 8) & 1) && (blockIdx.x + blockIdx.y * gridDim.x) < 512)
+    for (int z = 0; z < (a.cfg_probe >> 4); ++z) __builtin_amdgcn_s_sleep(127);
+#endif
   for (int p = 0; p < a.n_pieces; ++p) {
     const LinPiece<real> pc = a.piece[p];
     const int w_row0 = pc.w_row;   // first W row of the current piece
@@ -669,7 +685,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
             } else {
               ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
             }
-          } else if (a_src[j] != nullptr && k0 < pc.K) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
+          } else if (a_src[j] != nullptr && k0 < pc.K && !LIN_PROBE(a, 2)) ra[j][x] = *reinterpret_cast<const Vec4<real>*>(a_src[j] + k0);
           else ra[j][x] = Vec4<real>{{0, 0, 0, 0}};
         }
 #pragma unroll
@@ -685,7 +701,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
     };
     load_chunk(0);
     for (int kc = 0; kc < n_chunks; ++kc) {
-      __syncthreads();  // previous chunk's fragments have been read
+      if (!LIN_PROBE(a, 3)) __syncthreads();  // previous chunk's fragments have been read
 #pragma unroll
       for (int j = 0; j < APT; ++j)
 #pragma unroll
@@ -702,7 +718,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
           *reinterpret_cast<Vec4<real>*>(&Bs[k * BS + 4 * n4]) = Vec4<real>{{rb_[j][0], rb_[j][1], rb_[j][2], rb_[j][3]}};
         }
       }
-      __syncthreads();
+      if (!LIN_PROBE(a, 3)) __syncthreads();
       if (kc + 1 < n_chunks) load_chunk(kc + 1);  // prefetch while the MFMAs run
       // float32: every chunk of 16 / 32 k is summed into a FRESH accumulator and its result added to the running sum.  The MFMA rounds
       // its accumulator once per k-step of 4, and in one long chain each of those K / 4 roundings is as large as the sum has grown;
@@ -717,6 +733,7 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
 #pragma unroll
           for (int j = 0; j < NR; ++j) part[FRESH ? i : 0][FRESH ? j : 0] = acc_t{0, 0, 0, 0};
       }
+      if (!LIN_PROBE(a, 0))
 #pragma unroll
       for (int kk = 0; kk < BK / 4; ++kk) {
         const int kcol = kk * 4 + (lane >> 4);
@@ -745,6 +762,17 @@ __global__ void __launch_bounds__(256 * WN, GPW == -2 ? 2 : (GPW == 0 && NR == 4
   }
 
   if (!CHAIN) {
+#ifdef DQMC_LIN_PROBE
+    if (LIN_PROBE(a, 1)) {      // (the accumulators stay live through a store that never happens)
+      real t = 0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+      if (t == (real)12345.678) a.dst[0] = t;
+      return;
+    }
+#endif
     HbmSink<real> sink(a);
     lin_epilogue<real, MR, NR, GPW>(acc, a, a.bias, a.act, a.ldw, a.pre, col_blk0 + wn * (16 * NR), wm, n_groups, sink, bx, As);
     return;
@@ -1154,7 +1182,12 @@ template <typename real, int MR, int GPW> static void launch_chain_nr(hipStream_
 bool linear_chain_supported(int TP, int ldw_hidden, int ldw_out) {
   return (TP == 1 || TP == 8 || TP == 16 || TP == 32) && ldw_hidden <= 64 && ldw_out <= 32;
 }
-template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a) {
+template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a_in) {
+#ifdef DQMC_LIN_PROBE
+  const LinArgs<real> a = with_probe(a_in);
+#else
+  const LinArgs<real>& a = a_in;
+#endif
   switch (a.TP) {
     case 1: launch_chain_nr<real, 1, 0>(st, a); break;
     case 8: launch_chain_nr<real, 1, -1>(st, a); break;
@@ -1190,7 +1223,12 @@ template <typename real, int MRH> static bool launch_split(hipStream_t st, const
   return false;
 }
 
-template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a) {
+template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a_in) {
+#ifdef DQMC_LIN_PROBE
+  const LinArgs<real> a = with_probe(a_in);
+#else
+  const LinArgs<real>& a = a_in;
+#endif
   switch (a.TP) {
     case 1: {
       // value-only rows (Metropolis sub-steps of the larger ansatzes): small batches would leave CUs idle with

@@ -69,6 +69,11 @@ template <typename real> struct LinArgs {
   // read on the host by launch_linear only): per launch, so that contexts -- a float32 engine and its float64 twin,
   // contexts of other threads -- do not steer each other and a captured pass keeps what its own context chose
   int cfg_bf, cfg_bkx, cfg_f64_split;
+#ifdef DQMC_LIN_PROBE
+  // ablation hooks of tools/probe_lin.sh (a build with -DDQMC_LIN_PROBE only, never the product): bit 0 no MFMAs, 1 no epilogue,
+  // 2 no A-tile loads, 3 no barriers in the K loop; from bit 4 up: s_sleep units for the second workgroup of every CU at launch
+  int cfg_probe;
+#endif
 };
 template <typename real> void launch_linear(hipStream_t st, const LinArgs<real>& a);
 template <typename real> void launch_linear_chain(hipStream_t st, const LinArgs<real>& a);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# (investigation aid) ablation timings of k_linear with a PROBE build of the library (kernel_linear.hip compiled with the cfg_probe hooks:
+# (investigation aid) ablation timings of k_linear with the PROBE build of the library (tools/build_probe_lib.sh: -DDQMC_LIN_PROBE hooks of kernel_linear.hip:
 # 1 no MFMAs, 2 no epilogue, 4 no A-tile loads, 8 no barriers): tools/probe_lin.sh probe.so "0 1 2 4 8 ..."
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; ROOT=$(pwd)
 cp deepqmc_amd/csrc/libdqmc_hip.so /tmp/keep.so; cp $1 deepqmc_amd/csrc/libdqmc_hip.so
