@@ -530,8 +530,8 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
                 const int row = Mfma<real>::row_of(lane, rg);
                 const int t = tb * 16 + row;
                 const real x = acc[gj * GB + tb][n][rg];
-                // (ONE fused multiply-add on every lane: with d1 x rounded on its own and d2 S added afterwards the Laplacian lane pays a
-                // rounding more per layer -- N2 / FermiNet: 12.6 % -> 17.4 % of the walkers re-evaluated in float64)
+                // (ONE fused multiply-add on every lane, whatever the compiler would contract: d1 x rounded on its own with d2 S added
+                // afterwards would cost the Laplacian lane a rounding more per layer)
                 real o = r_fma<real>(d1, x, t == Tm1 ? d2S : (real)0);
                 if (t == 0) o = y;
                 if (t > Tm1) o = 0;
