@@ -288,6 +288,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
       const bool ok0 = g0 < n_groups, ok1 = g0 + 1 < n_groups;      // wave-uniform
       if (!ok0) {
         if constexpr (Sink::fills) {
+          sink.ugroup2(0, false, col_w0);         // (LdsSink: the column base of the zero fill)
 #pragma unroll
           for (int n = 0; n < NR; ++n)
 #pragma unroll
@@ -457,6 +458,7 @@ __device__ __forceinline__ void lin_epilogue(typename Mfma<real>::acc_t (&acc)[M
       const int g = (bx * 4 + wmu) * GPW + gj;
       if (g >= n_groups) {                       // wave-uniform
         if constexpr (Sink::fills) {
+          sink.ugroup(0, col_w0);                // (LdsSink: the column base of the zero fill)
 #pragma unroll
           for (int n = 0; n < NR; ++n)
 #pragma unroll
